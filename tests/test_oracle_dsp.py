@@ -1,0 +1,311 @@
+"""Oracle checks for the dsp/ rows of SURVEY.md §8a.
+
+What the reference pins (and is mirrored here): binToSpectrumIndex
+(dsp/fft_test.go:10-29), FrequencyMapping (dsp/fft_test.go:31-50), Goertzel
+blocksize law (dsp/dsp_test.go:151-161), PeaksTable (rx/peaks_test.go).
+What it does NOT pin (parity unpinned): FFT values, PSD, MagnitudeIndB,
+FindNoiseFloor, FindPeaks — those are cross-checked against numpy float64 and
+against literal Python re-readings of the Go loops.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+
+@pytest.mark.parametrize("bin_,expected", [(0, 256), (1, 257), (255, 511), (256, 0), (257, 1), (511, 255)])
+def test_bin_to_spectrum_index(bin_, expected):
+    assert orc.lib().orc_bin_to_spectrum_index(bin_, 512) == expected  # dsp/fft_test.go:16-21
+
+
+@pytest.mark.parametrize("bin_,center", [(0, 7020000 - 24000), (256, 7020000)])
+def test_frequency_mapping(bin_, center):
+    L = orc.lib()  # dsp/fft_test.go:31-50
+    assert L.orc_frequency_to_bin(48000, 512, 7020000, center) == bin_
+    assert L.orc_bin_to_frequency(48000, 512, 7020000, bin_, 0.0) == center
+
+
+def test_go_log10_matches_libm():
+    rng = np.random.default_rng(1)
+    xs = np.concatenate([10.0 ** rng.uniform(-30, 30, 20000), [1.0, 2.0, 0.5, 10.0, 100.0, 1e-300, 1e300]])
+    got = np.array([orc.go_log10(float(x)) for x in xs])
+    ref = np.log10(xs)
+    # Go computes log2 as Log(frac)*(1/Ln2)+exp, which cancels near x ~ 1: the error is bounded in
+    # absolute terms (a few 1e-17), not in ulps of a tiny result — so bound it by ulp(max(|ref|, 1))
+    ulp = np.spacing(np.maximum(np.abs(ref), 1.0))
+    assert np.max(np.abs(got - ref) / ulp) <= 2.0
+    assert orc.go_log10(0.0) == -math.inf
+    assert math.isnan(orc.go_log10(-1.0))
+    assert orc.go_log10(1.0) == 0.0 and orc.lib().orc_go_log2(8.0) == 3.0
+
+
+def test_go_sincos_matches_libm():
+    rng = np.random.default_rng(2)
+    xs = np.concatenate([rng.uniform(-2 * np.pi, 2 * np.pi, 20000), [0.0, -np.pi / 2, -np.pi, -np.pi / 4]])
+    worst = 0.0
+    for x in xs:
+        s, c = orc.go_sincos(float(x))
+        worst = max(worst, abs(s - math.sin(x)), abs(c - math.cos(x)))
+    assert worst <= 2.3e-16  # within ~1 ulp at |value| <= 1
+
+
+@pytest.mark.parametrize("n", [4, 8, 512, 4096, 16384])
+def test_radix2_factors(n):
+    w = orc.radix2_factors(n)
+    k = np.arange(n)
+    ref = np.exp(-2j * np.pi * k / n)
+    assert np.max(np.abs(w - ref)) < 3e-16
+    assert w[0] == 1 and w[n // 4] == -1j and w[n // 2] == -1 and w[3 * n // 4] == 1j  # literal size-4 table
+
+
+@pytest.mark.parametrize("n", [2, 8, 512, 4096, 8192, 16384])
+def test_fft_against_numpy(n):
+    rng = np.random.default_rng(n)
+    iq = rng.standard_normal(2 * n).astype(np.float32)
+    got = orc.iq_fft(iq)
+    x = iq[0::2].astype(np.float64) + 1j * iq[1::2].astype(np.float64)
+    ref = np.fft.fft(x)
+    assert np.max(np.abs(got - ref)) <= 1e-12 * np.max(np.abs(ref))
+
+
+def test_fft_single_tone_is_exact_bin():
+    n = 512
+    t = np.arange(n)
+    b = 37
+    x = 0.1 * np.exp(2j * np.pi * b * t / n)
+    iq = np.empty(2 * n, np.float32)
+    iq[0::2], iq[1::2] = x.real, x.imag
+    y = orc.iq_fft(iq)
+    assert np.argmax(np.abs(y)) == b
+    assert abs(abs(y[b]) - 0.1 * n) < 1e-4
+
+
+def _projection_py(y, n):
+    """Literal re-reading of dsp/fft.go:32-36,71-81 + receiver.go:376-378 with numpy scalars."""
+    sp = np.empty(n, np.float32)
+    psd = np.empty(n, np.float32)
+    for i in range(n):
+        k = (i + n // 2) % n
+        p = np.float32(y[i].real * y[i].real + y[i].imag * y[i].imag)
+        psd[k] = p
+        db = np.float32(10.0 * orc.go_log10(20.0 * float(p) / float(n) ** 2)) if p > 0 else np.float32(-np.inf)
+        sp[k] = np.float32(db + np.float32(120))
+    return sp, psd
+
+
+def test_projection_literal():
+    n = 512
+    rng = np.random.default_rng(7)
+    iq = (1e-3 * rng.standard_normal(2 * n)).astype(np.float32)
+    sp, psd = orc.iq_to_spectrum_and_psd(iq)
+    sp2, psd2 = _projection_py(orc.iq_fft(iq), n)
+    assert np.array_equal(psd, psd2) and np.array_equal(sp, sp2)
+    # and against libm log10 within float32 rounding (<= 1 ulp of f32)
+    ref = (10 * np.log10(20.0 * psd.astype(np.float64) / n ** 2)).astype(np.float32) + np.float32(120)
+    assert np.max(np.abs(sp - ref)) <= np.spacing(np.float32(64.0))
+
+
+def _find_noise_floor_py(psd, edge):
+    """Literal re-reading of dsp/fft.go:215-252."""
+    n = len(psd)
+    window = (n - 2 * edge) // 10
+    min_value = float(psd[0])
+    s = 0.0
+    count = 0
+    first = True
+    from_ = 0
+    result_mean = 0.0
+    result_from = result_to = 0
+    for i in range(edge, n - edge):
+        if count == 0:
+            from_ = i
+        if count == window:
+            count = 0
+            mean = s / float(window)
+            if mean < min_value or first:
+                min_value, first, result_mean, result_from, result_to = mean, False, mean, from_, i
+            s = 0.0
+        s += float(psd[i])
+        count += 1
+    s = 0.0
+    for i in range(result_from, result_to + 1):
+        d = float(psd[i]) - result_mean
+        s += d * d
+    return np.float32(min_value), s / float(window), result_from, result_to
+
+
+@pytest.mark.parametrize("n,edge", [(512, 70), (512, 0), (4096, 560), (512, 100)])
+def test_find_noise_floor_literal(n, edge):
+    rng = np.random.default_rng(n + edge)
+    psd = rng.exponential(1.0, n).astype(np.float32)
+    psd[n // 3] = 1e6  # a tone before most windows: shows up in the quirky variance
+    m, v = orc.find_noise_floor(psd, edge)
+    m2, v2, rf, rt = _find_noise_floor_py(psd, edge)
+    assert m == m2 and v == v2
+    assert rf == edge  # resultFrom is always edgeWidth
+
+
+def test_find_noise_floor_degenerate_window_is_nan():
+    # N - 2*edge < 10 -> windowSize 0 -> NaN (SURVEY §7 hard parts); the C-ABI must reject such configs
+    psd = np.ones(512, np.float32)
+    m, v = orc.find_noise_floor(psd, 252)
+    assert math.isnan(v)
+
+
+def _find_peaks_py(cum, size, thr):
+    peaks, cur = [], None
+    thr = np.float32(thr)
+    for i, v in enumerate(cum):
+        value = np.float32(v) / np.float32(size)
+        if cur is None and value > thr:
+            cur = [i, i, value, i]
+        elif cur is not None and value <= thr:
+            cur[1] = i - 1
+            peaks.append(tuple(cur))
+            cur = None
+        elif cur is not None and cur[2] < value:
+            cur[2], cur[3] = value, i
+    if cur is not None:
+        cur[1] = len(cum) - 1
+        peaks.append(tuple(cur))
+    return peaks
+
+
+def test_find_peaks_literal():
+    n = 512
+    rng = np.random.default_rng(3)
+    cum = (rng.uniform(3000, 4000, n)).astype(np.float32)
+    for b, w in [(0, 2), (100, 1), (200, 5), (300, 3), (510, 2)]:  # runs at both array ends too
+        cum[b:b + w] = 9000 + np.arange(w) * (1 if b != 300 else 0)  # 300: equal maxima -> first bin wins
+    got = orc.find_peaks(cum, 60.0, 48000, 7020000)
+    ref = _find_peaks_py(cum, 100, 60.0)
+    assert [(p[0], p[1], np.float32(p[5]), p[6]) for p in got] == [(a, b, v, sb) for a, b, v, sb in ref]
+    assert got[-1][1] == n - 1  # open run closed at N-1 (dsp/fft.go:276-282)
+    assert [p for p in got if p[0] == 300][0][6] == 300
+    # frequencies: BinToFrequency with BinFrom/BinTo and the quadratic correction
+    bs = 48000 / n
+    for p in got:
+        assert p[2] == 7020000 - 24000 + int(p[0] * bs + bs * -0.5)
+        assert p[3] == 7020000 - 24000 + int(p[1] * bs + bs * 0.5)
+
+
+def test_peak_center_correction():
+    sp = np.array([1, 2, 4, 3, 1], np.float32)
+    L = orc.lib()
+    import ctypes as C
+    ptr = sp.ctypes.data_as(C.POINTER(C.c_float))
+    assert L.orc_peak_center_correction(2, ptr, 5) == (3 - 2) / (2 * (2 * 4 - 2 - 3))
+    assert L.orc_peak_center_correction(0, ptr, 5) == 0 and L.orc_peak_center_correction(4, ptr, 5) == 0
+
+
+def test_rolling_mean_is_f32_running_sum():
+    L = orc.lib()  # dsp/dsp.go:257-268; the first n-1 means are biased low (App. C8)
+    h = L.orc_rolling_mean_new(60)
+    rng = np.random.default_rng(5)
+    xs = rng.uniform(30, 50, 300).astype(np.float32)
+    ring = np.zeros(60, np.float32)
+    s = np.float32(0)
+    nxt = 0
+    for x in xs:
+        s = np.float32(s - ring[nxt])
+        ring[nxt] = x
+        s = np.float32(s + x)
+        nxt = (nxt + 1) % 60
+        assert L.orc_rolling_mean_put(h, x) == np.float32(s / np.float32(60))
+    L.orc_rolling_mean_free(h)
+
+
+def test_goertzel_blocksize_law():
+    L = orc.lib()  # dsp/dsp_test.go:151-161 and SURVEY §3.4
+    assert L.orc_goertzel_blocksize(700.0, 48000, 0.005) == 207
+    for f in range(301, 24000, 7):
+        bs = L.orc_goertzel_blocksize(float(f), 48000, 0.005)
+        assert abs(bs / 48000 - 0.005) <= 0.0017
+    a = orc.AudioDemodulator(700.0, 48000)
+    assert a.blocksize == 207 and abs(a.coeff - 1.99171368506) < 1e-11
+
+
+def _tone(sr, f, n, amp=1.0):
+    t = np.arange(n) / sr
+    return (amp * np.cos(2 * np.pi * f * t)).astype(np.float32)
+
+
+def test_goertzel_signal_state_properties():
+    # dsp/dsp_test.go:25-149 (property tests): on pitch detected; half pitch, silence, DC not
+    sr = 48000
+    a = orc.AudioDemodulator(700.0, sr)
+    a.set_scale(1.0)
+    mags, raw, _ = a.write(_tone(sr, 700.0, a.blocksize * 10))
+    assert raw.all()
+    for sig in (_tone(sr, 350.0, 2070), np.zeros(2070, np.float32), np.ones(2070, np.float32)):
+        b = orc.AudioDemodulator(700.0, sr)
+        b.set_scale(1.0)
+        _, raw, _ = b.write(sig)
+        assert not raw.any()
+
+
+def test_audio_demodulator_decodes_keyed_tone():
+    # BASELINE config 1 plumbing: 48 kHz mono, 700 Hz tone keyed with Morse at 20 WPM -> text
+    sr = 48000
+    a = orc.AudioDemodulator(700.0, sr)
+    a.set_scale(0.0)  # autoscale path, cw/audio.go:184-193
+    bs = a.blocksize
+    keying = orc.generate_stream(sr, bs, 20, "cq de dl1abc")
+    env = np.repeat(keying, bs).astype(np.float32)
+    sig = 0.8 * _tone(sr, 700.0, env.size) * env
+    a.write(sig)
+    a.close()
+    assert a.text() == "cq de dl1abc"
+
+
+# ---- rx/peaks_test.go ---------------------------------------------------------------------
+
+def test_peaks_table_put_into_empty():
+    t = orc.PeaksTable(512)
+    e = t.put(234, 235)
+    assert t.at(234) == e and t.at(235) == e and t.state(e) == t.NEW
+
+
+def test_peaks_table_put_overlap_rules():
+    t = orc.PeaksTable(12)  # rx/peaks_test.go:28-72
+    p1 = t.place(3, 4, t.NEW)
+    p2 = t.place(5, 6, t.NEW)
+    p3 = t.place(8, 8, t.ACTIVE)
+    p4 = t.place(10, 10, t.INACTIVE)
+    n1, n2, n3, n4 = t.put(1, 2), t.put(4, 5), t.put(7, 8), t.put(10, 11)
+    assert n3 == -1 and n4 == -1
+    assert [t.at(i) for i in range(12)] == [-1, n1, n1, -1, n2, n2, -1, -1, p3, -1, p4, -1]
+    assert p1 != n2 and p2 != n2
+
+
+def test_peaks_table_cleanup():
+    t = orc.PeaksTable(512)  # rx/peaks_test.go:74-124
+    t.set_now(1000.0)
+    e = t.put(234, 235)
+    t.cleanup()
+    assert t.at(234) == e
+    t.set_now(1000.0 + 121.0)
+    t.cleanup()
+    assert t.at(234) == -1 and t.at(235) == -1
+    t2 = orc.PeaksTable(512)
+    t2.set_now(0.0)
+    e = t2.put(234, 235)
+    t2.activate(234, 235)
+    t2.set_now(121.0)
+    t2.cleanup()
+    assert t2.at(234) == e
+    t2.deactivate(234, 235)
+    t2.cleanup()
+    assert t2.at(234) == -1
+
+
+def test_peaks_table_find_next():
+    t = orc.PeaksTable(512)  # rx/peaks_test.go:126-143
+    e = t.put(234, 235)
+    assert t.find_next() == e
+    t.activate(234, 235)
+    assert t.find_next() == -1
+    t.deactivate(234, 235)
+    assert t.find_next() == -1
