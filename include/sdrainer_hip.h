@@ -1,0 +1,209 @@
+/*
+ * sdrainer_hip.h — C ABI of libsdrainer_hip.so, the MI355X (gfx950) implementation of sdrainer's
+ * per-block IQ-strainer DSP.  This is the drop-in boundary: plain pointers and sizes, no C++ or
+ * framework types.  A Go maintainer binds it with cgo behind rx.Receiver / rx.Listener
+ * (INTEGRATION.md shows the stub); this repo's C++ host mirror (sdrainer_amd/csrc/host/) and its
+ * Python tests bind exactly the same symbols.
+ *
+ * One `sdr_bank` = n_bands independent receivers of identical geometry (sample rate, block size) on
+ * one GPU and one HIP stream.  A band is what the reference calls a Receiver: it owns its rolling
+ * noise floor, cumulation, listeners and decoders and shares nothing with other bands
+ * (rx/receiver.go:64-91), which is what makes bands shardable across GPUs.
+ *
+ * Reference interface each entry point replaces (paths relative to the reference checkout):
+ *   sdr_create / sdr_destroy        rx.NewReceiver + Receiver.Start / Stop      rx/receiver.go:93,130,148
+ *   sdr_push_iq                     Receiver.IQData(sampleRate, []float32)      rx/receiver.go:315-334
+ *   sdr_process_staged              the frame case of Receiver.run              rx/receiver.go:353-463
+ *   sdr_process_device              same, for IQ already resident in HBM (the "IQ ring buffer")
+ *   sdr_attach / sdr_detach         ListenerPool.BindNext + Listener.Attach / Detach + Release
+ *                                                                               rx/listener.go:84-108,214-248
+ *   sdr_set_peak_threshold          Receiver.SetPeakThreshold                   rx/receiver.go:208-212
+ *   sdr_set_edge_width              Receiver.SetEdgeWidth                       rx/receiver.go:214-218
+ *   sdr_set_signal_debounce         Receiver.SetSignalDebounce                  rx/receiver.go:238-244
+ *   sdr_set_center_frequency        Receiver.SetCenterFrequency                 rx/receiver.go:246-253
+ *   sdr_read_peaks                  the []dsp.Peak of dsp.FindPeaks             dsp/fft.go:179-188,254-285
+ *   sdr_read_text                   the io.Writer each Listener's Decoder writes to  cw/decode.go:352-355
+ *   sdr_read_edges / _trace         what cw.SpectralDemodulator.Tick hands to Decoder.Tick  cw/spectral.go:48-54
+ *   sdr_read_frame_records          locals of Receiver.run (noise floor, thresholds)  rx/receiver.go:381-385
+ *   sdr_audio_*                     cw.AudioDemodulator (Goertzel audio path)   cw/audio.go:37-211
+ *
+ * Semantics kept from the reference: setters take effect between frames, never mid-frame (here: at
+ * the next process call, rx/receiver.go:166-172); wrong sample rate / block size / a full queue do
+ * not abort anything, the call returns a status the shim maps to the reference's log-and-drop
+ * (rx/receiver.go:319-333).  The one semantic extension is batching: a process call consumes many
+ * frames per band, in order.
+ *
+ * Threading: a bank is single-producer (like the reference's run goroutine, all DSP state is owned
+ * by one thread); different banks are independent.
+ */
+#ifndef SDRAINER_HIP_H
+#define SDRAINER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDR_ABI_VERSION 1
+
+/* status codes */
+#define SDR_OK 0
+#define SDR_ERR_BAD_ARG 1    /* null pointer, index out of range, unsupported geometry            */
+#define SDR_ERR_BAD_RATE 2   /* wrong incoming sample rate  -> reference logs + drops (:319-322)  */
+#define SDR_ERR_BAD_SIZE 3   /* wrong incoming block size   -> reference logs + drops (:323-326)  */
+#define SDR_ERR_WOULD_DROP 4 /* staging queue full          -> reference logs + drops (:328-333)  */
+#define SDR_ERR_HIP 5        /* a HIP runtime call failed; sdr_last_error() has the text          */
+#define SDR_ERR_NO_SLOT 6    /* listener pool exhausted (rx/listener.go:214-217)                  */
+#define SDR_ERR_STATE 7      /* call not valid in the current state                               */
+
+/* rx/receiver.go:15-27 */
+#define SDR_CUMULATION_SIZE 100
+#define SDR_NOISE_WINDOW 60
+#define SDR_DBM_SHIFT 120
+#define SDR_DEFAULT_PEAK_THRESHOLD 15.0f
+#define SDR_DEFAULT_EDGE_WIDTH 70
+#define SDR_DEFAULT_LISTENER_POOL_SIZE 30
+
+typedef struct sdr_bank sdr_bank;
+
+typedef struct sdr_config {
+    int32_t struct_size;      /* = sizeof(sdr_config), ABI guard                                  */
+    int32_t n_bands;          /* independent receivers in this bank                               */
+    int32_t sample_rate;      /* Receiver.Start(sampleRate, blockSize)                            */
+    int32_t block_size;       /* complex samples per frame; power of two in [512, 16384]          */
+    int32_t edge_width;       /* bins ignored at both spectrum edges (default 70)                 */
+    float peak_threshold;     /* dB over the noise floor for the peak scan (default 15)           */
+    int32_t signal_debounce;  /* BoolDebouncer threshold of new listeners (default 1)             */
+    int32_t max_listeners;    /* listener pool size per band (reference: 30 strain / 1 decode)    */
+    int32_t max_batch_frames; /* capacity: frames per band per process call                       */
+    int32_t max_peaks;        /* capacity: peaks reported per completed cumulation                */
+    int32_t find_peaks;       /* 1: run FindPeaks on every completed 100-frame cumulation         */
+    int32_t trace;            /* 1: keep per-frame value / raw / debounced traces (parity, scope) */
+    int32_t device_id;        /* HIP device ordinal                                               */
+    int32_t reserved;
+} sdr_config;
+
+/* dsp.Peak[float32,int] (dsp/fft.go:179-188), fixed-width */
+typedef struct sdr_peak {
+    int32_t from, to;
+    int64_t from_frequency, to_frequency, signal_frequency;
+    float signal_value;
+    int32_t signal_bin;
+} sdr_peak;
+
+/* per-frame locals of Receiver.run (rx/receiver.go:381-385,394) */
+typedef struct sdr_frame_rec {
+    float min_mean;    /* FindNoiseFloor: T(minValue)                      */
+    float dev_in;      /* value put into noiseDeviationMean                */
+    double variance;   /* FindNoiseFloor: variance                         */
+    float nf_in;       /* value put into noiseFloorMean                    */
+    float noise_dev;   /* noiseDeviation                                   */
+    float noise_floor; /* noiseFloor                                       */
+    float peak_thr;    /* peakThreshold = r.peakThreshold + noiseFloor     */
+    float listen_thr;  /* noiseFloor + noiseDeviation (Listener.Listen)    */
+    float pad;
+} sdr_frame_rec;
+
+/* one keying edge of a listener: debounced state changed at this frame (counted from bank start) */
+typedef struct sdr_edge {
+    uint32_t frame;
+    uint32_t state; /* 1 = key down */
+} sdr_edge;
+
+const char *sdr_last_error(void);
+int sdr_abi_version(void);
+
+/* lifecycle ---------------------------------------------------------------------------------- */
+int sdr_create(const sdr_config *cfg, sdr_bank **out);
+int sdr_destroy(sdr_bank *bank);
+/* Run on this hipStream_t (NULL = the null stream).  Must be called before the first process call
+ * or while the bank is idle. */
+int sdr_set_stream(sdr_bank *bank, void *hip_stream);
+
+/* producer side ------------------------------------------------------------------------------ */
+/* Copies n_floats/(2*block_size) interleaved I,Q float32 frames of `band` from host memory into the
+ * bank's pinned staging queue (the input is borrowed only for the duration of the call). */
+int sdr_push_iq(sdr_bank *bank, int band, int sample_rate, const float *iq, size_t n_floats);
+/* Frames currently staged for `band`. */
+int sdr_staged_frames(sdr_bank *bank, int band);
+/* Uploads and processes min-over-bands staged frames; *n_frames_out = frames consumed per band. */
+int sdr_process_staged(sdr_bank *bank, int *n_frames_out);
+/* Processes n_frames per band of IQ already in device memory, layout [band][frame][block_size][2]
+ * float32 (band stride = n_frames*2*block_size floats).  Asynchronous on the bank's stream. */
+int sdr_process_device(sdr_bank *bank, const float *iq_dev, int n_frames);
+/* Blocks until everything queued on the bank's stream has finished. */
+int sdr_sync(sdr_bank *bank);
+
+/* per-signal entry --------------------------------------------------------------------------- */
+/* Binds a fresh listener (new debouncer + new decoder, Reset) to spectrum bin `bin` of `band`,
+ * effective from the next processed frame. */
+int sdr_attach(sdr_bank *bank, int band, int bin, int *listener_id);
+int sdr_detach(sdr_bank *bank, int band, int listener_id);
+int sdr_listener_count(sdr_bank *bank, int band);
+/* Flush the listener's pending character (cw.Decoder.stop, cw/decode.go:352-354). */
+int sdr_listener_stop(sdr_bank *bank, int band, int listener_id);
+
+/* control ------------------------------------------------------------------------------------ */
+int sdr_set_peak_threshold(sdr_bank *bank, int band, float threshold);
+int sdr_set_edge_width(sdr_bank *bank, int edge_width);
+int sdr_set_signal_debounce(sdr_bank *bank, int band, int debounce);
+int sdr_set_center_frequency(sdr_bank *bank, int band, int64_t frequency);
+int sdr_set_find_peaks(sdr_bank *bank, int on);
+
+/* consumer side (all synchronise with the stream first) --------------------------------------- */
+/* Frames per band consumed by the last process call / since bank creation. */
+int sdr_last_batch_frames(sdr_bank *bank);
+int64_t sdr_total_frames(sdr_bank *bank);
+/* Number of 100-frame cumulations completed by the last process call. */
+int sdr_last_batch_chunks(sdr_bank *bank);
+/* Peaks of completed cumulation `chunk` (0-based within the last batch).  *frame_in_batch = index
+ * of the frame that completed it. */
+int sdr_read_peaks(sdr_bank *bank, int band, int chunk, sdr_peak *out, int max, int *n_out, int *frame_in_batch);
+/* Cumulated spectrum (sum over 100 frames, float32[block_size]) of that chunk. */
+int sdr_read_cumulation(sdr_bank *bank, int band, int chunk, float *out);
+/* Decoded text of a listener since the last read, UTF-8 (what the reference writes to io.Writer). */
+int sdr_read_text(sdr_bank *bank, int band, int listener_id, char *out, int max_bytes, int *n_bytes);
+/* Keying edges of a listener produced by the last process call. */
+int sdr_read_edges(sdr_bank *bank, int band, int listener_id, sdr_edge *out, int max, int *n_out);
+/* Packed debounced on/off bits of the last batch: bit (f & 63) of word (f >> 6). */
+int sdr_read_keying_bits(sdr_bank *bank, int band, int listener_id, uint64_t *out, int max_words);
+int sdr_read_frame_records(sdr_bank *bank, int band, sdr_frame_rec *out, int max);
+/* trace == 1 only: per-frame value handed to Listen, raw and debounced state of a listener. */
+int sdr_read_trace(sdr_bank *bank, int band, int listener_id, float *values, uint8_t *raw, uint8_t *debounced, int max);
+/* spectrum (dB+120, fftshifted) and psd of frame `frame` of the last batch, float32[block_size] each. */
+int sdr_read_spectrum(sdr_bank *bank, int band, int frame, float *spectrum, float *psd);
+/* cw.Decoder state of a listener: ticks, onStart, offStart, wpm, on{low,high,last,thr}, off{...}. */
+int sdr_read_decoder_state(sdr_bank *bank, int band, int listener_id, double *out12);
+
+/* measurement ------------------------------------------------------------------------------- */
+/* When enabled every kernel launch is bracketed by HIP events on the bank's stream. */
+int sdr_profile_enable(sdr_bank *bank, int on);
+/* kernel: 0 fft_project, 1 window_means, 2 noise_stats, 3 thresholds, 4 listen_decode,
+ *         5 cumulate, 6 find_peaks.  Returns accumulated milliseconds and launch count. */
+int sdr_profile_read(sdr_bank *bank, int kernel, double *total_ms, int *launches);
+int sdr_profile_reset(sdr_bank *bank);
+const char *sdr_kernel_name(int kernel);
+
+/* audio path (cw/audio.go): n_streams mono float32 streams, one Goertzel + debouncer + decoder each */
+typedef struct sdr_audio sdr_audio;
+int sdr_audio_create(int n_streams, double pitch, int sample_rate, int max_blocks, int device_id, sdr_audio **out);
+int sdr_audio_destroy(sdr_audio *a);
+int sdr_audio_blocksize(sdr_audio *a);
+int sdr_audio_set_scale(sdr_audio *a, double scale);             /* 0 = autoscale (audio.go:184-187) */
+int sdr_audio_set_debounce(sdr_audio *a, int threshold);          /* default 3 (audio.go:18)          */
+int sdr_audio_set_magnitude_threshold(sdr_audio *a, double t);    /* default 0.75 (dsp.go:12)         */
+/* Feed n_samples mono float32 samples per stream (host memory, layout [stream][n_samples]); whole
+ * Goertzel blocks are processed, the remainder is kept for the next call (audio.go:175-179). */
+int sdr_audio_write(sdr_audio *a, const float *samples, int n_samples);
+int sdr_audio_close(sdr_audio *a);                                /* decoder.stop (audio.go:205-207)  */
+int sdr_audio_read_text(sdr_audio *a, int stream, char *out, int max_bytes, int *n_bytes);
+/* per-block normalised magnitude / raw / debounced state of the last write (parity) */
+int sdr_audio_read_trace(sdr_audio *a, int stream, double *magnitudes, uint8_t *raw, uint8_t *debounced, int max,
+                         int *n_blocks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDRAINER_HIP_H */

@@ -1,0 +1,377 @@
+"""ctypes binding of libsdrainer_hip.so — the same C ABI (include/sdrainer_hip.h) a cgo shim binds.
+
+There is no CPU implementation behind this module: if the HIP library is missing or fails to load,
+importing raises.  PyTorch is only used by callers for device memory / streams; the ABI takes raw
+device pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsdrainer_hip.so")
+
+OK, ERR_BAD_ARG, ERR_BAD_RATE, ERR_BAD_SIZE, ERR_WOULD_DROP, ERR_HIP, ERR_NO_SLOT, ERR_STATE = range(8)
+CUMULATION_SIZE = 100
+KERNELS = ("k_fft_project", "k_window_means", "k_noise_stats", "k_thresholds", "k_listen", "k_cumulate",
+           "k_find_peaks")
+
+
+class SdrError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libsdrainer_hip status {code}: {msg}")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("n_bands", C.c_int32), ("sample_rate", C.c_int32), ("block_size", C.c_int32),
+        ("edge_width", C.c_int32), ("peak_threshold", C.c_float), ("signal_debounce", C.c_int32),
+        ("max_listeners", C.c_int32), ("max_batch_frames", C.c_int32), ("max_peaks", C.c_int32),
+        ("find_peaks", C.c_int32), ("trace", C.c_int32), ("device_id", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class Peak(C.Structure):
+    _fields_ = [
+        ("from_", C.c_int32), ("to", C.c_int32), ("from_frequency", C.c_int64), ("to_frequency", C.c_int64),
+        ("signal_frequency", C.c_int64), ("signal_value", C.c_float), ("signal_bin", C.c_int32),
+    ]
+
+    def astuple(self):
+        return (self.from_, self.to, self.from_frequency, self.to_frequency, self.signal_frequency,
+                float(np.float32(self.signal_value)), self.signal_bin)
+
+
+FRAME_REC_DTYPE = np.dtype([("min_mean", "<f4"), ("dev_in", "<f4"), ("variance", "<f8"), ("nf_in", "<f4"),
+                            ("noise_dev", "<f4"), ("noise_floor", "<f4"), ("peak_thr", "<f4"), ("listen_thr", "<f4"),
+                            ("pad", "<f4")])
+EDGE_DTYPE = np.dtype([("frame", "<u4"), ("state", "<u4")])
+
+_lib = None
+
+# every symbol include/sdrainer_hip.h declares (tests/test_capi_symbols.py checks the header against this)
+SYMBOLS = (
+    "sdr_last_error sdr_abi_version sdr_create sdr_destroy sdr_set_stream sdr_push_iq sdr_staged_frames "
+    "sdr_process_staged sdr_process_device sdr_sync sdr_attach sdr_detach sdr_listener_count sdr_listener_stop "
+    "sdr_set_peak_threshold sdr_set_edge_width sdr_set_signal_debounce sdr_set_center_frequency sdr_set_find_peaks "
+    "sdr_last_batch_frames sdr_total_frames sdr_last_batch_chunks sdr_read_peaks sdr_read_cumulation sdr_read_text "
+    "sdr_read_edges sdr_read_keying_bits sdr_read_frame_records sdr_read_trace sdr_read_spectrum "
+    "sdr_read_decoder_state sdr_profile_enable sdr_profile_read sdr_profile_reset sdr_kernel_name sdr_audio_create "
+    "sdr_audio_destroy sdr_audio_blocksize sdr_audio_set_scale sdr_audio_set_debounce "
+    "sdr_audio_set_magnitude_threshold sdr_audio_write sdr_audio_close sdr_audio_read_text sdr_audio_read_trace"
+).split()
+
+
+def load():
+    """Loads the HIP library.  Fails loudly: there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m sdrainer_amd.csrc.build` (hipcc, gfx950). "
+            "sdrainer_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)
+
+    def sig(name, res, *args):
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = list(args)
+
+    sig("sdr_last_error", C.c_char_p)
+    sig("sdr_abi_version", C.c_int)
+    sig("sdr_create", C.c_int, C.POINTER(Config), C.POINTER(vp))
+    sig("sdr_destroy", C.c_int, vp)
+    sig("sdr_set_stream", C.c_int, vp, vp)
+    sig("sdr_push_iq", C.c_int, vp, C.c_int, C.c_int, fp, C.c_size_t)
+    sig("sdr_staged_frames", C.c_int, vp, C.c_int)
+    sig("sdr_process_staged", C.c_int, vp, ip)
+    sig("sdr_process_device", C.c_int, vp, vp, C.c_int)
+    sig("sdr_sync", C.c_int, vp)
+    sig("sdr_attach", C.c_int, vp, C.c_int, C.c_int, ip)
+    sig("sdr_detach", C.c_int, vp, C.c_int, C.c_int)
+    sig("sdr_listener_count", C.c_int, vp, C.c_int)
+    sig("sdr_listener_stop", C.c_int, vp, C.c_int, C.c_int)
+    sig("sdr_set_peak_threshold", C.c_int, vp, C.c_int, C.c_float)
+    sig("sdr_set_edge_width", C.c_int, vp, C.c_int)
+    sig("sdr_set_signal_debounce", C.c_int, vp, C.c_int, C.c_int)
+    sig("sdr_set_center_frequency", C.c_int, vp, C.c_int, C.c_int64)
+    sig("sdr_set_find_peaks", C.c_int, vp, C.c_int)
+    sig("sdr_last_batch_frames", C.c_int, vp)
+    sig("sdr_total_frames", C.c_int64, vp)
+    sig("sdr_last_batch_chunks", C.c_int, vp)
+    sig("sdr_read_peaks", C.c_int, vp, C.c_int, C.c_int, C.POINTER(Peak), C.c_int, ip, ip)
+    sig("sdr_read_cumulation", C.c_int, vp, C.c_int, C.c_int, fp)
+    sig("sdr_read_text", C.c_int, vp, C.c_int, C.c_int, C.c_char_p, C.c_int, ip)
+    sig("sdr_read_edges", C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, ip)
+    sig("sdr_read_keying_bits", C.c_int, vp, C.c_int, C.c_int, vp, C.c_int)
+    sig("sdr_read_frame_records", C.c_int, vp, C.c_int, vp, C.c_int)
+    sig("sdr_read_trace", C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int)
+    sig("sdr_read_spectrum", C.c_int, vp, C.c_int, C.c_int, vp, vp)
+    sig("sdr_read_decoder_state", C.c_int, vp, C.c_int, C.c_int, C.POINTER(C.c_double))
+    sig("sdr_profile_enable", C.c_int, vp, C.c_int)
+    sig("sdr_profile_read", C.c_int, vp, C.c_int, C.POINTER(C.c_double), ip)
+    sig("sdr_profile_reset", C.c_int, vp)
+    sig("sdr_kernel_name", C.c_char_p, C.c_int)
+    sig("sdr_audio_create", C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(vp))
+    sig("sdr_audio_destroy", C.c_int, vp)
+    sig("sdr_audio_blocksize", C.c_int, vp)
+    sig("sdr_audio_set_scale", C.c_int, vp, C.c_double)
+    sig("sdr_audio_set_debounce", C.c_int, vp, C.c_int)
+    sig("sdr_audio_set_magnitude_threshold", C.c_int, vp, C.c_double)
+    sig("sdr_audio_write", C.c_int, vp, fp, C.c_int)
+    sig("sdr_audio_close", C.c_int, vp)
+    sig("sdr_audio_read_text", C.c_int, vp, C.c_int, C.c_char_p, C.c_int, ip)
+    sig("sdr_audio_read_trace", C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, ip)
+    _lib = L
+    return L
+
+
+def _check(rc: int):
+    if rc != OK:
+        raise SdrError(rc, load().sdr_last_error().decode(errors="replace"))
+
+
+def _vp(a):
+    return C.c_void_p(a.ctypes.data) if a is not None else None
+
+
+class Bank:
+    """A bank of n_bands receivers on one GPU (see include/sdrainer_hip.h)."""
+
+    def __init__(self, sample_rate: int, block_size: int, n_bands: int = 1, edge_width: int | None = None,
+                 peak_threshold: float = 15.0, signal_debounce: int = 1, max_listeners: int = 30,
+                 max_batch_frames: int = 1024, max_peaks: int = 1024, find_peaks: bool = True, trace: bool = False,
+                 device_id: int = 0):
+        L = load()
+        if edge_width is None:
+            edge_width = 70 * block_size // 512  # the reference default (rx/receiver.go:25) scaled with N
+        self.cfg = Config(C.sizeof(Config), n_bands, sample_rate, block_size, edge_width, peak_threshold,
+                          signal_debounce, max_listeners, max_batch_frames, max_peaks, int(find_peaks), int(trace),
+                          device_id, 0)
+        self.n = block_size
+        self.n_bands = n_bands
+        h = C.c_void_p()
+        _check(L.sdr_create(C.byref(self.cfg), C.byref(h)))
+        self._h = h
+        self._L = L
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.sdr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # producer ---------------------------------------------------------------------------------
+    def set_stream(self, stream_ptr: int):
+        _check(self._L.sdr_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def push_iq(self, band: int, sample_rate: int, iq: np.ndarray) -> int:
+        """Returns the status code (0 ok) instead of raising for the reference's log-and-drop cases."""
+        iq = np.ascontiguousarray(iq, dtype=np.float32)
+        rc = self._L.sdr_push_iq(self._h, band, sample_rate, iq.ctypes.data_as(C.POINTER(C.c_float)), iq.size)
+        if rc not in (OK, ERR_BAD_RATE, ERR_BAD_SIZE, ERR_WOULD_DROP):
+            _check(rc)
+        return rc
+
+    def staged_frames(self, band: int) -> int:
+        return self._L.sdr_staged_frames(self._h, band)
+
+    def process_staged(self) -> int:
+        n = C.c_int()
+        _check(self._L.sdr_process_staged(self._h, C.byref(n)))
+        return n.value
+
+    def process_device(self, iq_dev_ptr: int, n_frames: int):
+        _check(self._L.sdr_process_device(self._h, C.c_void_p(iq_dev_ptr), n_frames))
+
+    def process_host(self, iq: np.ndarray) -> int:
+        """iq: float32 [n_bands, n_frames, 2N] (or [n_frames, 2N] for one band) from host memory."""
+        iq = np.ascontiguousarray(iq, dtype=np.float32).reshape(self.n_bands, -1, 2 * self.n)
+        for b in range(self.n_bands):
+            rc = self.push_iq(b, self.cfg.sample_rate, iq[b])
+            if rc != OK:
+                raise SdrError(rc, self._L.sdr_last_error().decode())
+        return self.process_staged()
+
+    def sync(self):
+        _check(self._L.sdr_sync(self._h))
+
+    # listeners --------------------------------------------------------------------------------
+    def attach(self, band: int, bin_: int) -> int:
+        lid = C.c_int()
+        _check(self._L.sdr_attach(self._h, band, int(bin_), C.byref(lid)))
+        return lid.value
+
+    def detach(self, band: int, lid: int):
+        _check(self._L.sdr_detach(self._h, band, lid))
+
+    def listener_count(self, band: int) -> int:
+        return self._L.sdr_listener_count(self._h, band)
+
+    def listener_stop(self, band: int, lid: int):
+        _check(self._L.sdr_listener_stop(self._h, band, lid))
+
+    # control ----------------------------------------------------------------------------------
+    def set_peak_threshold(self, band: int, t: float):
+        _check(self._L.sdr_set_peak_threshold(self._h, band, t))
+
+    def set_edge_width(self, e: int):
+        _check(self._L.sdr_set_edge_width(self._h, e))
+
+    def set_signal_debounce(self, band: int, d: int):
+        _check(self._L.sdr_set_signal_debounce(self._h, band, d))
+
+    def set_center_frequency(self, band: int, f: int):
+        _check(self._L.sdr_set_center_frequency(self._h, band, f))
+
+    def set_find_peaks(self, on: bool):
+        _check(self._L.sdr_set_find_peaks(self._h, int(on)))
+
+    # consumer ---------------------------------------------------------------------------------
+    @property
+    def last_batch_frames(self) -> int:
+        return self._L.sdr_last_batch_frames(self._h)
+
+    @property
+    def total_frames(self) -> int:
+        return self._L.sdr_total_frames(self._h)
+
+    @property
+    def last_batch_chunks(self) -> int:
+        return self._L.sdr_last_batch_chunks(self._h)
+
+    def read_peaks(self, band: int, chunk: int):
+        cap = self.cfg.max_peaks
+        arr = (Peak * cap)()
+        n, fr = C.c_int(), C.c_int()
+        _check(self._L.sdr_read_peaks(self._h, band, chunk, arr, cap, C.byref(n), C.byref(fr)))
+        return [arr[i].astuple() for i in range(min(n.value, cap))], n.value, fr.value
+
+    def read_cumulation(self, band: int, chunk: int) -> np.ndarray:
+        out = np.empty(self.n, np.float32)
+        _check(self._L.sdr_read_cumulation(self._h, band, chunk, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def read_text(self, band: int, lid: int) -> str:
+        buf = C.create_string_buffer(16384)
+        n = C.c_int()
+        _check(self._L.sdr_read_text(self._h, band, lid, buf, len(buf), C.byref(n)))
+        return buf.raw[:n.value].decode("utf-8")
+
+    def read_edges(self, band: int, lid: int) -> np.ndarray:
+        cap = min(self.cfg.max_batch_frames, 8192)
+        out = np.zeros(cap, EDGE_DTYPE)
+        n = C.c_int()
+        _check(self._L.sdr_read_edges(self._h, band, lid, _vp(out), cap, C.byref(n)))
+        return out[:min(n.value, cap)]
+
+    def read_keying_bits(self, band: int, lid: int) -> np.ndarray:
+        """Debounced on/off state per frame of the last batch, as uint8 [n_frames]."""
+        nf = self.last_batch_frames
+        words = (nf + 63) // 64
+        out = np.zeros(max(words, 1), np.uint64)
+        _check(self._L.sdr_read_keying_bits(self._h, band, lid, _vp(out), words))
+        bits = np.unpackbits(out.view(np.uint8), bitorder="little")
+        return bits[:nf].astype(np.uint8)
+
+    def read_frame_records(self, band: int) -> np.ndarray:
+        nf = self.last_batch_frames
+        out = np.zeros(max(nf, 1), FRAME_REC_DTYPE)
+        _check(self._L.sdr_read_frame_records(self._h, band, _vp(out), nf))
+        return out[:nf]
+
+    def read_trace(self, band: int, lid: int):
+        nf = self.last_batch_frames
+        v, r, d = np.zeros(nf, np.float32), np.zeros(nf, np.uint8), np.zeros(nf, np.uint8)
+        _check(self._L.sdr_read_trace(self._h, band, lid, _vp(v), _vp(r), _vp(d), nf))
+        return v, r, d
+
+    def read_spectrum(self, band: int, frame: int):
+        sp, psd = np.empty(self.n, np.float32), np.empty(self.n, np.float32)
+        _check(self._L.sdr_read_spectrum(self._h, band, frame, _vp(sp), _vp(psd)))
+        return sp, psd
+
+    def read_decoder_state(self, band: int, lid: int) -> np.ndarray:
+        out = np.empty(12)
+        _check(self._L.sdr_read_decoder_state(self._h, band, lid, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    # measurement ------------------------------------------------------------------------------
+    def profile_enable(self, on: bool):
+        _check(self._L.sdr_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        _check(self._L.sdr_profile_reset(self._h))
+
+    def profile_read(self) -> dict:
+        out = {}
+        for k, name in enumerate(KERNELS):
+            ms, n = C.c_double(), C.c_int()
+            _check(self._L.sdr_profile_read(self._h, k, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
+
+
+class AudioBank:
+    """n_streams cw.AudioDemodulator instances (cw/audio.go) on the GPU."""
+
+    def __init__(self, n_streams: int, pitch: float, sample_rate: int, max_blocks: int = 4096, device_id: int = 0):
+        L = load()
+        h = C.c_void_p()
+        _check(L.sdr_audio_create(n_streams, pitch, sample_rate, max_blocks, device_id, C.byref(h)))
+        self._h, self._L, self.n_streams = h, L, n_streams
+
+    def close_handle(self):
+        if getattr(self, "_h", None):
+            self._L.sdr_audio_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close_handle()
+        except Exception:
+            pass
+
+    @property
+    def blocksize(self) -> int:
+        return self._L.sdr_audio_blocksize(self._h)
+
+    def set_scale(self, s: float):
+        _check(self._L.sdr_audio_set_scale(self._h, s))
+
+    def set_debounce(self, t: int):
+        _check(self._L.sdr_audio_set_debounce(self._h, t))
+
+    def set_magnitude_threshold(self, t: float):
+        _check(self._L.sdr_audio_set_magnitude_threshold(self._h, t))
+
+    def write(self, samples: np.ndarray):
+        s = np.ascontiguousarray(samples, dtype=np.float32).reshape(self.n_streams, -1)
+        _check(self._L.sdr_audio_write(self._h, s.ctypes.data_as(C.POINTER(C.c_float)), s.shape[1]))
+
+    def close(self):
+        _check(self._L.sdr_audio_close(self._h))
+
+    def read_text(self, stream: int) -> str:
+        buf = C.create_string_buffer(65536)
+        n = C.c_int()
+        _check(self._L.sdr_audio_read_text(self._h, stream, buf, len(buf), C.byref(n)))
+        return buf.raw[:n.value].decode("utf-8")
+
+    def read_trace(self, stream: int, max_blocks: int = 1 << 16):
+        m, r, d = np.zeros(max_blocks), np.zeros(max_blocks, np.uint8), np.zeros(max_blocks, np.uint8)
+        n = C.c_int()
+        _check(self._L.sdr_audio_read_trace(self._h, stream, _vp(m), _vp(r), _vp(d), max_blocks, C.byref(n)))
+        k = min(n.value, max_blocks)
+        return m[:k], r[:k], d[:k]

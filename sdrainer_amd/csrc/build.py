@@ -1,0 +1,61 @@
+"""Builds libsdrainer_hip.so in-tree with hipcc for gfx950 (MI355X only).
+
+-ffp-contract=off is part of the numerical contract: the kernels reproduce the Go reference's
+rounding, and Go on amd64 never fuses a multiply-add (see gomath.h, fft_f64.h).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libsdrainer_hip.so")
+SOURCES = ["sdr_kernels.hip", "sdr_capi.hip", "sdr_audio.hip"]
+HEADERS = ["sdr_device.h", "fft_f64.h", "gomath.h", "cw_decoder.h", "twiddles.h", "host/frequency_mapping.h",
+           "../../include/sdrainer_hip.h"]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
+         "-DSDR_BUILD"]
+
+
+def hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: libsdrainer_hip.so cannot be built (no CPU fallback exists)")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(HERE, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB
+    cc = hipcc()
+    objs = []
+    for s in SOURCES:
+        src = os.path.join(HERE, s)
+        if not os.path.exists(src):
+            continue
+        obj = os.path.join(HERE, s.replace(".hip", ".o"))
+        cmd = [cc] + FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,138 @@
+// gomath.h — the Go stdlib math routines the strainer path calls, written once for host and device.
+//
+// The reference computes its dB projection with math.Log10 (dsp/fft.go:79-85) and go-dsp builds its
+// twiddle tables with math.Sincos.  On amd64 both are pure-Go (FreeBSD e_log.c / Cephes derived,
+// go1.23.4 src/math/log.go, log10.go, sincos.go) and the Go compiler does not fuse multiply-add
+// there, so bit-parity needs the same operation sequence in IEEE double with contraction OFF:
+// this translation unit must be compiled with -ffp-contract=off (csrc/build.py does).
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define SDR_HD __host__ __device__
+#else
+#define SDR_HD
+#endif
+
+namespace gomath {
+
+// math.Log (src/math/log.go)
+SDR_HD inline double log(double x)
+{
+    const double Ln2Hi = 6.93147180369123816490e-01;
+    const double Ln2Lo = 1.90821492927058770002e-10;
+    const double L1 = 6.666666666666735130e-01;
+    const double L2 = 3.999999999940941908e-01;
+    const double L3 = 2.857142874366239149e-01;
+    const double L4 = 2.222219843214978396e-01;
+    const double L5 = 1.818357216161805012e-01;
+    const double L6 = 1.531383769920937332e-01;
+    const double L7 = 1.479819860511658591e-01;
+    const double HalfSqrt2 = 1.41421356237309504880168872420969808 / 2;
+
+    if (x != x || x == INFINITY)
+        return x;
+    if (x < 0)
+        return NAN;
+    if (x == 0)
+        return -INFINITY;
+
+    int ki;
+    double f1 = ::frexp(x, &ki);
+    if (f1 < HalfSqrt2) {
+        f1 *= 2;
+        ki--;
+    }
+    const double f = f1 - 1;
+    const double k = (double)ki;
+
+    const double s = f / (2 + f);
+    const double s2 = s * s;
+    const double s4 = s2 * s2;
+    const double t1 = s2 * (L1 + s4 * (L3 + s4 * (L5 + s4 * L7)));
+    const double t2 = s4 * (L2 + s4 * (L4 + s4 * L6));
+    const double R = t1 + t2;
+    const double hfsq = 0.5 * f * f;
+    return k * Ln2Hi - ((hfsq - (s * (hfsq + R) + k * Ln2Lo)) - f);
+}
+
+// math.Log2 (src/math/log10.go)
+SDR_HD inline double log2(double x)
+{
+    const double InvLn2 = 1 / 0.693147180559945309417232121458176568;
+    int e;
+    const double frac = ::frexp(x, &e);
+    if (frac == 0.5)
+        return (double)(e - 1);
+    return gomath::log(frac) * InvLn2 + (double)e;
+}
+
+// math.Log10 (src/math/log10.go)
+SDR_HD inline double log10(double x)
+{
+    const double Ln2OverLn10 = 0.301029995663981195213738894724493027;
+    return gomath::log2(x) * Ln2OverLn10;
+}
+
+// dsp.PSDValueIndB[float32] (dsp/fft.go:83-85): T(10*log10(20*float64(x)/N^2)).
+// N is a power of two, so the division by N^2 is an exact scaling: inv_n2 = 2^(-2 log2 N).
+SDR_HD inline float psd_value_in_db(float psd, double inv_n2)
+{
+    return (float)(10.0 * gomath::log10(20.0 * (double)psd * inv_n2));
+}
+
+// (host only)
+// math.Sincos (src/math/sincos.go), |x| < 2^29 branch.  Host only: twiddle tables are built once on
+// the host and uploaded, exactly as go-dsp caches them.
+inline void sincos(double x, double *sn, double *cs)
+{
+    static const double S[6] = {1.58962301576546568060E-10, -2.50507477628578072866E-8, 2.75573136213857245213E-6,
+                                -1.98412698295895385996E-4, 8.33333333332211858878E-3,  -1.66666666666666307295E-1};
+    static const double Cc[6] = {-1.13585365213876817300E-11, 2.08757008419747316778E-9, -2.75573141792967388112E-7,
+                                 2.48015872888517045348E-5,   -1.38888888888730564116E-3, 4.16666666666665929218E-2};
+    const double PI4A = 7.85398125648498535156E-1, PI4B = 3.77489470793079817668E-8, PI4C = 2.69515142907905952645E-15;
+    const double Pi = 3.14159265358979323846264338327950288;
+    if (x == 0) {
+        *sn = x;
+        *cs = 1;
+        return;
+    }
+    if (x != x || std::isinf(x)) {
+        *sn = NAN;
+        *cs = NAN;
+        return;
+    }
+    bool sinSign = false, cosSign = false;
+    if (x < 0) {
+        x = -x;
+        sinSign = true;
+    }
+    uint64_t j = (uint64_t)(x * (4 / Pi));
+    double y = (double)j;
+    if (j & 1) {
+        j++;
+        y++;
+    }
+    j &= 7;
+    const double z = ((x - y * PI4A) - y * PI4B) - y * PI4C;
+    if (j > 3) {
+        j -= 4;
+        sinSign = !sinSign;
+        cosSign = !cosSign;
+    }
+    if (j > 1)
+        cosSign = !cosSign;
+    const double zz = z * z;
+    double c = 1.0 - 0.5 * zz + zz * zz * ((((((Cc[0] * zz) + Cc[1]) * zz + Cc[2]) * zz + Cc[3]) * zz + Cc[4]) * zz + Cc[5]);
+    double s = z + z * zz * ((((((S[0] * zz) + S[1]) * zz + S[2]) * zz + S[3]) * zz + S[4]) * zz + S[5]);
+    if (j == 1 || j == 2) {
+        const double t = s;
+        s = c;
+        c = t;
+    }
+    *sn = sinSign ? -s : s;
+    *cs = cosSign ? -c : c;
+}
+
+}  // namespace gomath

@@ -1,0 +1,922 @@
+// sdr_capi.hip — the C ABI of libsdrainer_hip.so (include/sdrainer_hip.h): owns the HBM-resident
+// state of a bank of receivers and sequences the kernels of sdr_kernels.hip on one HIP stream.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sdrainer_hip.h"
+#include "host/frequency_mapping.h"
+#include "sdr_device.h"
+#include "twiddles.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess)                                                                          \
+            return fail(SDR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));               \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count)
+    {
+        n = count;
+        if (count == 0)
+            return hipSuccess;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        if (e != hipSuccess)
+            return e;
+        return hipMemset(p, 0, count * sizeof(T));
+    }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+    }
+};
+
+int ilog2(int n)
+{
+    int s = 0;
+    while ((1 << s) < n)
+        s++;
+    return s;
+}
+
+const char *kKernelNames[sdr::K_COUNT] = {"k_fft_project", "k_window_means", "k_noise_stats", "k_thresholds",
+                                          "k_listen",      "k_cumulate",     "k_find_peaks"};
+
+}  // namespace
+
+namespace sdr {
+int set_error(int code, const char *msg) { return fail(code, msg); }
+}  // namespace sdr
+
+struct sdr_bank {
+    sdr_config cfg{};
+    int logn = 0;
+    hipStream_t stream = nullptr;
+    int device = 0;
+
+    // geometry
+    int max_chunks = 0;
+    int text_cap = 2048;
+    int edge_cap = 0;
+    int bit_words = 0;
+
+    // device buffers
+    DevBuf<fft64::cplx> tw;
+    DevBuf<float> iq_stage_dev;  // [band][max_batch][2N] for the host-staged path
+    DevBuf<float> spectrum, psd;  // [band][max_batch][N]
+    DevBuf<double> win_mean;      // [band][max_batch][10]
+    DevBuf<sdr_frame_rec> recs;   // [band][max_batch]
+    DevBuf<sdr::BandState> band_state;
+    DevBuf<sdr::ListenerSlot> slots;  // [band][max_listeners]
+    DevBuf<uint16_t> morse;
+    DevBuf<uint32_t> text;    // [band][L][text_cap]
+    DevBuf<sdr_edge> edges;   // [band][L][edge_cap]
+    DevBuf<uint64_t> bits;    // [band][L][bit_words]
+    DevBuf<float> tr_values;  // [band][max_batch][L]
+    DevBuf<uint8_t> tr_raw, tr_deb;
+    DevBuf<float> carry[2];          // [band][N] cumulation carried between batches (double buffered)
+    DevBuf<float> cum_out;           // [band][max_chunks][N]
+    DevBuf<sdr::DevPeak> dev_peaks;  // [band][max_chunks][max_peaks]
+    DevBuf<int> peak_counts;         // [band][max_chunks]
+
+    // host mirrors
+    std::vector<sdr::BandState> h_band_state;
+    std::vector<sdr::ListenerSlot> h_slots;  // authoritative only for active/bin at attach time
+    std::vector<int> n_slots;                // high-water mark of used slots per band
+    std::vector<int64_t> center_frequency;
+    std::vector<uint16_t> h_morse;
+    int carry_cur = 0;
+    int cum_count = 0;  // cumulationCount, identical for every band of the bank
+    int64_t total_frames = 0;
+    int last_frames = 0, last_chunks = 0, last_count0 = 0;
+    int edge_width = 0;
+    int find_peaks = 1;
+
+    // host staging (pinned)
+    float *h_stage = nullptr;  // [band][max_batch][2N]
+    std::vector<int> staged;
+
+    // profiling
+    bool profiling = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double prof_ms[sdr::K_COUNT] = {};
+    int prof_n[sdr::K_COUNT] = {};
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;  // events to resolve at sync
+
+    sdr::NoiseGeom noise_geom() const
+    {
+        sdr::NoiseGeom g;
+        g.n = cfg.block_size;
+        g.edge = edge_width;
+        g.window = (cfg.block_size - 2 * edge_width) / 10;
+        const int span = cfg.block_size - 2 * edge_width;
+        // window w is evaluated at i = edge + (w+1)*window, which must be < N - edge (dsp/fft.go:226-238)
+        g.n_windows = (g.window > 0 && span > 10 * g.window) ? 10 : 9;
+        g.inv_n2 = 1.0 / ((double)cfg.block_size * (double)cfg.block_size);
+        return g;
+    }
+};
+
+namespace {
+
+struct ProfScope {
+    sdr_bank *b;
+    int k;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(sdr_bank *bank, int kernel) : b(bank), k(kernel)
+    {
+        if (b->profiling) {
+            (void)hipEventCreate(&e0);
+            (void)hipEventCreate(&e1);
+            (void)hipEventRecord(e0, b->stream);
+        }
+    }
+    ~ProfScope()
+    {
+        if (b->profiling) {
+            (void)hipEventRecord(e1, b->stream);
+            b->pending.push_back({k, {e0, e1}});
+        }
+    }
+};
+
+void resolve_profile(sdr_bank *b)
+{
+    for (auto &p : b->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.second.first, p.second.second) == hipSuccess) {
+            b->prof_ms[p.first] += ms;
+            b->prof_n[p.first] += 1;
+        }
+        (void)hipEventDestroy(p.second.first);
+        (void)hipEventDestroy(p.second.second);
+    }
+    b->pending.clear();
+}
+
+int sync_bank(sdr_bank *b)
+{
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    resolve_profile(b);
+    return SDR_OK;
+}
+
+int check_band(sdr_bank *b, int band)
+{
+    if (!b)
+        return fail(SDR_ERR_BAD_ARG, "null bank");
+    if (band < 0 || band >= b->cfg.n_bands)
+        return fail(SDR_ERR_BAD_ARG, "band out of range");
+    return SDR_OK;
+}
+
+int check_listener(sdr_bank *b, int band, int lid)
+{
+    int rc = check_band(b, band);
+    if (rc)
+        return rc;
+    if (lid < 0 || lid >= b->n_slots[band])
+        return fail(SDR_ERR_BAD_ARG, "listener id out of range");
+    return SDR_OK;
+}
+
+size_t utf8_encode(uint32_t r, char *out)
+{
+    if (r < 0x80) {
+        out[0] = (char)r;
+        return 1;
+    }
+    if (r < 0x800) {
+        out[0] = (char)(0xC0 | (r >> 6));
+        out[1] = (char)(0x80 | (r & 0x3F));
+        return 2;
+    }
+    out[0] = (char)(0xE0 | (r >> 12));
+    out[1] = (char)(0x80 | ((r >> 6) & 0x3F));
+    out[2] = (char)(0x80 | (r & 0x3F));
+    return 3;
+}
+
+int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_stride)
+{
+    const sdr_config &c = b->cfg;
+    if (n_frames <= 0)
+        return SDR_OK;
+    if (n_frames > c.max_batch_frames)
+        return fail(SDR_ERR_BAD_ARG, "n_frames exceeds max_batch_frames");
+    HIP_TRY(hipSetDevice(b->device));
+    const int B = c.n_bands, N = c.block_size, stride = c.max_batch_frames;
+    const sdr::NoiseGeom ng = b->noise_geom();
+    {
+        ProfScope ps(b, sdr::K_FFT);
+        HIP_TRY(sdr::launch_fft(b->logn, iq_dev, b->tw.p, b->spectrum.p, b->psd.p, n_frames, B, in_stride, stride,
+                                b->stream));
+    }
+    {
+        ProfScope ps(b, sdr::K_WINDOW_MEANS);
+        HIP_TRY(sdr::launch_window_means(b->psd.p, b->win_mean.p, ng, n_frames, B, stride, b->stream));
+    }
+    {
+        ProfScope ps(b, sdr::K_NOISE_STATS);
+        HIP_TRY(sdr::launch_noise_stats(b->psd.p, b->win_mean.p, b->recs.p, ng, n_frames, B, stride, b->stream));
+    }
+    {
+        ProfScope ps(b, sdr::K_THRESHOLDS);
+        HIP_TRY(sdr::launch_thresholds(b->recs.p, b->band_state.p, n_frames, B, stride, b->stream));
+    }
+    int max_slots = 0;
+    for (int i = 0; i < B; i++)
+        max_slots = std::max(max_slots, b->n_slots[i]);
+    if (max_slots > 0) {
+        ProfScope ps(b, sdr::K_LISTEN);
+        sdr::ListenGeom lg;
+        lg.n = N;
+        lg.stride = stride;
+        lg.max_listeners = c.max_listeners;
+        lg.text_cap = b->text_cap;
+        lg.edge_cap = b->edge_cap;
+        lg.bit_words = b->bit_words;
+        lg.trace = c.trace;
+        lg.frame_base = (uint32_t)b->total_frames;
+        HIP_TRY(sdr::launch_listen(b->spectrum.p, b->recs.p, b->slots.p, b->morse.p, b->text.p, b->edges.p, b->bits.p,
+                                   b->tr_values.p, b->tr_raw.p, b->tr_deb.p, lg, n_frames, max_slots, B, b->stream));
+    }
+    // cumulation slots of this batch (rx/receiver.go:404-409,459-460)
+    const int count0 = b->cum_count;
+    const int first_len = SDR_CUMULATION_SIZE - count0;
+    int n_slots_c = 1, n_chunks = 0;
+    if (n_frames >= first_len) {
+        n_chunks = 1 + (n_frames - first_len) / SDR_CUMULATION_SIZE;
+        const int rem = (n_frames - first_len) % SDR_CUMULATION_SIZE;
+        n_slots_c = n_chunks + (rem > 0 ? 1 : 0);
+    }
+    {
+        ProfScope ps(b, sdr::K_CUMULATE);
+        sdr::CumGeom cg{N, stride, n_frames, count0, b->max_chunks};
+        HIP_TRY(sdr::launch_cumulate(b->spectrum.p, b->carry[b->carry_cur].p, b->carry[b->carry_cur ^ 1].p,
+                                     b->cum_out.p, cg, n_slots_c, B, b->stream));
+    }
+    const int new_count = (count0 + n_frames) % SDR_CUMULATION_SIZE;
+    // the carry buffer flips only when this batch wrote a new partial cumulation; if the batch ended
+    // exactly on a chunk boundary the next batch starts from zero (count0 == 0 ignores the carry)
+    if (new_count != 0)
+        b->carry_cur ^= 1;
+    if (b->find_peaks && n_chunks > 0) {
+        ProfScope ps(b, sdr::K_FIND_PEAKS);
+        sdr::PeakGeom pg{N, stride, count0, b->max_chunks, c.max_peaks};
+        HIP_TRY(sdr::launch_find_peaks(b->cum_out.p, b->recs.p, b->dev_peaks.p, b->peak_counts.p, pg, n_chunks, B,
+                                       b->stream));
+    }
+    b->cum_count = new_count;
+    b->last_frames = n_frames;
+    b->last_chunks = n_chunks;
+    b->last_count0 = count0;
+    b->total_frames += n_frames;
+    return SDR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+const char *sdr_last_error(void) { return g_last_error.c_str(); }
+int sdr_abi_version(void) { return SDR_ABI_VERSION; }
+const char *sdr_kernel_name(int kernel) { return (kernel >= 0 && kernel < sdr::K_COUNT) ? kKernelNames[kernel] : ""; }
+
+int sdr_create(const sdr_config *cfg, sdr_bank **out)
+{
+    if (!cfg || !out)
+        return fail(SDR_ERR_BAD_ARG, "null argument");
+    if (cfg->struct_size != (int32_t)sizeof(sdr_config))
+        return fail(SDR_ERR_BAD_ARG, "sdr_config.struct_size mismatch (ABI)");
+    const int N = cfg->block_size;
+    if (N < 512 || N > 16384 || (N & (N - 1)))
+        return fail(SDR_ERR_BAD_SIZE, "block_size must be a power of two in [512, 16384]");
+    if (cfg->n_bands < 1 || cfg->sample_rate < 1 || cfg->max_batch_frames < 1 || cfg->max_listeners < 0 ||
+        cfg->max_peaks < 1)
+        return fail(SDR_ERR_BAD_ARG, "non-positive geometry");
+    if (cfg->edge_width < 0 || N - 2 * cfg->edge_width < 10)
+        return fail(SDR_ERR_BAD_ARG, "edge_width leaves fewer than 10 bins: the reference's windowSize would be 0 (NaN)");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (cfg->device_id < 0 || cfg->device_id >= ndev)
+        return fail(SDR_ERR_BAD_ARG, "device_id out of range");
+    HIP_TRY(hipSetDevice(cfg->device_id));
+
+    sdr_bank *b = new sdr_bank();
+    b->cfg = *cfg;
+    b->device = cfg->device_id;
+    b->logn = ilog2(N);
+    b->edge_width = cfg->edge_width;
+    b->find_peaks = cfg->find_peaks;
+    const size_t B = (size_t)cfg->n_bands, F = (size_t)cfg->max_batch_frames, L = (size_t)cfg->max_listeners;
+    b->max_chunks = cfg->max_batch_frames / SDR_CUMULATION_SIZE + 2;
+    b->edge_cap = cfg->max_batch_frames < 8192 ? cfg->max_batch_frames : 8192;
+    b->bit_words = (cfg->max_batch_frames + 63) / 64;
+
+#define ALLOC(buf, count)                                                                              \
+    do {                                                                                               \
+        hipError_t _e = (buf).alloc(count);                                                            \
+        if (_e != hipSuccess) {                                                                        \
+            sdr_destroy(b);                                                                            \
+            return fail(SDR_ERR_HIP, std::string("hipMalloc " #buf ": ") + hipGetErrorString(_e));     \
+        }                                                                                              \
+    } while (0)
+
+    // twiddles: go-dsp's table, re-laid-out per register pass
+    {
+        std::vector<double> wre, wim;
+        fft64::radix2_factors(N, wre, wim);
+        std::vector<fft64::cplx> h((size_t)sdr::twiddle_count(b->logn));
+        sdr::build_twiddles(b->logn, wre.data(), wim.data(), h.data());
+        ALLOC(b->tw, h.size());
+        hipError_t e = hipMemcpy(b->tw.p, h.data(), h.size() * sizeof(fft64::cplx), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            sdr_destroy(b);
+            return fail(SDR_ERR_HIP, "twiddle upload failed");
+        }
+    }
+    ALLOC(b->spectrum, B * F * N);
+    ALLOC(b->psd, B * F * N);
+    ALLOC(b->win_mean, B * F * 10);
+    ALLOC(b->recs, B * F);
+    ALLOC(b->band_state, B);
+    ALLOC(b->slots, B * L);
+    ALLOC(b->morse, cw::kMorseTableSize);
+    ALLOC(b->text, B * L * (size_t)b->text_cap);
+    ALLOC(b->edges, B * L * (size_t)b->edge_cap);
+    ALLOC(b->bits, B * L * (size_t)b->bit_words);
+    if (cfg->trace) {
+        ALLOC(b->tr_values, B * F * L);
+        ALLOC(b->tr_raw, B * F * L);
+        ALLOC(b->tr_deb, B * F * L);
+    }
+    ALLOC(b->carry[0], B * N);
+    ALLOC(b->carry[1], B * N);
+    ALLOC(b->cum_out, B * (size_t)b->max_chunks * N);
+    ALLOC(b->dev_peaks, B * (size_t)b->max_chunks * (size_t)cfg->max_peaks);
+    ALLOC(b->peak_counts, B * (size_t)b->max_chunks);
+#undef ALLOC
+
+    b->h_morse.resize(cw::kMorseTableSize);
+    cw::build_morse_table(b->h_morse.data());
+    hipError_t e = hipMemcpy(b->morse.p, b->h_morse.data(), sizeof(uint16_t) * cw::kMorseTableSize, hipMemcpyHostToDevice);
+    b->h_band_state.assign(B, sdr::BandState{});
+    for (auto &s : b->h_band_state)
+        s.peak_threshold = cfg->peak_threshold;
+    if (e == hipSuccess)
+        e = hipMemcpy(b->band_state.p, b->h_band_state.data(), sizeof(sdr::BandState) * B, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        sdr_destroy(b);
+        return fail(SDR_ERR_HIP, "state upload failed");
+    }
+    b->h_slots.assign(B * L, sdr::ListenerSlot{});
+    b->n_slots.assign(B, 0);
+    b->center_frequency.assign(B, 0);
+    b->staged.assign(B, 0);
+    *out = b;
+    return SDR_OK;
+}
+
+int sdr_destroy(sdr_bank *b)
+{
+    if (!b)
+        return SDR_OK;
+    (void)hipSetDevice(b->device);
+    (void)hipStreamSynchronize(b->stream);
+    resolve_profile(b);
+    b->tw.release();
+    b->iq_stage_dev.release();
+    b->spectrum.release();
+    b->psd.release();
+    b->win_mean.release();
+    b->recs.release();
+    b->band_state.release();
+    b->slots.release();
+    b->morse.release();
+    b->text.release();
+    b->edges.release();
+    b->bits.release();
+    b->tr_values.release();
+    b->tr_raw.release();
+    b->tr_deb.release();
+    b->carry[0].release();
+    b->carry[1].release();
+    b->cum_out.release();
+    b->dev_peaks.release();
+    b->peak_counts.release();
+    if (b->h_stage)
+        (void)hipHostFree(b->h_stage);
+    delete b;
+    return SDR_OK;
+}
+
+int sdr_set_stream(sdr_bank *b, void *hip_stream)
+{
+    if (!b)
+        return fail(SDR_ERR_BAD_ARG, "null bank");
+    int rc = sync_bank(b);
+    if (rc)
+        return rc;
+    b->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return SDR_OK;
+}
+
+int sdr_push_iq(sdr_bank *b, int band, int sample_rate, const float *iq, size_t n_floats)
+{
+    int rc = check_band(b, band);
+    if (rc)
+        return rc;
+    if (!iq)
+        return fail(SDR_ERR_BAD_ARG, "null iq");
+    const sdr_config &c = b->cfg;
+    if (sample_rate != c.sample_rate)  // rx/receiver.go:319-322
+        return fail(SDR_ERR_BAD_RATE, "wrong incoming sample rate");
+    const size_t per = 2 * (size_t)c.block_size;
+    if (n_floats == 0 || n_floats % per != 0)  // rx/receiver.go:323-326
+        return fail(SDR_ERR_BAD_SIZE, "wrong incoming block size");
+    const size_t nf = n_floats / per;
+    if ((size_t)b->staged[band] + nf > (size_t)c.max_batch_frames)  // rx/receiver.go:328-333
+        return fail(SDR_ERR_WOULD_DROP, "IQ data skipped: staging queue full");
+    if (!b->h_stage) {
+        HIP_TRY(hipSetDevice(b->device));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_stage),
+                              sizeof(float) * per * (size_t)c.max_batch_frames * (size_t)c.n_bands, hipHostMallocDefault));
+    }
+    float *dst = b->h_stage + ((size_t)band * c.max_batch_frames + (size_t)b->staged[band]) * per;
+    memcpy(dst, iq, sizeof(float) * n_floats);  // copy on push: the caller may reuse its buffer (kiwi/client.go:203)
+    b->staged[band] += (int)nf;
+    return SDR_OK;
+}
+
+int sdr_staged_frames(sdr_bank *b, int band)
+{
+    if (check_band(b, band))
+        return -1;
+    return b->staged[band];
+}
+
+int sdr_process_staged(sdr_bank *b, int *n_frames_out)
+{
+    if (!b)
+        return fail(SDR_ERR_BAD_ARG, "null bank");
+    const sdr_config &c = b->cfg;
+    int n = c.max_batch_frames;
+    for (int v : b->staged)
+        n = std::min(n, v);
+    if (n_frames_out)
+        *n_frames_out = n;
+    if (n == 0)
+        return SDR_OK;
+    HIP_TRY(hipSetDevice(b->device));
+    const size_t per = 2 * (size_t)c.block_size;
+    if (!b->iq_stage_dev.p) {
+        hipError_t e = b->iq_stage_dev.alloc(per * (size_t)c.max_batch_frames * (size_t)c.n_bands);
+        if (e != hipSuccess)
+            return fail(SDR_ERR_HIP, "hipMalloc iq staging failed");
+    }
+    for (int band = 0; band < c.n_bands; band++)
+        HIP_TRY(hipMemcpyAsync(b->iq_stage_dev.p + (size_t)band * n * per,
+                               b->h_stage + (size_t)band * c.max_batch_frames * per, sizeof(float) * per * (size_t)n,
+                               hipMemcpyHostToDevice, b->stream));
+    int rc = process_device_impl(b, b->iq_stage_dev.p, n, n);
+    if (rc)
+        return rc;
+    // the pinned queue is reused: wait for the upload, then keep what was not consumed
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    resolve_profile(b);
+    for (int band = 0; band < c.n_bands; band++) {
+        const int left = b->staged[band] - n;
+        if (left > 0) {
+            float *base = b->h_stage + (size_t)band * c.max_batch_frames * per;
+            memmove(base, base + (size_t)n * per, sizeof(float) * per * (size_t)left);
+        }
+        b->staged[band] = left;
+    }
+    return SDR_OK;
+}
+
+int sdr_process_device(sdr_bank *b, const float *iq_dev, int n_frames)
+{
+    if (!b || !iq_dev)
+        return fail(SDR_ERR_BAD_ARG, "null argument");
+    return process_device_impl(b, iq_dev, n_frames, n_frames);
+}
+
+int sdr_sync(sdr_bank *b)
+{
+    if (!b)
+        return fail(SDR_ERR_BAD_ARG, "null bank");
+    return sync_bank(b);
+}
+
+int sdr_attach(sdr_bank *b, int band, int bin, int *listener_id)
+{
+    int rc = check_band(b, band);
+    if (rc)
+        return rc;
+    const sdr_config &c = b->cfg;
+    if (bin < 0 || bin >= c.block_size)
+        return fail(SDR_ERR_BAD_ARG, "bin out of range");
+    // reuse a released slot first, else grow (ListenerPool.BindNext, rx/listener.go:214-229)
+    int lid = -1;
+    for (int i = 0; i < b->n_slots[band]; i++)
+        if (!b->h_slots[(size_t)band * c.max_listeners + i].active) {
+            lid = i;
+            break;
+        }
+    if (lid < 0) {
+        if (b->n_slots[band] >= c.max_listeners)
+            return fail(SDR_ERR_NO_SLOT, "listener pool exhausted");
+        lid = b->n_slots[band]++;
+    }
+    sdr::ListenerSlot &s = b->h_slots[(size_t)band * c.max_listeners + lid];
+    memset(&s, 0, sizeof s);
+    s.active = 1;
+    s.bin = bin;
+    cw::debouncer_init(s.deb, c.signal_debounce);              // NewSpectralDemodulator, cw/spectral.go:25-33
+    cw::decoder_init(s.dec, c.sample_rate, c.block_size);      // NewDecoder, cw/decode.go:131-147
+    cw::decoder_reset(s.dec);                                  // Listener.Attach -> demodulator.Reset, listener.go:88
+    HIP_TRY(hipSetDevice(b->device));
+    // a reused slot may still hold unread text of its previous owner: wait and drop it
+    HIP_TRY(hipMemcpyAsync(b->slots.p + (size_t)band * c.max_listeners + lid, &s, sizeof s, hipMemcpyHostToDevice,
+                           b->stream));
+    if (listener_id)
+        *listener_id = lid;
+    return SDR_OK;
+}
+
+int sdr_detach(sdr_bank *b, int band, int lid)
+{
+    int rc = check_listener(b, band, lid);
+    if (rc)
+        return rc;
+    sdr::ListenerSlot &s = b->h_slots[(size_t)band * b->cfg.max_listeners + lid];
+    if (!s.active)
+        return fail(SDR_ERR_STATE, "listener not attached");
+    s.active = 0;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipMemcpyAsync(&b->slots.p[(size_t)band * b->cfg.max_listeners + lid].active, &s.active, sizeof(int32_t),
+                           hipMemcpyHostToDevice, b->stream));
+    return SDR_OK;
+}
+
+int sdr_listener_count(sdr_bank *b, int band)
+{
+    if (check_band(b, band))
+        return -1;
+    int n = 0;
+    for (int i = 0; i < b->n_slots[band]; i++)
+        n += b->h_slots[(size_t)band * b->cfg.max_listeners + i].active;
+    return n;
+}
+
+int sdr_listener_stop(sdr_bank *b, int band, int lid)
+{
+    int rc = check_listener(b, band, lid);
+    if (rc)
+        return rc;
+    const size_t idx = (size_t)band * b->cfg.max_listeners + lid;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(sdr::launch_listener_stop(b->slots.p + idx, b->morse.p, b->text.p + idx * b->text_cap, b->text_cap, b->stream));
+    return SDR_OK;
+}
+
+int sdr_set_peak_threshold(sdr_bank *b, int band, float threshold)
+{
+    int rc = check_band(b, band);
+    if (rc)
+        return rc;
+    b->h_band_state[band].peak_threshold = threshold;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipMemcpyAsync(&b->band_state.p[band].peak_threshold, &b->h_band_state[band].peak_threshold, sizeof(float),
+                           hipMemcpyHostToDevice, b->stream));
+    return SDR_OK;
+}
+
+int sdr_set_edge_width(sdr_bank *b, int edge_width)
+{
+    if (!b)
+        return fail(SDR_ERR_BAD_ARG, "null bank");
+    if (edge_width < 0 || b->cfg.block_size - 2 * edge_width < 10)
+        return fail(SDR_ERR_BAD_ARG, "edge_width leaves fewer than 10 bins");
+    b->edge_width = edge_width;
+    return SDR_OK;
+}
+
+int sdr_set_signal_debounce(sdr_bank *b, int band, int debounce)
+{
+    int rc = check_band(b, band);
+    if (rc)
+        return rc;
+    if (b->n_slots[band] == 0)
+        return SDR_OK;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(sdr::launch_set_debounce(b->slots.p + (size_t)band * b->cfg.max_listeners, b->n_slots[band], debounce,
+                                     b->stream));
+    return SDR_OK;
+}
+
+int sdr_set_center_frequency(sdr_bank *b, int band, int64_t frequency)
+{
+    int rc = check_band(b, band);
+    if (rc)
+        return rc;
+    b->center_frequency[band] = frequency;
+    return SDR_OK;
+}
+
+int sdr_set_find_peaks(sdr_bank *b, int on)
+{
+    if (!b)
+        return fail(SDR_ERR_BAD_ARG, "null bank");
+    b->find_peaks = on ? 1 : 0;
+    return SDR_OK;
+}
+
+int sdr_last_batch_frames(sdr_bank *b) { return b ? b->last_frames : -1; }
+int64_t sdr_total_frames(sdr_bank *b) { return b ? b->total_frames : -1; }
+int sdr_last_batch_chunks(sdr_bank *b) { return b ? b->last_chunks : -1; }
+
+int sdr_read_peaks(sdr_bank *b, int band, int chunk, sdr_peak *out, int max, int *n_out, int *frame_in_batch)
+{
+    int rc = check_band(b, band);
+    if (rc)
+        return rc;
+    if (chunk < 0 || chunk >= b->last_chunks)
+        return fail(SDR_ERR_BAD_ARG, "chunk out of range");
+    rc = sync_bank(b);
+    if (rc)
+        return rc;
+    const sdr_config &c = b->cfg;
+    if (frame_in_batch)
+        *frame_in_batch = (SDR_CUMULATION_SIZE - b->last_count0) + chunk * SDR_CUMULATION_SIZE - 1;
+    if (!b->find_peaks) {
+        if (n_out)
+            *n_out = 0;
+        return SDR_OK;
+    }
+    int count = 0;
+    HIP_TRY(hipMemcpy(&count, b->peak_counts.p + (size_t)band * b->max_chunks + chunk, sizeof(int), hipMemcpyDeviceToHost));
+    if (n_out)
+        *n_out = count;
+    const int n = std::min(std::min(count, c.max_peaks), max);
+    if (n <= 0 || !out)
+        return SDR_OK;
+    std::vector<sdr::DevPeak> dp((size_t)n);
+    HIP_TRY(hipMemcpy(dp.data(), b->dev_peaks.p + ((size_t)band * b->max_chunks + chunk) * c.max_peaks,
+                      sizeof(sdr::DevPeak) * (size_t)n, hipMemcpyDeviceToHost));
+    host::FrequencyMapping fm(c.sample_rate, c.block_size, b->center_frequency[band]);
+    for (int i = 0; i < n; i++) {
+        const sdr::DevPeak &p = dp[i];
+        sdr_peak &o = out[i];
+        o.from = p.from;
+        o.to = p.to;
+        o.signal_bin = p.signal_bin;
+        o.signal_value = p.signal_value;
+        o.from_frequency = fm.BinToFrequency(p.from, host::BinFrom);
+        o.to_frequency = fm.BinToFrequency(p.to, host::BinTo);
+        const double corr = host::PeakCenterCorrection(p.signal_bin, c.block_size, p.y1, p.y2, p.y3);
+        o.signal_frequency = fm.BinToFrequency(p.signal_bin, corr);
+    }
+    return SDR_OK;
+}
+
+int sdr_read_cumulation(sdr_bank *b, int band, int chunk, float *out)
+{
+    int rc = check_band(b, band);
+    if (rc)
+        return rc;
+    if (chunk < 0 || chunk >= b->last_chunks || !out)
+        return fail(SDR_ERR_BAD_ARG, "chunk out of range");
+    rc = sync_bank(b);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpy(out, b->cum_out.p + ((size_t)band * b->max_chunks + chunk) * b->cfg.block_size,
+                      sizeof(float) * (size_t)b->cfg.block_size, hipMemcpyDeviceToHost));
+    return SDR_OK;
+}
+
+int sdr_read_text(sdr_bank *b, int band, int lid, char *out, int max_bytes, int *n_bytes)
+{
+    int rc = check_listener(b, band, lid);
+    if (rc)
+        return rc;
+    rc = sync_bank(b);
+    if (rc)
+        return rc;
+    const size_t idx = (size_t)band * b->cfg.max_listeners + lid;
+    sdr::ListenerSlot s;
+    HIP_TRY(hipMemcpy(&s, b->slots.p + idx, sizeof s, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> runes(s.text_count);
+    if (s.text_count)
+        HIP_TRY(hipMemcpy(runes.data(), b->text.p + idx * b->text_cap, sizeof(uint32_t) * s.text_count,
+                          hipMemcpyDeviceToHost));
+    int n = 0;
+    uint32_t consumed = 0;
+    for (; consumed < s.text_count; consumed++) {
+        char tmp[4];
+        const size_t k = utf8_encode(runes[consumed], tmp);
+        if (n + (int)k > max_bytes)
+            break;
+        if (out)
+            memcpy(out + n, tmp, k);
+        n += (int)k;
+    }
+    if (n_bytes)
+        *n_bytes = n;
+    // drop what was handed out, keep the rest at the front of the buffer
+    const uint32_t left = s.text_count - consumed;
+    if (left && consumed)
+        HIP_TRY(hipMemcpy(b->text.p + idx * b->text_cap, runes.data() + consumed, sizeof(uint32_t) * left,
+                          hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(&b->slots.p[idx].text_count, &left, sizeof(uint32_t), hipMemcpyHostToDevice));
+    return SDR_OK;
+}
+
+int sdr_read_edges(sdr_bank *b, int band, int lid, sdr_edge *out, int max, int *n_out)
+{
+    int rc = check_listener(b, band, lid);
+    if (rc)
+        return rc;
+    rc = sync_bank(b);
+    if (rc)
+        return rc;
+    const size_t idx = (size_t)band * b->cfg.max_listeners + lid;
+    uint32_t count = 0;
+    HIP_TRY(hipMemcpy(&count, &b->slots.p[idx].edge_count, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (n_out)
+        *n_out = (int)count;
+    const int n = std::min(std::min((int)count, b->edge_cap), max);
+    if (n > 0 && out)
+        HIP_TRY(hipMemcpy(out, b->edges.p + idx * b->edge_cap, sizeof(sdr_edge) * (size_t)n, hipMemcpyDeviceToHost));
+    return SDR_OK;
+}
+
+int sdr_read_keying_bits(sdr_bank *b, int band, int lid, uint64_t *out, int max_words)
+{
+    int rc = check_listener(b, band, lid);
+    if (rc)
+        return rc;
+    rc = sync_bank(b);
+    if (rc)
+        return rc;
+    const size_t idx = (size_t)band * b->cfg.max_listeners + lid;
+    const int words = std::min((b->last_frames + 63) / 64, max_words);
+    if (words > 0 && out)
+        HIP_TRY(hipMemcpy(out, b->bits.p + idx * b->bit_words, sizeof(uint64_t) * (size_t)words, hipMemcpyDeviceToHost));
+    return SDR_OK;
+}
+
+int sdr_read_frame_records(sdr_bank *b, int band, sdr_frame_rec *out, int max)
+{
+    int rc = check_band(b, band);
+    if (rc)
+        return rc;
+    rc = sync_bank(b);
+    if (rc)
+        return rc;
+    const int n = std::min(b->last_frames, max);
+    if (n > 0 && out)
+        HIP_TRY(hipMemcpy(out, b->recs.p + (size_t)band * b->cfg.max_batch_frames, sizeof(sdr_frame_rec) * (size_t)n,
+                          hipMemcpyDeviceToHost));
+    return SDR_OK;
+}
+
+int sdr_read_trace(sdr_bank *b, int band, int lid, float *values, uint8_t *raw, uint8_t *debounced, int max)
+{
+    int rc = check_listener(b, band, lid);
+    if (rc)
+        return rc;
+    if (!b->cfg.trace)
+        return fail(SDR_ERR_STATE, "bank was created without trace");
+    rc = sync_bank(b);
+    if (rc)
+        return rc;
+    const sdr_config &c = b->cfg;
+    const int n = std::min(b->last_frames, max);
+    if (n <= 0)
+        return SDR_OK;
+    const size_t L = (size_t)c.max_listeners;
+    const size_t base = (size_t)band * c.max_batch_frames * L + lid;
+    // strided gather: [frame][listener] -> per-listener row
+    if (values)
+        HIP_TRY(hipMemcpy2D(values, sizeof(float), b->tr_values.p + base, sizeof(float) * L, sizeof(float), (size_t)n,
+                            hipMemcpyDeviceToHost));
+    if (raw)
+        HIP_TRY(hipMemcpy2D(raw, 1, b->tr_raw.p + base, L, 1, (size_t)n, hipMemcpyDeviceToHost));
+    if (debounced)
+        HIP_TRY(hipMemcpy2D(debounced, 1, b->tr_deb.p + base, L, 1, (size_t)n, hipMemcpyDeviceToHost));
+    return SDR_OK;
+}
+
+int sdr_read_spectrum(sdr_bank *b, int band, int frame, float *spectrum, float *psd)
+{
+    int rc = check_band(b, band);
+    if (rc)
+        return rc;
+    if (frame < 0 || frame >= b->last_frames)
+        return fail(SDR_ERR_BAD_ARG, "frame out of range");
+    rc = sync_bank(b);
+    if (rc)
+        return rc;
+    const size_t N = (size_t)b->cfg.block_size;
+    const size_t off = ((size_t)band * b->cfg.max_batch_frames + frame) * N;
+    if (spectrum)
+        HIP_TRY(hipMemcpy(spectrum, b->spectrum.p + off, sizeof(float) * N, hipMemcpyDeviceToHost));
+    if (psd)
+        HIP_TRY(hipMemcpy(psd, b->psd.p + off, sizeof(float) * N, hipMemcpyDeviceToHost));
+    return SDR_OK;
+}
+
+int sdr_read_decoder_state(sdr_bank *b, int band, int lid, double *out12)
+{
+    int rc = check_listener(b, band, lid);
+    if (rc)
+        return rc;
+    if (!out12)
+        return fail(SDR_ERR_BAD_ARG, "null out");
+    rc = sync_bank(b);
+    if (rc)
+        return rc;
+    sdr::ListenerSlot s;
+    HIP_TRY(hipMemcpy(&s, b->slots.p + (size_t)band * b->cfg.max_listeners + lid, sizeof s, hipMemcpyDeviceToHost));
+    const cw::DecoderState &d = s.dec;
+    out12[0] = d.ticks;
+    out12[1] = d.onStart;
+    out12[2] = d.offStart;
+    out12[3] = d.wpm;
+    out12[4] = d.onThreshold.low;
+    out12[5] = d.onThreshold.high;
+    out12[6] = d.onThreshold.last;
+    out12[7] = d.onThreshold.threshold;
+    out12[8] = d.offThreshold.low;
+    out12[9] = d.offThreshold.high;
+    out12[10] = d.offThreshold.last;
+    out12[11] = d.offThreshold.threshold;
+    return SDR_OK;
+}
+
+int sdr_profile_enable(sdr_bank *b, int on)
+{
+    if (!b)
+        return fail(SDR_ERR_BAD_ARG, "null bank");
+    int rc = sync_bank(b);
+    if (rc)
+        return rc;
+    b->profiling = on != 0;
+    return SDR_OK;
+}
+
+int sdr_profile_read(sdr_bank *b, int kernel, double *total_ms, int *launches)
+{
+    if (!b || kernel < 0 || kernel >= sdr::K_COUNT)
+        return fail(SDR_ERR_BAD_ARG, "bad kernel id");
+    int rc = sync_bank(b);
+    if (rc)
+        return rc;
+    if (total_ms)
+        *total_ms = b->prof_ms[kernel];
+    if (launches)
+        *launches = b->prof_n[kernel];
+    return SDR_OK;
+}
+
+int sdr_profile_reset(sdr_bank *b)
+{
+    if (!b)
+        return fail(SDR_ERR_BAD_ARG, "null bank");
+    int rc = sync_bank(b);
+    if (rc)
+        return rc;
+    for (int i = 0; i < sdr::K_COUNT; i++) {
+        b->prof_ms[i] = 0;
+        b->prof_n[i] = 0;
+    }
+    return SDR_OK;
+}
+
+#pragma GCC visibility pop
+}  // extern "C"

@@ -1,0 +1,85 @@
+// sdr_device.h — HBM-resident state and launch geometry shared by the kernels and the C-ABI host code.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/sdrainer_hip.h"
+#include "cw_decoder.h"
+#include "fft_f64.h"
+
+namespace sdr {
+
+// Per-band state carried across batches (locals of Receiver.run, rx/receiver.go:339-346).
+struct BandState {
+    float nf_ring[SDR_NOISE_WINDOW];   // noiseFloorMean.values
+    float dev_ring[SDR_NOISE_WINDOW];  // noiseDeviationMean.values
+    float nf_sum, dev_sum;             // sumForMean of both
+    int32_t next;                      // shared ring cursor (both means are Put once per frame)
+    float peak_threshold;              // r.peakThreshold
+};
+
+// One listener of a band's pool (rx/listener.go:19-32 + cw/spectral.go:19-23).
+struct ListenerSlot {
+    int32_t active;
+    int32_t bin;  // Peak.SignalBin
+    cw::Debouncer deb;
+    cw::DecoderState dec;
+    uint32_t text_count;    // runes in the text buffer not yet read by the host
+    uint32_t text_dropped;  // runes dropped because the buffer was full
+    uint32_t edge_count;    // edges produced by the last batch
+    int32_t last_debounced;
+};
+
+// What k_find_peaks hands to the host, which finishes dsp.Peak (frequencies are float64 -> int).
+struct DevPeak {
+    int32_t from, to, signal_bin;
+    float signal_value;
+    float y1, y2, y3;  // cumulation at signal_bin-1, signal_bin, signal_bin+1 (PeakCenterCorrection)
+};
+
+struct NoiseGeom {
+    int n;          // block size
+    int edge;       // edgeWidth
+    int window;     // windowSize = (N - 2 edge) / 10
+    int n_windows;  // windows the reference's loop actually evaluates (9 or 10)
+    double inv_n2;  // 1 / N^2 (exact power of two)
+};
+
+struct ListenGeom {
+    int n, stride, max_listeners, text_cap, edge_cap, bit_words, trace;
+    uint32_t frame_base;
+};
+
+struct CumGeom {
+    int n, stride, n_frames, count0, max_chunks;
+};
+
+struct PeakGeom {
+    int n, stride, count0, max_chunks, max_peaks;
+};
+
+enum KernelId { K_FFT = 0, K_WINDOW_MEANS, K_NOISE_STATS, K_THRESHOLDS, K_LISTEN, K_CUMULATE, K_FIND_PEAKS, K_COUNT };
+
+hipError_t launch_fft(int logn, const float *iq, const fft64::cplx *tw, float *spectrum, float *psd, int n_frames,
+                      int n_bands, int in_stride, int out_stride, hipStream_t stream);
+int twiddle_count(int logn);
+void build_twiddles(int logn, const double *wre, const double *wim, fft64::cplx *out);
+hipError_t launch_window_means(const float *psd, double *win_mean, NoiseGeom g, int n_frames, int n_bands, int stride,
+                               hipStream_t stream);
+hipError_t launch_noise_stats(const float *psd, const double *win_mean, sdr_frame_rec *recs, NoiseGeom g, int n_frames,
+                              int n_bands, int stride, hipStream_t stream);
+hipError_t launch_thresholds(sdr_frame_rec *recs, BandState *st, int n_frames, int n_bands, int stride,
+                             hipStream_t stream);
+hipError_t launch_listen(const float *spectrum, const sdr_frame_rec *recs, ListenerSlot *slots, const uint16_t *morse,
+                         uint32_t *text, sdr_edge *edges, uint64_t *bits, float *tr_values, uint8_t *tr_raw,
+                         uint8_t *tr_deb, ListenGeom g, int n_frames, int n_slots, int n_bands, hipStream_t stream);
+hipError_t launch_listener_stop(ListenerSlot *slot, const uint16_t *morse, uint32_t *text, int text_cap,
+                                hipStream_t stream);
+hipError_t launch_set_debounce(ListenerSlot *slots, int n, int threshold, hipStream_t stream);
+hipError_t launch_cumulate(const float *spectrum, const float *carry_in, float *carry_out, float *cum_out, CumGeom g,
+                           int n_slots, int n_bands, hipStream_t stream);
+hipError_t launch_find_peaks(const float *cum, const sdr_frame_rec *recs, DevPeak *peaks, int *counts, PeakGeom g,
+                             int n_chunks, int n_bands, hipStream_t stream);
+
+}  // namespace sdr
