@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""IQ-strainer throughput benchmark (BASELINE.json metric: IQ MSamples/s through FFT + peak scan +
+per-peak envelope / Morse decode, at 1/2/4/8 GPUs; % of the HBM roofline).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU.  A *step* is one pass of the whole hot path (all seven kernels) over one batch of
+synthetic IQ that is already resident in HBM.  Workload at every N: BASELINE config 3 — one 2 MS/s
+band, 16384-point FFT, 256 tracked CW signals — per GPU (config 4 = 8 x config 3, one band per GPU):
+bands are independent receivers, so the job shards by band with no data-path collective (weak
+scaling); the only collective is the RCCL broadcast of the shared configuration / threshold struct
+from rank 0 before the timed region.
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying, besides the throughput:
+  roofline      dominant kernel (k_fft_project) algorithmic bytes (8 B per IQ sample) per launch over
+                its average launch duration measured with HIP events on the launch stream, vs 8 TB/s
+  cpu_baseline  the CPU oracle (port of the Go path) timed on this box's host cores on a bounded
+                sample of the same workload
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_SAMPLE = 8   # one complex64 IQ sample read once
+
+WORKLOADS = {
+    # name: (sample_rate, block_size, tracked signals per band, bands per GPU, free_last_window)
+    "c2": (192_000, 4096, 16, 1, False),
+    "c3": (2_000_000, 16384, 256, 1, True),
+    "c5": (2_000_000, 8192, 16, 8, False),
+}
+WORKLOAD_TEXT = {
+    "c2": "BASELINE config 2: one TCI-shaped IQ stream, 192 kS/s, 4096-pt FFT, 16 tracked peaks",
+    "c3": "BASELINE config 3: wideband synthetic IQ, 2 MS/s, 16384-pt FFT, 256 concurrent CW peaks, one band per GPU "
+          "(config 4 at N>1: N independent bands, one per GPU)",
+    "c5": "BASELINE config 5: 8 channels per GPU x 8192-pt FFT x 16 peaks per channel (64 channels / 1024 peaks at 8 GPUs)",
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
+    ap.add_argument("--frames", type=int, default=2048, help="frames per band per step (batch)")
+    ap.add_argument("--ring", type=int, default=3, help="distinct input batches cycled through (defeats cache reuse)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU work per core for the baseline")
+    ap.add_argument("--kernel-breakdown", action="store_true", help="print per-kernel HIP-event times to stderr")
+    return ap.parse_args()
+
+
+def cpu_baseline(rate, n, tones, free_last, seconds):
+    """Times oracle (port of the Go path: complex128 radix-2 FFT + log10 projection + noise floor +
+    thresholds + listeners + cumulation + FindPeaks) with one band per host core."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import oracle as orc
+    from sdrainer_amd import synth
+
+    cores = os.cpu_count() or 1
+    block_frames = 128
+    iq, bins, _ = synth.make_band(block_frames, rate, n, tones, seed=4242, free_last_window=free_last)
+    edge = synth.default_edge_width(n)
+
+    def make():
+        r = orc.Receiver(rate, n, edge)
+        for b in bins:
+            r.attach(int(b))
+        return r
+
+    # calibrate on one core
+    r = make()
+    t0 = time.perf_counter()
+    r.run_baseline(iq)
+    dt = time.perf_counter() - t0
+    one_core = block_frames * n / dt / 1e6
+    reps = max(1, int(seconds / dt))
+
+    def work(_):
+        rr = make()
+        for _ in range(reps):
+            rr.run_baseline(iq)  # ctypes releases the GIL: threads run in parallel
+        return reps * block_frames * n
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        total = sum(ex.map(work, range(cores)))
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(total / dt / 1e6, 2),
+        "unit": "MSamples/s",
+        "cores": cores,
+        "kind": "port",
+        "value_1core": round(one_core, 2),
+        "sample": f"{cores} bands (one per host core) x {reps * block_frames} frames of {n} samples "
+                  f"({block_frames}-frame block replayed {reps}x), {tones} listeners each, oracle/sdr_oracle.c "
+                  f"(C restatement of the Go path, -O2 -ffp-contract=off); the Go binary itself cannot be built here",
+    }
+
+
+def main():
+    args = parse()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from sdrainer_amd import capi, sharding, synth
+
+    rate, n, tones, bands_per_gpu, free_last = WORKLOADS[args.workload]
+    frames = args.frames
+    edge = synth.default_edge_width(n)
+
+    # the one genuinely shared piece of state: configuration / thresholds, broadcast from rank 0
+    shared = sharding.SharedConfig(sample_rate=rate, block_size=n, edge_width=edge, peak_threshold=15.0,
+                                   signal_debounce=1, max_listeners=max(tones, 1))
+    shared = sharding.broadcast_config(shared, dist, dev)
+    my_bands = sharding.bands_of_rank(bands_per_gpu * world, world, rank)
+    assert len(my_bands) == bands_per_gpu
+
+    bank = capi.Bank(shared.sample_rate, shared.block_size, n_bands=bands_per_gpu, edge_width=shared.edge_width,
+                     peak_threshold=shared.peak_threshold, signal_debounce=shared.signal_debounce,
+                     max_listeners=shared.max_listeners, max_batch_frames=frames, max_peaks=1024, find_peaks=True,
+                     trace=False, device_id=local_rank)
+    stream = torch.cuda.current_stream()
+    bank.set_stream(stream.cuda_stream)
+
+    # inputs: `ring` distinct batches, layout [band][frame][N][2] float32, generated in HBM
+    ring = []
+    bins_of_band = {}
+    for k in range(args.ring):
+        per_band = []
+        for bi, band in enumerate(my_bands):
+            iq, bins, _ = synth.make_band_torch(frames, rate, n, tones, seed=1000 * 3 + 17 * band + k, device=dev,
+                                                free_last_window=free_last)
+            bins_of_band[bi] = bins
+            per_band.append(iq)
+        ring.append(torch.stack(per_band).contiguous())
+    for bi in range(bands_per_gpu):
+        for b in bins_of_band[bi]:
+            bank.attach(bi, int(b))
+    torch.cuda.synchronize()
+
+    def step(i):
+        bank.process_device(ring[i % len(ring)].data_ptr(), frames)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    samples_per_step_rank = frames * n * bands_per_gpu
+    total_samples = samples_per_step_rank * args.steps * world
+    value = total_samples / elapsed / 1e6
+
+    # dominant kernel: HIP events on the launch stream, live, same workload, after the timed region
+    bank.profile_reset()
+    bank.profile_enable(True)
+    prof_steps = max(3, min(args.steps, 10))
+    for i in range(prof_steps):
+        step(i)
+    bank.sync()
+    prof = bank.profile_read()
+    bank.profile_enable(False)
+    fft_ms, fft_n = prof["k_fft_project"]
+    fft_avg_ms = fft_ms / max(fft_n, 1)
+    achieved = BYTES_PER_SAMPLE * samples_per_step_rank / (fft_avg_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            key = f"{args.workload}_f{frames}"
+            if key in tj:
+                traffic = tj[key]["k_fft_project_hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+    if args.kernel_breakdown and rank == 0:
+        tot = sum(v[0] for v in prof.values())
+        for k, (ms, cnt) in prof.items():
+            print(f"  {k:16s} {ms / max(cnt, 1):9.3f} ms/launch  {100 * ms / max(tot, 1e-9):5.1f}%", file=sys.stderr)
+        print(f"  sum of kernels   {tot / prof_steps:9.3f} ms/step ; wall {1e3 * elapsed / args.steps:9.3f} ms/step",
+              file=sys.stderr)
+
+    # sanity: the timed path really decoded something (guards against measuring an empty pipeline)
+    decoded = sum(len(bank.read_text(0, lid)) for lid in range(min(tones, 4)))
+    chunks = bank.last_batch_chunks
+
+    result = {
+        "metric": "IQ MSamples/s through FFT+peak+envelope",
+        "value": round(value, 1),
+        "unit": "MSamples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": WORKLOAD_TEXT[args.workload],
+            "sample_rate": rate, "block_size": n, "tracked_signals_per_band": tones,
+            "bands_per_gpu": bands_per_gpu, "frames_per_step_per_band": frames,
+            "samples_per_step_per_gpu": samples_per_step_rank, "input": "complex64 IQ resident in HBM",
+            "sharding": f"{bands_per_gpu * world} independent bands, {bands_per_gpu} per GPU, no data-path collective",
+            "sanity": {"runes_decoded_first_listeners": decoded, "cumulations_per_step": chunks},
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "k_fft_project", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "avg_launch_ms": round(fft_avg_ms, 4), "launches_timed": fft_n,
+            "whole_path_frac": round(value * 1e6 / world * BYTES_PER_SAMPLE / (HBM_PEAK_GBS * 1e9), 4),
+        },
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(rate, n, tones, free_last, args.cpu_seconds)
+    bank.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

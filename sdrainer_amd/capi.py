@@ -75,6 +75,15 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m sdrainer_amd.csrc.build` (hipcc, gfx950). "
             "sdrainer_amd has no CPU fallback.")
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.so.1.  Two HSA runtimes
+    # in one process fight over the device ("No HIP GPUs are available" for whichever comes second),
+    # so when torch is installed let it load its copy first: the dynamic loader then resolves this
+    # library's libamdhip64.so.7 to the already-loaded one.  Without torch (e.g. under a cgo host) the
+    # system ROCm runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)
 
