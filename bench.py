@@ -63,6 +63,23 @@ def parse():
     return ap.parse_args()
 
 
+def available_cores() -> int:
+    """Host cores this process may actually use (affinity mask and cgroup quota), capped at 16 — the
+    CPU share of a one-GPU box."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(rate, n, tones, free_last, seconds):
     """Times oracle (port of the Go path: complex128 radix-2 FFT + log10 projection + noise floor +
     thresholds + listeners + cumulation + FindPeaks) with one band per host core."""
@@ -71,7 +88,7 @@ def cpu_baseline(rate, n, tones, free_last, seconds):
     from oracle import oracle as orc
     from sdrainer_amd import synth
 
-    cores = os.cpu_count() or 1
+    cores = available_cores()
     block_frames = 128
     iq, bins, _ = synth.make_band(block_frames, rate, n, tones, seed=4242, free_last_window=free_last)
     edge = synth.default_edge_width(n)

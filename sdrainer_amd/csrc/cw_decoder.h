@@ -252,6 +252,28 @@ SDR_HD inline void decoder_tick(DecoderState &d, bool state, const uint16_t *tab
     }
 }
 
+// `k` consecutive Tick(state) calls with state == lastState, in closed form.  Between edges Tick only
+// counts (`ticks++`) and checks `decoding && currentDuration > upperBound` (:244-249); neither
+// threshold changes, currentDuration = now - start is an exact integer, so the check first fires at
+// the tick where now == floor(upperBound) + 1 + start (if that tick is within the run) and never again
+// (it clears `decoding`).  Results are identical to k literal Tick calls.
+template <class Sink>
+SDR_HD inline void decoder_advance(DecoderState &d, int k, const uint16_t *table, Sink &out)
+{
+    if (k <= 0)
+        return;
+    if (d.decoding) {
+        const double start = d.lastState ? d.onStart : d.offStart;
+        const double upperBound = d.offThreshold.threshold * (double)d.abortDecodeAfterDits;
+        const double first_now = ::floor(upperBound) + 1.0 + start;  // smallest integer now with now-start > upperBound
+        if (first_now <= d.ticks + (double)k) {  // (first_now <= ticks cannot happen while decoding is still set)
+            d.decoding = 0;
+            decode_current_char(d, table, out);
+        }
+    }
+    d.ticks += (double)k;
+}
+
 template <class Sink>
 SDR_HD inline void decoder_stop(DecoderState &d, const uint16_t *table, Sink &out)  // stop :352-354
 {

@@ -1,0 +1,176 @@
+// k_listen.hip — the per-signal chain: rx/receiver.go:388-402 -> rx/listener.go:142-148 ->
+// cw/spectral.go:48-54 (value > threshold) -> dsp/dsp.go:164-182 (debounce) -> cw/decode.go:202-250
+// (Morse timing state machine).  Compiled with -ffp-contract=off.
+//
+// Two kernels:
+//   k_listen_gather  data-parallel over (signal, frame): one wave takes 64 consecutive frames of one
+//                    signal, gathers spectrum[f][bin], compares against that frame's threshold and turns
+//                    the 64 results into one 64-bit word with a single ballot.
+//   k_listen_decode  one LANE per signal (64 signals per wave): the debouncer and the decoder are
+//                    inherently serial per signal, but between keying edges Decoder.Tick only counts, so
+//                    the lane walks RUNS of equal bits (ffs on the XOR-ed word) and handles each run in
+//                    closed form (cw::decoder_advance) — a few hundred edges per batch instead of
+//                    thousands of ticks.
+#include <hip/hip_runtime.h>
+
+#include "../../include/sdrainer_hip.h"
+#include "cw_decoder.h"
+#include "sdr_device.h"
+
+namespace sdr {
+
+__global__ __launch_bounds__(64) void k_listen_gather(const float *__restrict__ spectrum,
+                                                      const sdr_frame_rec *__restrict__ recs,
+                                                      const ListenerSlot *__restrict__ slots,
+                                                      uint64_t *__restrict__ raw_bits, float *__restrict__ tr_values,
+                                                      uint8_t *__restrict__ tr_raw, ListenGeom g, int n_frames)
+{
+    const int word = blockIdx.x, l = blockIdx.y, band = blockIdx.z, lane = threadIdx.x;
+    const size_t lidx = (size_t)band * g.max_listeners + l;
+    const ListenerSlot *slot = &slots[lidx];
+    if (!slot->active)
+        return;
+    const int f = word * 64 + lane;
+    float v = 0.f;
+    bool raw = false;
+    if (f < n_frames) {
+        v = spectrum[((size_t)band * g.stride + f) * g.n + slot->bin];
+        raw = v > recs[(size_t)band * g.stride + f].listen_thr;  // cw/spectral.go:49
+    }
+    const uint64_t mask = __ballot(raw);
+    if (lane == 0)
+        raw_bits[lidx * g.bit_words + word] = mask;
+    if (g.trace && f < n_frames) {
+        const size_t ti = ((size_t)band * g.stride + f) * g.max_listeners + l;
+        tr_values[ti] = v;
+        tr_raw[ti] = raw;
+    }
+}
+
+struct TextSink {
+    uint32_t *buf;
+    uint32_t count, cap, dropped;
+    __device__ void put(uint32_t r)
+    {
+        if (count < cap)
+            buf[count++] = r;
+        else
+            dropped++;
+    }
+};
+
+__global__ __launch_bounds__(64) void k_listen_decode(ListenerSlot *__restrict__ slots,
+                                                      const uint16_t *__restrict__ morse,
+                                                      const uint64_t *__restrict__ raw_bits,
+                                                      uint64_t *__restrict__ deb_bits, uint32_t *__restrict__ text,
+                                                      sdr_edge *__restrict__ edges, uint8_t *__restrict__ tr_deb,
+                                                      ListenGeom g, int n_frames, int n_total)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (band, slot) flattened
+    if (idx >= n_total)
+        return;
+    ListenerSlot *slot = &slots[idx];
+    if (!slot->active)
+        return;
+    cw::Debouncer deb = slot->deb;
+    cw::DecoderState dec = slot->dec;
+    TextSink sink{text + (size_t)idx * g.text_cap, slot->text_count, (uint32_t)g.text_cap, slot->text_dropped};
+    sdr_edge *my_edges = edges + (size_t)idx * g.edge_cap;
+    const uint64_t *rw = raw_bits + (size_t)idx * g.bit_words;
+    uint64_t *dw = deb_bits + (size_t)idx * g.bit_words;
+    uint32_t n_edges = 0;
+    const int band = idx / g.max_listeners, l = idx - band * g.max_listeners;
+
+    for (int f0 = 0; f0 < n_frames; f0 += 64) {
+        const int cnt = min(64, n_frames - f0);
+        const uint64_t raw = rw[f0 >> 6];
+        uint64_t d = raw;
+        if (deb.threshold >= 2) {  // dsp/dsp.go:165-167: threshold < 2 is a passthrough
+            d = 0;
+            for (int j = 0; j < cnt; j++)
+                d |= (uint64_t)cw::debounce(deb, (raw >> j) & 1ull) << j;
+        }
+        dw[f0 >> 6] = d;
+        // walk the runs of equal debounced bits
+        int pos = 0;
+        while (pos < cnt) {
+            const bool cur = dec.lastState != 0;
+            uint64_t diff = (cur ? ~d : d) >> pos;  // 1 where the bit differs from the decoder's state
+            if (cnt - pos < 64)
+                diff &= (1ull << (cnt - pos)) - 1ull;
+            const int run = diff ? (__ffsll((long long)diff) - 1) : (cnt - pos);
+            cw::decoder_advance(dec, run, morse, sink);
+            pos += run;
+            if (pos < cnt) {  // the edge tick
+                const bool st = !cur;
+                if (n_edges < (uint32_t)g.edge_cap)
+                    my_edges[n_edges] = sdr_edge{(uint32_t)(g.frame_base + f0 + pos), st ? 1u : 0u};
+                n_edges++;
+                cw::decoder_tick(dec, st, morse, sink);
+                pos++;
+            }
+        }
+        if (g.trace)
+            for (int j = 0; j < cnt; j++)
+                tr_deb[((size_t)band * g.stride + f0 + j) * g.max_listeners + l] = (d >> j) & 1ull;
+    }
+    slot->deb = deb;
+    slot->dec = dec;
+    slot->text_count = sink.count;
+    slot->text_dropped = sink.dropped;
+    slot->edge_count = n_edges;
+}
+
+// cw.Decoder.stop for one listener (cw/decode.go:352-354)
+__global__ void k_listener_stop(ListenerSlot *slot, const uint16_t *morse, uint32_t *text, int text_cap)
+{
+    if (threadIdx.x != 0 || !slot->active)
+        return;
+    cw::DecoderState dec = slot->dec;
+    TextSink sink{text, slot->text_count, (uint32_t)text_cap, slot->text_dropped};
+    cw::decoder_stop(dec, morse, sink);
+    slot->dec = dec;
+    slot->text_count = sink.count;
+    slot->text_dropped = sink.dropped;
+}
+
+// Receiver.SetSignalDebounce on the band's current listeners (rx/receiver.go:238-244)
+__global__ void k_set_debounce(ListenerSlot *slots, int n, int threshold)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && slots[i].active)
+        slots[i].deb.threshold = threshold;
+}
+
+hipError_t launch_listen(const float *spectrum, const sdr_frame_rec *recs, ListenerSlot *slots, const uint16_t *morse,
+                         uint32_t *text, sdr_edge *edges, uint64_t *raw_bits, uint64_t *deb_bits, float *tr_values,
+                         uint8_t *tr_raw, uint8_t *tr_deb, ListenGeom g, int n_frames, int n_slots, int n_bands,
+                         hipStream_t stream)
+{
+    if (n_slots == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(k_listen_gather, dim3((n_frames + 63) / 64, n_slots, n_bands), dim3(64), 0, stream, spectrum,
+                       recs, slots, raw_bits, tr_values, tr_raw, g, n_frames);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return e;
+    const int n_total = n_bands * g.max_listeners;
+    hipLaunchKernelGGL(k_listen_decode, dim3((n_total + 63) / 64), dim3(64), 0, stream, slots, morse, raw_bits,
+                       deb_bits, text, edges, tr_deb, g, n_frames, n_total);
+    return hipGetLastError();
+}
+
+hipError_t launch_listener_stop(ListenerSlot *slot, const uint16_t *morse, uint32_t *text, int text_cap,
+                                hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_listener_stop, dim3(1), dim3(64), 0, stream, slot, morse, text, text_cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_set_debounce(ListenerSlot *slots, int n, int threshold, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_set_debounce, dim3((n + 63) / 64), dim3(64), 0, stream, slots, n, threshold);
+    return hipGetLastError();
+}
+
+}  // namespace sdr

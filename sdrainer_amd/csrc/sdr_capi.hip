@@ -92,7 +92,8 @@ struct sdr_bank {
     DevBuf<uint16_t> morse;
     DevBuf<uint32_t> text;    // [band][L][text_cap]
     DevBuf<sdr_edge> edges;   // [band][L][edge_cap]
-    DevBuf<uint64_t> bits;    // [band][L][bit_words]
+    DevBuf<uint64_t> bits;    // [band][L][bit_words] debounced on/off bits of the last batch
+    DevBuf<uint64_t> raw_bits;  // same layout, before the debouncer
     DevBuf<float> tr_values;  // [band][max_batch][L]
     DevBuf<uint8_t> tr_raw, tr_deb;
     DevBuf<float> carry[2];          // [band][N] cumulation carried between batches (double buffered)
@@ -259,8 +260,8 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         lg.bit_words = b->bit_words;
         lg.trace = c.trace;
         lg.frame_base = (uint32_t)b->total_frames;
-        HIP_TRY(sdr::launch_listen(b->spectrum.p, b->recs.p, b->slots.p, b->morse.p, b->text.p, b->edges.p, b->bits.p,
-                                   b->tr_values.p, b->tr_raw.p, b->tr_deb.p, lg, n_frames, max_slots, B, b->stream));
+        HIP_TRY(sdr::launch_listen(b->spectrum.p, b->recs.p, b->slots.p, b->morse.p, b->text.p, b->edges.p, b->raw_bits.p,
+                                   b->bits.p, b->tr_values.p, b->tr_raw.p, b->tr_deb.p, lg, n_frames, max_slots, B, b->stream));
     }
     // cumulation slots of this batch (rx/receiver.go:404-409,459-460)
     const int count0 = b->cum_count;
@@ -368,6 +369,7 @@ int sdr_create(const sdr_config *cfg, sdr_bank **out)
     ALLOC(b->text, B * L * (size_t)b->text_cap);
     ALLOC(b->edges, B * L * (size_t)b->edge_cap);
     ALLOC(b->bits, B * L * (size_t)b->bit_words);
+    ALLOC(b->raw_bits, B * L * (size_t)b->bit_words);
     if (cfg->trace) {
         ALLOC(b->tr_values, B * F * L);
         ALLOC(b->tr_raw, B * F * L);
@@ -419,6 +421,7 @@ int sdr_destroy(sdr_bank *b)
     b->text.release();
     b->edges.release();
     b->bits.release();
+    b->raw_bits.release();
     b->tr_values.release();
     b->tr_raw.release();
     b->tr_deb.release();

@@ -72,8 +72,9 @@ hipError_t launch_noise_stats(const float *psd, const double *win_mean, sdr_fram
 hipError_t launch_thresholds(sdr_frame_rec *recs, BandState *st, int n_frames, int n_bands, int stride,
                              hipStream_t stream);
 hipError_t launch_listen(const float *spectrum, const sdr_frame_rec *recs, ListenerSlot *slots, const uint16_t *morse,
-                         uint32_t *text, sdr_edge *edges, uint64_t *bits, float *tr_values, uint8_t *tr_raw,
-                         uint8_t *tr_deb, ListenGeom g, int n_frames, int n_slots, int n_bands, hipStream_t stream);
+                         uint32_t *text, sdr_edge *edges, uint64_t *raw_bits, uint64_t *deb_bits, float *tr_values,
+                         uint8_t *tr_raw, uint8_t *tr_deb, ListenGeom g, int n_frames, int n_slots, int n_bands,
+                         hipStream_t stream);
 hipError_t launch_listener_stop(ListenerSlot *slot, const uint16_t *morse, uint32_t *text, int text_cap,
                                 hipStream_t stream);
 hipError_t launch_set_debounce(ListenerSlot *slots, int n, int threshold, hipStream_t stream);

@@ -51,7 +51,9 @@ def test_code_object_is_gfx950_only(lib_path):
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
     if not os.path.exists(objdump):
         pytest.skip("llvm-objdump not available")
-    out = subprocess.run([objdump, "--offloading", lib_path], capture_output=True, text=True).stdout
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:  # --offloading extracts the code objects into the cwd
+        out = subprocess.run([objdump, "--offloading", lib_path], capture_output=True, text=True, cwd=tmp).stdout
     archs = set(re.findall(r"gfx[0-9a-f]+", out))
     assert archs == {"gfx950"}, archs
 
