@@ -180,8 +180,8 @@ int sdr_read_decoder_state(sdr_bank *bank, int band, int listener_id, double *ou
 /* measurement ------------------------------------------------------------------------------- */
 /* When enabled every kernel launch is bracketed by HIP events on the bank's stream. */
 int sdr_profile_enable(sdr_bank *bank, int on);
-/* kernel: 0 fft_project, 1 window_means, 2 noise_stats, 3 thresholds, 4 listen_decode,
- *         5 cumulate, 6 find_peaks.  Returns accumulated milliseconds and launch count. */
+/* kernel: 0 fft_project, 1 window_means, 2 noise_stats, 3 thresholds, 4 listen_gather,
+ *         5 cumulate, 6 find_peaks, 7 listen_decode.  Returns accumulated milliseconds and launch count. */
 int sdr_profile_read(sdr_bank *bank, int kernel, double *total_ms, int *launches);
 int sdr_profile_reset(sdr_bank *bank);
 const char *sdr_kernel_name(int kernel);

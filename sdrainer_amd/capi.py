@@ -16,8 +16,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsdrainer_hip.so")
 
 OK, ERR_BAD_ARG, ERR_BAD_RATE, ERR_BAD_SIZE, ERR_WOULD_DROP, ERR_HIP, ERR_NO_SLOT, ERR_STATE = range(8)
 CUMULATION_SIZE = 100
-KERNELS = ("k_fft_project", "k_window_means", "k_noise_stats", "k_thresholds", "k_listen", "k_cumulate",
-           "k_find_peaks")
+KERNELS = ("k_fft_project", "k_window_means", "k_noise_stats", "k_thresholds", "k_listen_gather", "k_cumulate",
+           "k_find_peaks", "k_listen_decode")
 
 
 class SdrError(RuntimeError):

@@ -142,18 +142,19 @@ __global__ void k_set_debounce(ListenerSlot *slots, int n, int threshold)
         slots[i].deb.threshold = threshold;
 }
 
-hipError_t launch_listen(const float *spectrum, const sdr_frame_rec *recs, ListenerSlot *slots, const uint16_t *morse,
-                         uint32_t *text, sdr_edge *edges, uint64_t *raw_bits, uint64_t *deb_bits, float *tr_values,
-                         uint8_t *tr_raw, uint8_t *tr_deb, ListenGeom g, int n_frames, int n_slots, int n_bands,
-                         hipStream_t stream)
+hipError_t launch_listen_gather(const float *spectrum, const sdr_frame_rec *recs, const ListenerSlot *slots,
+                                uint64_t *raw_bits, float *tr_values, uint8_t *tr_raw, ListenGeom g, int n_frames,
+                                int n_slots, int n_bands, hipStream_t stream)
 {
-    if (n_slots == 0)
-        return hipSuccess;
     hipLaunchKernelGGL(k_listen_gather, dim3((n_frames + 63) / 64, n_slots, n_bands), dim3(64), 0, stream, spectrum,
                        recs, slots, raw_bits, tr_values, tr_raw, g, n_frames);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess)
-        return e;
+    return hipGetLastError();
+}
+
+hipError_t launch_listen_decode(ListenerSlot *slots, const uint16_t *morse, const uint64_t *raw_bits,
+                                uint64_t *deb_bits, uint32_t *text, sdr_edge *edges, uint8_t *tr_deb, ListenGeom g,
+                                int n_frames, int n_bands, hipStream_t stream)
+{
     const int n_total = n_bands * g.max_listeners;
     hipLaunchKernelGGL(k_listen_decode, dim3((n_total + 63) / 64), dim3(64), 0, stream, slots, morse, raw_bits,
                        deb_bits, text, edges, tr_deb, g, n_frames, n_total);

@@ -4,10 +4,10 @@
 // FindNoiseFloor is two SEQUENTIAL float64 accumulations per frame (window sums, then the variance
 // about the winning window's mean): float64 addition is not associative, so to reproduce the
 // reference's bits each chain keeps its order — one lane per chain.  What is parallel is everything
-// around the chain: a wave owns 64 chains of 64 consecutive frames, its lanes fetch each chain's next
-// 64 values with one fully coalesced 256-byte load per chain, transpose them through LDS, and only then
-// does every lane walk its own row.  The next tile's loads are in flight while the current one is
-// consumed.
+// around the chain: a workgroup owns 64 chains (64 consecutive frames); three producer waves fetch each
+// chain's next 64 values with one fully coalesced 256-byte load, widen / subtract / square them in
+// float64 and lay them down in LDS transposed, double-buffered; the consumer wave's lane i then only
+// reads row i and adds — the strictly serial part is one ds_read_b64 + one v_add_f64 per term.
 #include <hip/hip_runtime.h>
 
 #include "../../include/sdrainer_hip.h"
@@ -17,109 +17,130 @@
 namespace sdr {
 
 constexpr int TILE = 64;
+constexpr int CHAIN_THREADS = 256;  // wave 0 = consumer (the chains), waves 1-3 = producers
 
-// Stage tile `t` (64 columns) of 64 equally long rows that start `row_stride` floats apart into regs.
-__device__ __forceinline__ void tile_load(const float *__restrict__ base, size_t row_stride, int rows, int col0,
-                                          int n_cols, int lane, float (&regs)[TILE])
+struct ChainShared {
+    double term[2][TILE][TILE + 1];  // [buffer][chain][column], row stride 65 doubles: conflict-free both ways
+    double mean[TILE];               // per chain: value subtracted before squaring (variance pass)
+    int n_terms[TILE];               // per chain: number of leading terms that count
+};
+
+// Producer side: waves 1..3 stage tile `t` — 64 columns of every chain — as float64 terms.
+// Row r of the tile is one coalesced 256-byte read of chain r's next 64 floats.  Terms past a chain's
+// own end are stored as +0.0: adding +0.0 to a non-negative float64 sum leaves it bit-identical, so the
+// consumer needs no per-lane predicate.
+template <bool VARIANCE>
+__device__ __forceinline__ void chain_produce(ChainShared &sh, int buf, const float *__restrict__ base,
+                                              size_t row_stride, int rows, int n_cols, int t, int wave, int lane)
 {
-    const int col = col0 + lane;
-#pragma unroll
-    for (int r = 0; r < TILE; r++)
-        regs[r] = (r < rows && col < n_cols) ? base[(size_t)r * row_stride + col] : 0.f;
+    const int col = t * TILE + lane;
+    for (int r = wave - 1; r < TILE; r += 3) {
+        double x = 0.0;
+        if (r < rows && col < n_cols && col < sh.n_terms[r]) {
+            x = (double)base[(size_t)r * row_stride + col];
+            if (VARIANCE) {
+                const double d = x - sh.mean[r];
+                x = d * d;  // math.Pow(d, 2)
+            }
+        }
+        sh.term[buf][r][lane] = x;
+    }
 }
 
-__device__ __forceinline__ void tile_store(float (*tile)[TILE + 1], int lane, const float (&regs)[TILE])
+// Consumer side: lane = chain; 64 strictly ordered float64 additions per tile.
+__device__ __forceinline__ double chain_consume(const ChainShared &sh, int buf, int lane, double sum)
 {
 #pragma unroll
-    for (int r = 0; r < TILE; r++)
-        tile[r][lane] = regs[r];
+    for (int j = 0; j < TILE; j++)
+        sum += sh.term[buf][lane][j];
+    return sum;
+}
+
+// Runs 64 chains (lane i of wave 0 owns chain i).  `my_terms` / `my_mean` are the consumer lane's chain
+// length and mean; returns the chain's sum in the consumer lanes.
+template <bool VARIANCE>
+__device__ __forceinline__ double chain_run(ChainShared &sh, const float *__restrict__ base, size_t row_stride,
+                                            int rows, int n_cols, int my_terms, double my_mean)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave == 0) {
+        sh.n_terms[lane] = my_terms;
+        sh.mean[lane] = my_mean;
+    }
+    __syncthreads();
+    int max_terms = sh.n_terms[lane];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        max_terms = max(max_terms, __shfl_xor(max_terms, o));
+    const int n_tiles = (max_terms + TILE - 1) / TILE;
+    if (wave > 0 && n_tiles > 0)
+        chain_produce<VARIANCE>(sh, 0, base, row_stride, rows, n_cols, 0, wave, lane);
+    __syncthreads();
+    double sum = 0;
+    for (int t = 0; t < n_tiles; t++) {
+        if (wave == 0)
+            sum = chain_consume(sh, t & 1, lane, sum);
+        else if (t + 1 < n_tiles)
+            chain_produce<VARIANCE>(sh, (t + 1) & 1, base, row_stride, rows, n_cols, t + 1, wave, lane);
+        __syncthreads();
+    }
+    return sum;
 }
 
 // pass 1: mean of window w of frame f = sequential float64 sum of psd[edge + w*W .. +W) / W (:239-241,:230)
-__global__ __launch_bounds__(64) void k_window_means(const float *__restrict__ psd, double *__restrict__ win_mean,
-                                                     NoiseGeom g, int n_frames, int stride)
+__global__ __launch_bounds__(CHAIN_THREADS) void k_window_means(const float *__restrict__ psd,
+                                                                double *__restrict__ win_mean, NoiseGeom g,
+                                                                int n_frames, int stride)
 {
-    __shared__ float tile[TILE][TILE + 1];
-    const int lane = threadIdx.x;
+    __shared__ ChainShared sh;
+    const int lane = threadIdx.x & 63;
     const int f0 = blockIdx.x * TILE, w = blockIdx.y, band = blockIdx.z;
     const int rows = min(TILE, n_frames - f0);
     const size_t frame0 = (size_t)band * stride + f0;
     const float *base = psd + frame0 * g.n + g.edge + (size_t)w * g.window;
-    const int n_tiles = (g.window + TILE - 1) / TILE;
-    float regs[TILE];
-    tile_load(base, g.n, rows, 0, g.window, lane, regs);
-    double sum = 0;
-    for (int t = 0; t < n_tiles; t++) {
-        tile_store(tile, lane, regs);
-        __syncthreads();
-        if (t + 1 < n_tiles)
-            tile_load(base, g.n, rows, (t + 1) * TILE, g.window, lane, regs);
-        const int lim = min(TILE, g.window - t * TILE);
-        for (int j = 0; j < lim; j++)
-            sum += (double)tile[lane][j];
-        __syncthreads();
-    }
-    if (lane < rows)
+    const double sum = chain_run<false>(sh, base, g.n, rows, g.window, lane < rows ? g.window : 0, 0.0);
+    if (threadIdx.x < rows)
         win_mean[(frame0 + lane) * 10 + w] = sum / (double)g.window;
 }
 
 // pass 2: pick the minimum window in the reference's order, then the variance chain over
 // psd[edge .. resultTo] (inclusive) about that mean, divided by windowSize (:244-249, App. C1);
 // finally the two dB inputs of the rolling means (rx/receiver.go:383-384).
-__global__ __launch_bounds__(64) void k_noise_stats(const float *__restrict__ psd, const double *__restrict__ win_mean,
-                                                    sdr_frame_rec *__restrict__ recs, NoiseGeom g, int n_frames,
-                                                    int stride)
+__global__ __launch_bounds__(CHAIN_THREADS) void k_noise_stats(const float *__restrict__ psd,
+                                                               const double *__restrict__ win_mean,
+                                                               sdr_frame_rec *__restrict__ recs, NoiseGeom g,
+                                                               int n_frames, int stride)
 {
-    __shared__ float tile[TILE][TILE + 1];
-    const int lane = threadIdx.x;
+    __shared__ ChainShared sh;
+    const int lane = threadIdx.x & 63;
+    const bool consumer = threadIdx.x < TILE;
     const int f0 = blockIdx.x * TILE, band = blockIdx.y;
     const int rows = min(TILE, n_frames - f0);
     const size_t frame0 = (size_t)band * stride + f0;
-    const bool valid = lane < rows;
-    const size_t frame = frame0 + (valid ? lane : 0);
-    const float *p = psd + frame * g.n;
+    const bool valid = consumer && lane < rows;
+    const size_t frame = frame0 + (lane < rows ? lane : 0);
 
-    double minValue = (double)p[0];
-    bool first = true;
-    double resultMean = 0;
-    int n_terms = 1;  // resultTo - resultFrom + 1 when no window qualifies (resultFrom = resultTo = 0)
-    bool from_edge = false;
-    for (int w = 0; w < g.n_windows; w++) {
-        const double mean = win_mean[frame * 10 + w];
-        if (mean < minValue || first) {  // :232
-            minValue = mean;
-            first = false;
-            resultMean = mean;
-            from_edge = true;  // resultFrom = edge: `from` is only assigned on the first iteration (App. C1)
-            n_terms = (w + 1) * g.window + 1;  // resultTo = edge + (w+1)*W
+    double minValue = 0, resultMean = 0;
+    int n_terms = 0;
+    if (valid) {
+        minValue = (double)psd[frame * g.n];  // :217, overridden by `first` as soon as a window is evaluated
+        bool first = true;
+        n_terms = 1;
+        for (int w = 0; w < g.n_windows; w++) {
+            const double mean = win_mean[frame * 10 + w];
+            if (mean < minValue || first) {  // :232
+                minValue = mean;
+                first = false;
+                resultMean = mean;
+                // resultFrom = edge (`from` is only assigned on the first iteration, App. C1),
+                // resultTo = edge + (w+1)*W  ->  (w+1)*W + 1 terms
+                n_terms = (w + 1) * g.window + 1;
+            }
         }
     }
-    if (!valid)
-        n_terms = 0;
-    // chain length of this wave = the longest lane; lanes past their own end just skip the add
-    int max_terms = n_terms;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        max_terms = max(max_terms, __shfl_xor(max_terms, o));
-    const float *base = psd + frame0 * g.n + (from_edge ? g.edge : 0);
-    // (from_edge is wave-uniform whenever n_windows >= 1, which sdr_create guarantees)
-    const int n_cols = g.n - g.edge;  // never read past the frame
-    const int n_tiles = (max_terms + TILE - 1) / TILE;
-    float regs[TILE];
-    tile_load(base, g.n, rows, 0, n_cols, lane, regs);
-    double sum = 0;
-    for (int t = 0; t < n_tiles; t++) {
-        tile_store(tile, lane, regs);
-        __syncthreads();
-        if (t + 1 < n_tiles)
-            tile_load(base, g.n, rows, (t + 1) * TILE, n_cols, lane, regs);
-        const int lim = min(TILE, n_terms - t * TILE);
-        for (int j = 0; j < lim; j++) {
-            const double d = (double)tile[lane][j] - resultMean;
-            sum += d * d;  // math.Pow(d, 2)
-        }
-        __syncthreads();
-    }
+    // sdr_create guarantees n_windows >= 9, so every chain starts at `edge`
+    const float *base = psd + frame0 * g.n + g.edge;
+    const double sum = chain_run<true>(sh, base, g.n, rows, g.n - g.edge, n_terms, resultMean);
     if (!valid)
         return;
     const double variance = sum / (double)g.window;
@@ -228,7 +249,7 @@ __global__ __launch_bounds__(256) void k_thresholds(sdr_frame_rec *__restrict__ 
 hipError_t launch_window_means(const float *psd, double *win_mean, NoiseGeom g, int n_frames, int n_bands, int stride,
                                hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_window_means, dim3((n_frames + TILE - 1) / TILE, g.n_windows, n_bands), dim3(64), 0, stream,
+    hipLaunchKernelGGL(k_window_means, dim3((n_frames + TILE - 1) / TILE, g.n_windows, n_bands), dim3(CHAIN_THREADS), 0, stream,
                        psd, win_mean, g, n_frames, stride);
     return hipGetLastError();
 }
@@ -236,7 +257,7 @@ hipError_t launch_window_means(const float *psd, double *win_mean, NoiseGeom g, 
 hipError_t launch_noise_stats(const float *psd, const double *win_mean, sdr_frame_rec *recs, NoiseGeom g, int n_frames,
                               int n_bands, int stride, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_noise_stats, dim3((n_frames + TILE - 1) / TILE, n_bands), dim3(64), 0, stream, psd, win_mean,
+    hipLaunchKernelGGL(k_noise_stats, dim3((n_frames + TILE - 1) / TILE, n_bands), dim3(CHAIN_THREADS), 0, stream, psd, win_mean,
                        recs, g, n_frames, stride);
     return hipGetLastError();
 }

@@ -60,8 +60,8 @@ int ilog2(int n)
     return s;
 }
 
-const char *kKernelNames[sdr::K_COUNT] = {"k_fft_project", "k_window_means", "k_noise_stats", "k_thresholds",
-                                          "k_listen",      "k_cumulate",     "k_find_peaks"};
+const char *kKernelNames[sdr::K_COUNT] = {"k_fft_project",   "k_window_means", "k_noise_stats", "k_thresholds",
+                                          "k_listen_gather", "k_cumulate",     "k_find_peaks",  "k_listen_decode"};
 
 }  // namespace
 
@@ -250,7 +250,6 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     for (int i = 0; i < B; i++)
         max_slots = std::max(max_slots, b->n_slots[i]);
     if (max_slots > 0) {
-        ProfScope ps(b, sdr::K_LISTEN);
         sdr::ListenGeom lg;
         lg.n = N;
         lg.stride = stride;
@@ -260,8 +259,16 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         lg.bit_words = b->bit_words;
         lg.trace = c.trace;
         lg.frame_base = (uint32_t)b->total_frames;
-        HIP_TRY(sdr::launch_listen(b->spectrum.p, b->recs.p, b->slots.p, b->morse.p, b->text.p, b->edges.p, b->raw_bits.p,
-                                   b->bits.p, b->tr_values.p, b->tr_raw.p, b->tr_deb.p, lg, n_frames, max_slots, B, b->stream));
+        {
+            ProfScope ps(b, sdr::K_LISTEN_GATHER);
+            HIP_TRY(sdr::launch_listen_gather(b->spectrum.p, b->recs.p, b->slots.p, b->raw_bits.p, b->tr_values.p,
+                                              b->tr_raw.p, lg, n_frames, max_slots, B, b->stream));
+        }
+        {
+            ProfScope ps(b, sdr::K_LISTEN_DECODE);
+            HIP_TRY(sdr::launch_listen_decode(b->slots.p, b->morse.p, b->raw_bits.p, b->bits.p, b->text.p, b->edges.p,
+                                              b->tr_deb.p, lg, n_frames, B, b->stream));
+        }
     }
     // cumulation slots of this batch (rx/receiver.go:404-409,459-460)
     const int count0 = b->cum_count;

@@ -59,7 +59,10 @@ struct PeakGeom {
     int n, stride, count0, max_chunks, max_peaks;
 };
 
-enum KernelId { K_FFT = 0, K_WINDOW_MEANS, K_NOISE_STATS, K_THRESHOLDS, K_LISTEN, K_CUMULATE, K_FIND_PEAKS, K_COUNT };
+enum KernelId {
+    K_FFT = 0, K_WINDOW_MEANS, K_NOISE_STATS, K_THRESHOLDS, K_LISTEN_GATHER, K_CUMULATE, K_FIND_PEAKS, K_LISTEN_DECODE,
+    K_COUNT
+};
 
 hipError_t launch_fft(int logn, const float *iq, const fft64::cplx *tw, float *spectrum, float *psd, int n_frames,
                       int n_bands, int in_stride, int out_stride, hipStream_t stream);
@@ -71,10 +74,12 @@ hipError_t launch_noise_stats(const float *psd, const double *win_mean, sdr_fram
                               int n_bands, int stride, hipStream_t stream);
 hipError_t launch_thresholds(sdr_frame_rec *recs, BandState *st, int n_frames, int n_bands, int stride,
                              hipStream_t stream);
-hipError_t launch_listen(const float *spectrum, const sdr_frame_rec *recs, ListenerSlot *slots, const uint16_t *morse,
-                         uint32_t *text, sdr_edge *edges, uint64_t *raw_bits, uint64_t *deb_bits, float *tr_values,
-                         uint8_t *tr_raw, uint8_t *tr_deb, ListenGeom g, int n_frames, int n_slots, int n_bands,
-                         hipStream_t stream);
+hipError_t launch_listen_gather(const float *spectrum, const sdr_frame_rec *recs, const ListenerSlot *slots,
+                                uint64_t *raw_bits, float *tr_values, uint8_t *tr_raw, ListenGeom g, int n_frames,
+                                int n_slots, int n_bands, hipStream_t stream);
+hipError_t launch_listen_decode(ListenerSlot *slots, const uint16_t *morse, const uint64_t *raw_bits,
+                                uint64_t *deb_bits, uint32_t *text, sdr_edge *edges, uint8_t *tr_deb, ListenGeom g,
+                                int n_frames, int n_bands, hipStream_t stream);
 hipError_t launch_listener_stop(ListenerSlot *slot, const uint16_t *morse, uint32_t *text, int text_cap,
                                 hipStream_t stream);
 hipError_t launch_set_debounce(ListenerSlot *slots, int n, int threshold, hipStream_t stream);

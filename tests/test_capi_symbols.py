@@ -42,7 +42,7 @@ def test_library_loads_and_reports_abi(lib_path):
     from sdrainer_amd import capi
     L = capi.load()
     assert L.sdr_abi_version() == 1
-    assert [L.sdr_kernel_name(i).decode() for i in range(7)] == list(capi.KERNELS)
+    assert [L.sdr_kernel_name(i).decode() for i in range(8)] == list(capi.KERNELS)
     assert ctypes.sizeof(capi.Config) == 56 and ctypes.sizeof(capi.Peak) == 40
     assert capi.FRAME_REC_DTYPE.itemsize == 40 and capi.EDGE_DTYPE.itemsize == 8
 
