@@ -252,6 +252,50 @@ SDR_HD inline void decoder_tick(DecoderState &d, bool state, const uint16_t *tab
     }
 }
 
+// Tick(state) for a tick that IS an edge (state != lastState) — the same arithmetic as decoder_tick,
+// arranged for a SIMD lane: rising and falling edges share one AdaptiveThreshold.Put (selected copy in,
+// selected copy out) instead of two divergent code paths.  The end-of-tick check (:244-249) is skipped
+// because currentDuration is 0 on an edge tick and upperBound is never negative.
+template <class Sink>
+SDR_HD inline void decoder_edge(DecoderState &d, bool state, const uint16_t *table, Sink &out)
+{
+    d.ticks += 1;
+    const double now = d.ticks;
+    const double duration = state ? now - d.offStart : now - d.onStart;  // offDuration / onDuration
+    if (state)
+        d.onStart = now;
+    else
+        d.offStart = now;
+    if (duration >= kMinDitTime) {  // :254, :279
+        AdaptiveThreshold t = state ? d.offThreshold : d.onThreshold;
+        at_put(t, duration);
+        if (state)
+            d.offThreshold = t;
+        else
+            d.onThreshold = t;
+        const double threshold = t.threshold;
+        if (state) {  // onRisingEdge :260-274
+            if (duration >= 4.5 * t.low) {
+                decode_current_char(d, table, out);
+                out.put(' ');
+            } else if (duration >= threshold) {
+                decode_current_char(d, table, out);
+            }
+        } else {  // onFallingEdge :285-297
+            if (duration >= 2 * t.high) {
+                d.currentCharInvalid = 1;
+            } else {
+                const bool da = duration >= threshold;
+                append_symbol(d, da, table, out);
+                if (da)
+                    d.wpm = (d.wpm + dit_to_wpm(d, t.low)) / 2.0;
+            }
+        }
+    }
+    d.decoding = 1;
+    d.lastState = state;
+}
+
 // `k` consecutive Tick(state) calls with state == lastState, in closed form.  Between edges Tick only
 // counts (`ticks++`) and checks `decoding && currentDuration > upperBound` (:244-249); neither
 // threshold changes, currentDuration = now - start is an exact integer, so the check first fires at

@@ -63,7 +63,8 @@ __global__ __launch_bounds__(64) void k_listen_decode(ListenerSlot *__restrict__
                                                       const uint16_t *__restrict__ morse,
                                                       const uint64_t *__restrict__ raw_bits,
                                                       uint64_t *__restrict__ deb_bits, uint32_t *__restrict__ text,
-                                                      sdr_edge *__restrict__ edges, uint8_t *__restrict__ tr_deb,
+                                                      sdr_edge *__restrict__ edges,
+                                                      uint32_t *__restrict__ edge_counts, uint8_t *__restrict__ tr_deb,
                                                       ListenGeom g, int n_frames, int n_total)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (band, slot) flattened
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(64) void k_listen_decode(ListenerSlot *__restrict__
                 if (n_edges < (uint32_t)g.edge_cap)
                     my_edges[n_edges] = sdr_edge{(uint32_t)(g.frame_base + f0 + pos), st ? 1u : 0u};
                 n_edges++;
-                cw::decoder_tick(dec, st, morse, sink);
+                cw::decoder_edge(dec, st, morse, sink);
                 pos++;
             }
         }
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(64) void k_listen_decode(ListenerSlot *__restrict__
     slot->dec = dec;
     slot->text_count = sink.count;
     slot->text_dropped = sink.dropped;
-    slot->edge_count = n_edges;
+    edge_counts[idx] = n_edges;
 }
 
 // cw.Decoder.stop for one listener (cw/decode.go:352-354)
@@ -152,12 +153,12 @@ hipError_t launch_listen_gather(const float *spectrum, const sdr_frame_rec *recs
 }
 
 hipError_t launch_listen_decode(ListenerSlot *slots, const uint16_t *morse, const uint64_t *raw_bits,
-                                uint64_t *deb_bits, uint32_t *text, sdr_edge *edges, uint8_t *tr_deb, ListenGeom g,
-                                int n_frames, int n_bands, hipStream_t stream)
+                                uint64_t *deb_bits, uint32_t *text, sdr_edge *edges, uint32_t *edge_counts,
+                                uint8_t *tr_deb, ListenGeom g, int n_frames, int n_bands, hipStream_t stream)
 {
     const int n_total = n_bands * g.max_listeners;
     hipLaunchKernelGGL(k_listen_decode, dim3((n_total + 63) / 64), dim3(64), 0, stream, slots, morse, raw_bits,
-                       deb_bits, text, edges, tr_deb, g, n_frames, n_total);
+                       deb_bits, text, edges, edge_counts, tr_deb, g, n_frames, n_total);
     return hipGetLastError();
 }
 

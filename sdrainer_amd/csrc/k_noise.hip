@@ -4,10 +4,11 @@
 // FindNoiseFloor is two SEQUENTIAL float64 accumulations per frame (window sums, then the variance
 // about the winning window's mean): float64 addition is not associative, so to reproduce the
 // reference's bits each chain keeps its order — one lane per chain.  What is parallel is everything
-// around the chain: a workgroup owns 64 chains (64 consecutive frames); three producer waves fetch each
-// chain's next 64 values with one fully coalesced 256-byte load, widen / subtract / square them in
-// float64 and lay them down in LDS transposed, double-buffered; the consumer wave's lane i then only
-// reads row i and adds — the strictly serial part is one ds_read_b64 + one v_add_f64 per term.
+// around the chain: a workgroup owns 64 chains (64 consecutive frames); seven producer waves take turns
+// fetching each chain's next 64 values (one fully coalesced 256-byte load per chain, kept in flight
+// across six barrier steps), widen / subtract / square them in float64 and lay them down in LDS
+// transposed, double-buffered; the consumer wave's lane i then only reads row i and adds — the strictly
+// serial part is one ds_read_b64 + one v_add_f64 per term.
 #include <hip/hip_runtime.h>
 
 #include "../../include/sdrainer_hip.h"
@@ -17,7 +18,8 @@
 namespace sdr {
 
 constexpr int TILE = 64;
-constexpr int CHAIN_THREADS = 256;  // wave 0 = consumer (the chains), waves 1-3 = producers
+constexpr int N_PRODUCERS = 7;  // wave 0 = consumer (the chains), waves 1..7 = producers
+constexpr int CHAIN_THREADS = 64 * (1 + N_PRODUCERS);
 
 struct ChainShared {
     double term[2][TILE][TILE + 1];  // [buffer][chain][column], row stride 65 doubles: conflict-free both ways
@@ -25,29 +27,56 @@ struct ChainShared {
     int n_terms[TILE];               // per chain: number of leading terms that count
 };
 
-// Producer side: waves 1..3 stage tile `t` — 64 columns of every chain — as float64 terms.
-// Row r of the tile is one coalesced 256-byte read of chain r's next 64 floats.  Terms past a chain's
-// own end are stored as +0.0: adding +0.0 to a non-negative float64 sum leaves it bit-identical, so the
-// consumer needs no per-lane predicate.
+constexpr int ROWS_PER = (TILE + N_PRODUCERS - 1) / N_PRODUCERS;  // rows p, p+7, ... of every tile: <= 10
+constexpr int DEPTH = 6;                                           // tiles a producer keeps in flight
+
+// What a producer wave keeps about its own rows (p, p+7, ...) for the whole chain.
+struct ProducerRows {
+    int n_terms[ROWS_PER];
+    double mean[ROWS_PER];
+    unsigned row_off[ROWS_PER];  // r * row_stride: 32-bit offsets keep the address math on one VALU add
+};
+
+// Producer, step 1: issue this wave's coalesced row loads of tile `t` (row r = chain r's next 64 floats,
+// one 256-byte read) and keep them in flight in VGPRs.
+__device__ __forceinline__ void tile_issue(const float *__restrict__ base, const ProducerRows &pr, int rows, int n_cols,
+                                           int t, int p, int lane, float (&regs)[ROWS_PER])
+{
+    const unsigned col = (unsigned)(t * TILE + lane);
+    const bool in = (int)col < n_cols;
+#pragma unroll
+    for (int i = 0; i < ROWS_PER; i++) {
+        const int r = p + i * N_PRODUCERS;
+        regs[i] = (in && r < rows) ? base[pr.row_off[i] + col] : 0.f;
+    }
+}
+
+// Producer, step 2 (DEPTH barrier steps later): widen / subtract / square in float64 and lay the rows
+// down transposed.  Terms past a chain's own end are stored as +0.0: adding +0.0 to a non-negative
+// float64 sum leaves it bit-identical, so the consumer needs no per-lane predicate.  `full` (wave
+// uniform) says every chain still covers the whole tile, so the end test is skipped.
 template <bool VARIANCE>
-__device__ __forceinline__ void chain_produce(ChainShared &sh, int buf, const float *__restrict__ base,
-                                              size_t row_stride, int rows, int n_cols, int t, int wave, int lane)
+__device__ __forceinline__ void tile_publish(ChainShared &sh, const ProducerRows &pr, int buf, int t, int p, int lane,
+                                             bool full, const float (&regs)[ROWS_PER])
 {
     const int col = t * TILE + lane;
-    for (int r = wave - 1; r < TILE; r += 3) {
-        double x = 0.0;
-        if (r < rows && col < n_cols && col < sh.n_terms[r]) {
-            x = (double)base[(size_t)r * row_stride + col];
-            if (VARIANCE) {
-                const double d = x - sh.mean[r];
-                x = d * d;  // math.Pow(d, 2)
-            }
+#pragma unroll
+    for (int i = 0; i < ROWS_PER; i++) {
+        const int r = p + i * N_PRODUCERS;
+        if (r >= TILE)
+            break;
+        double x = (double)regs[i];
+        if (VARIANCE) {
+            const double d = x - pr.mean[i];
+            x = d * d;  // math.Pow(d, 2)
         }
+        if (!full && col >= pr.n_terms[i])
+            x = 0.0;
         sh.term[buf][r][lane] = x;
     }
 }
 
-// Consumer side: lane = chain; 64 strictly ordered float64 additions per tile.
+// Consumer: lane = chain; 64 strictly ordered float64 additions per tile.
 __device__ __forceinline__ double chain_consume(const ChainShared &sh, int buf, int lane, double sum)
 {
 #pragma unroll
@@ -57,7 +86,9 @@ __device__ __forceinline__ double chain_consume(const ChainShared &sh, int buf, 
 }
 
 // Runs 64 chains (lane i of wave 0 owns chain i).  `my_terms` / `my_mean` are the consumer lane's chain
-// length and mean; returns the chain's sum in the consumer lanes.
+// length and mean; returns the chain's sum in the consumer lanes.  At barrier step s the consumer adds
+// tile s while every producer publishes its rows of tile s+1 (loaded DEPTH steps earlier) and re-issues
+// the same register slot for tile s+1+DEPTH.
 template <bool VARIANCE>
 __device__ __forceinline__ double chain_run(ChainShared &sh, const float *__restrict__ base, size_t row_stride,
                                             int rows, int n_cols, int my_terms, double my_mean)
@@ -68,21 +99,48 @@ __device__ __forceinline__ double chain_run(ChainShared &sh, const float *__rest
         sh.mean[lane] = my_mean;
     }
     __syncthreads();
-    int max_terms = sh.n_terms[lane];
+    int max_terms = sh.n_terms[lane], min_terms = max_terms;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
+    for (int o = 32; o > 0; o >>= 1) {
         max_terms = max(max_terms, __shfl_xor(max_terms, o));
+        min_terms = min(min_terms, __shfl_xor(min_terms, o));
+    }
     const int n_tiles = (max_terms + TILE - 1) / TILE;
-    if (wave > 0 && n_tiles > 0)
-        chain_produce<VARIANCE>(sh, 0, base, row_stride, rows, n_cols, 0, wave, lane);
-    __syncthreads();
+    const int p = wave - 1;
+    ProducerRows pr;
+    float ring[DEPTH][ROWS_PER];
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < ROWS_PER; i++) {
+            const int r = min(p + i * N_PRODUCERS, TILE - 1);
+            pr.n_terms[i] = sh.n_terms[r];
+            pr.mean[i] = sh.mean[r];
+            pr.row_off[i] = (unsigned)r * (unsigned)row_stride;
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++)
+            if (d < n_tiles)
+                tile_issue(base, pr, rows, n_cols, d, p, lane, ring[d]);
+    }
     double sum = 0;
-    for (int t = 0; t < n_tiles; t++) {
-        if (wave == 0)
-            sum = chain_consume(sh, t & 1, lane, sum);
-        else if (t + 1 < n_tiles)
-            chain_produce<VARIANCE>(sh, (t + 1) & 1, base, row_stride, rows, n_cols, t + 1, wave, lane);
-        __syncthreads();
+    for (int s0 = -1; s0 < n_tiles; s0 += DEPTH) {
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) {  // register slot k holds tile s+1 (== k mod DEPTH)
+            const int s = s0 + k;
+            if (s < n_tiles) {             // wave-uniform
+                if (wave == 0) {
+                    if (s >= 0)
+                        sum = chain_consume(sh, s & 1, lane, sum);
+                } else {
+                    const int t = s + 1;
+                    if (t < n_tiles)
+                        tile_publish<VARIANCE>(sh, pr, t & 1, t, p, lane, (t + 1) * TILE <= min_terms, ring[k]);
+                    if (t + DEPTH < n_tiles)
+                        tile_issue(base, pr, rows, n_cols, t + DEPTH, p, lane, ring[k]);
+                }
+                __syncthreads();
+            }
+        }
     }
     return sum;
 }

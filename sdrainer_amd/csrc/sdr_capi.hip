@@ -1,7 +1,25 @@
 // sdr_capi.hip — the C ABI of libsdrainer_hip.so (include/sdrainer_hip.h): owns the HBM-resident
-// state of a bank of receivers and sequences the kernels of sdr_kernels.hip on one HIP stream.
+// state of a bank of receivers and sequences the kernels on HIP streams.
+//
+// Scheduling.  The FFT/projection kernel is throughput work that fills the whole chip; everything
+// after it is a set of short, strictly ordered chains (float64 noise-floor sums, the rolling means,
+// the per-signal decoders) that occupy a handful of CUs for a long time.  Run back to back they would
+// leave the chip idle most of the step, so a bank is a four-stage software pipeline on four streams:
+//
+//   s_fft     k_fft_project(i)                                        (the caller's stream)
+//   s_noise   k_window_means(i) -> k_noise_stats(i) -> k_thresholds(i)
+//   s_listen  k_listen_gather(i) -> k_listen_decode(i)
+//   s_peaks   k_cumulate(i) -> k_find_peaks(i)
+//
+// Batch i's per-batch buffers (spectrum, psd, frame records, keying bits, peaks ...) live in set
+// i % RING, and events order the stages: noise(i) after fft(i); listen(i) after noise(i); cumulate(i)
+// after fft(i), find_peaks(i) after noise(i); fft(i) after every reader of set i % RING from batch
+// i - RING.  State that is carried from frame to frame (rolling rings, cumulation carry, decoders) is
+// only ever touched by one stage, whose stream keeps it in batch order.  Results are read after
+// sdr_sync(), which drains all four streams.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -63,6 +81,45 @@ int ilog2(int n)
 const char *kKernelNames[sdr::K_COUNT] = {"k_fft_project",   "k_window_means", "k_noise_stats", "k_thresholds",
                                           "k_listen_gather", "k_cumulate",     "k_find_peaks",  "k_listen_decode"};
 
+constexpr int RING = 3;  // per-batch buffer sets in flight
+enum Stage { S_FFT = 0, S_NOISE, S_LISTEN, S_PEAKS, N_STAGES };
+
+// Everything one batch produces.
+struct BatchSet {
+    DevBuf<float> spectrum, psd;      // [band][max_batch][N]
+    DevBuf<double> win_mean;          // [band][max_batch][10]
+    DevBuf<sdr_frame_rec> recs;       // [band][max_batch]
+    DevBuf<uint64_t> raw_bits, bits;  // [band][L][bit_words] before / after the debouncer
+    DevBuf<sdr_edge> edges;           // [band][L][edge_cap]
+    DevBuf<uint32_t> edge_counts;     // [band][L] edges produced by this batch
+    DevBuf<float> tr_values;          // [band][max_batch][L] (trace only)
+    DevBuf<uint8_t> tr_raw, tr_deb;
+    DevBuf<float> cum_out;            // [band][max_chunks][N]
+    DevBuf<sdr::DevPeak> dev_peaks;   // [band][max_chunks][max_peaks]
+    DevBuf<int> peak_counts;          // [band][max_chunks]
+    hipEvent_t done[N_STAGES] = {};   // recorded when the stage has finished with this set
+    void release()
+    {
+        spectrum.release();
+        psd.release();
+        win_mean.release();
+        recs.release();
+        raw_bits.release();
+        bits.release();
+        edges.release();
+        edge_counts.release();
+        tr_values.release();
+        tr_raw.release();
+        tr_deb.release();
+        cum_out.release();
+        dev_peaks.release();
+        peak_counts.release();
+        for (auto &e : done)
+            if (e)
+                (void)hipEventDestroy(e);
+    }
+};
+
 }  // namespace
 
 namespace sdr {
@@ -72,58 +129,43 @@ int set_error(int code, const char *msg) { return fail(code, msg); }
 struct sdr_bank {
     sdr_config cfg{};
     int logn = 0;
-    hipStream_t stream = nullptr;
     int device = 0;
+    hipStream_t stream[N_STAGES] = {};  // stream[S_FFT] is the caller's (or the null stream)
+    bool own_stream[N_STAGES] = {};
 
-    // geometry
     int max_chunks = 0;
     int text_cap = 2048;
     int edge_cap = 0;
     int bit_words = 0;
 
-    // device buffers
     DevBuf<fft64::cplx> tw;
     DevBuf<float> iq_stage_dev;  // [band][max_batch][2N] for the host-staged path
-    DevBuf<float> spectrum, psd;  // [band][max_batch][N]
-    DevBuf<double> win_mean;      // [band][max_batch][10]
-    DevBuf<sdr_frame_rec> recs;   // [band][max_batch]
+    BatchSet set[RING];
     DevBuf<sdr::BandState> band_state;
     DevBuf<sdr::ListenerSlot> slots;  // [band][max_listeners]
     DevBuf<uint16_t> morse;
-    DevBuf<uint32_t> text;    // [band][L][text_cap]
-    DevBuf<sdr_edge> edges;   // [band][L][edge_cap]
-    DevBuf<uint64_t> bits;    // [band][L][bit_words] debounced on/off bits of the last batch
-    DevBuf<uint64_t> raw_bits;  // same layout, before the debouncer
-    DevBuf<float> tr_values;  // [band][max_batch][L]
-    DevBuf<uint8_t> tr_raw, tr_deb;
-    DevBuf<float> carry[2];          // [band][N] cumulation carried between batches (double buffered)
-    DevBuf<float> cum_out;           // [band][max_chunks][N]
-    DevBuf<sdr::DevPeak> dev_peaks;  // [band][max_chunks][max_peaks]
-    DevBuf<int> peak_counts;         // [band][max_chunks]
+    DevBuf<uint32_t> text;   // [band][L][text_cap]
+    DevBuf<float> carry[2];  // [band][N] cumulation carried between batches (double buffered)
 
-    // host mirrors
     std::vector<sdr::BandState> h_band_state;
     std::vector<sdr::ListenerSlot> h_slots;  // authoritative only for active/bin at attach time
     std::vector<int> n_slots;                // high-water mark of used slots per band
     std::vector<int64_t> center_frequency;
-    std::vector<uint16_t> h_morse;
     int carry_cur = 0;
     int cum_count = 0;  // cumulationCount, identical for every band of the bank
     int64_t total_frames = 0;
-    int last_frames = 0, last_chunks = 0, last_count0 = 0;
+    int64_t batch_index = 0;
+    int last_set = 0, last_frames = 0, last_chunks = 0, last_count0 = 0;
     int edge_width = 0;
     int find_peaks = 1;
 
-    // host staging (pinned)
-    float *h_stage = nullptr;  // [band][max_batch][2N]
+    float *h_stage = nullptr;  // pinned [band][max_batch][2N]
     std::vector<int> staged;
 
-    // profiling
     bool profiling = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double prof_ms[sdr::K_COUNT] = {};
     int prof_n[sdr::K_COUNT] = {};
-    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;  // events to resolve at sync
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
 
     sdr::NoiseGeom noise_geom() const
     {
@@ -144,19 +186,20 @@ namespace {
 struct ProfScope {
     sdr_bank *b;
     int k;
+    hipStream_t s;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    ProfScope(sdr_bank *bank, int kernel) : b(bank), k(kernel)
+    ProfScope(sdr_bank *bank, int kernel, hipStream_t st) : b(bank), k(kernel), s(st)
     {
         if (b->profiling) {
             (void)hipEventCreate(&e0);
             (void)hipEventCreate(&e1);
-            (void)hipEventRecord(e0, b->stream);
+            (void)hipEventRecord(e0, s);
         }
     }
     ~ProfScope()
     {
         if (b->profiling) {
-            (void)hipEventRecord(e1, b->stream);
+            (void)hipEventRecord(e1, s);
             b->pending.push_back({k, {e0, e1}});
         }
     }
@@ -178,7 +221,9 @@ void resolve_profile(sdr_bank *b)
 
 int sync_bank(sdr_bank *b)
 {
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipSetDevice(b->device));
+    for (int s = 0; s < N_STAGES; s++)
+        HIP_TRY(hipStreamSynchronize(b->stream[s]));
     resolve_profile(b);
     return SDR_OK;
 }
@@ -229,26 +274,42 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     HIP_TRY(hipSetDevice(b->device));
     const int B = c.n_bands, N = c.block_size, stride = c.max_batch_frames;
     const sdr::NoiseGeom ng = b->noise_geom();
+    const int si = (int)(b->batch_index % RING);
+    BatchSet &S = b->set[si];
+    hipStream_t s_fft = b->stream[S_FFT], s_noise = b->stream[S_NOISE], s_listen = b->stream[S_LISTEN],
+                s_peaks = b->stream[S_PEAKS];
+
+    // stage 0: FFT + projection, once every reader of this set (batch i - RING) is done with it
+    HIP_TRY(hipStreamWaitEvent(s_fft, S.done[S_NOISE], 0));
+    HIP_TRY(hipStreamWaitEvent(s_fft, S.done[S_LISTEN], 0));
+    HIP_TRY(hipStreamWaitEvent(s_fft, S.done[S_PEAKS], 0));
     {
-        ProfScope ps(b, sdr::K_FFT);
-        HIP_TRY(sdr::launch_fft(b->logn, iq_dev, b->tw.p, b->spectrum.p, b->psd.p, n_frames, B, in_stride, stride,
-                                b->stream));
+        ProfScope ps(b, sdr::K_FFT, s_fft);
+        HIP_TRY(sdr::launch_fft(b->logn, iq_dev, b->tw.p, S.spectrum.p, S.psd.p, n_frames, B, in_stride, stride, s_fft));
+    }
+    HIP_TRY(hipEventRecord(S.done[S_FFT], s_fft));
+
+    // stage 1: noise floor + thresholds
+    HIP_TRY(hipStreamWaitEvent(s_noise, S.done[S_FFT], 0));
+    {
+        ProfScope ps(b, sdr::K_WINDOW_MEANS, s_noise);
+        HIP_TRY(sdr::launch_window_means(S.psd.p, S.win_mean.p, ng, n_frames, B, stride, s_noise));
     }
     {
-        ProfScope ps(b, sdr::K_WINDOW_MEANS);
-        HIP_TRY(sdr::launch_window_means(b->psd.p, b->win_mean.p, ng, n_frames, B, stride, b->stream));
+        ProfScope ps(b, sdr::K_NOISE_STATS, s_noise);
+        HIP_TRY(sdr::launch_noise_stats(S.psd.p, S.win_mean.p, S.recs.p, ng, n_frames, B, stride, s_noise));
     }
     {
-        ProfScope ps(b, sdr::K_NOISE_STATS);
-        HIP_TRY(sdr::launch_noise_stats(b->psd.p, b->win_mean.p, b->recs.p, ng, n_frames, B, stride, b->stream));
+        ProfScope ps(b, sdr::K_THRESHOLDS, s_noise);
+        HIP_TRY(sdr::launch_thresholds(S.recs.p, b->band_state.p, n_frames, B, stride, s_noise));
     }
-    {
-        ProfScope ps(b, sdr::K_THRESHOLDS);
-        HIP_TRY(sdr::launch_thresholds(b->recs.p, b->band_state.p, n_frames, B, stride, b->stream));
-    }
+    HIP_TRY(hipEventRecord(S.done[S_NOISE], s_noise));
+
+    // stage 2: per-signal envelope + decoder
     int max_slots = 0;
     for (int i = 0; i < B; i++)
         max_slots = std::max(max_slots, b->n_slots[i]);
+    HIP_TRY(hipStreamWaitEvent(s_listen, S.done[S_NOISE], 0));
     if (max_slots > 0) {
         sdr::ListenGeom lg;
         lg.n = N;
@@ -260,17 +321,19 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         lg.trace = c.trace;
         lg.frame_base = (uint32_t)b->total_frames;
         {
-            ProfScope ps(b, sdr::K_LISTEN_GATHER);
-            HIP_TRY(sdr::launch_listen_gather(b->spectrum.p, b->recs.p, b->slots.p, b->raw_bits.p, b->tr_values.p,
-                                              b->tr_raw.p, lg, n_frames, max_slots, B, b->stream));
+            ProfScope ps(b, sdr::K_LISTEN_GATHER, s_listen);
+            HIP_TRY(sdr::launch_listen_gather(S.spectrum.p, S.recs.p, b->slots.p, S.raw_bits.p, S.tr_values.p,
+                                              S.tr_raw.p, lg, n_frames, max_slots, B, s_listen));
         }
         {
-            ProfScope ps(b, sdr::K_LISTEN_DECODE);
-            HIP_TRY(sdr::launch_listen_decode(b->slots.p, b->morse.p, b->raw_bits.p, b->bits.p, b->text.p, b->edges.p,
-                                              b->tr_deb.p, lg, n_frames, B, b->stream));
+            ProfScope ps(b, sdr::K_LISTEN_DECODE, s_listen);
+            HIP_TRY(sdr::launch_listen_decode(b->slots.p, b->morse.p, S.raw_bits.p, S.bits.p, b->text.p, S.edges.p,
+                                              S.edge_counts.p, S.tr_deb.p, lg, n_frames, B, s_listen));
         }
     }
-    // cumulation slots of this batch (rx/receiver.go:404-409,459-460)
+    HIP_TRY(hipEventRecord(S.done[S_LISTEN], s_listen));
+
+    // stage 3: cumulation + peak scan (rx/receiver.go:404-409,459-460)
     const int count0 = b->cum_count;
     const int first_len = SDR_CUMULATION_SIZE - count0;
     int n_slots_c = 1, n_chunks = 0;
@@ -279,11 +342,12 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         const int rem = (n_frames - first_len) % SDR_CUMULATION_SIZE;
         n_slots_c = n_chunks + (rem > 0 ? 1 : 0);
     }
+    HIP_TRY(hipStreamWaitEvent(s_peaks, S.done[S_FFT], 0));
     {
-        ProfScope ps(b, sdr::K_CUMULATE);
+        ProfScope ps(b, sdr::K_CUMULATE, s_peaks);
         sdr::CumGeom cg{N, stride, n_frames, count0, b->max_chunks};
-        HIP_TRY(sdr::launch_cumulate(b->spectrum.p, b->carry[b->carry_cur].p, b->carry[b->carry_cur ^ 1].p,
-                                     b->cum_out.p, cg, n_slots_c, B, b->stream));
+        HIP_TRY(sdr::launch_cumulate(S.spectrum.p, b->carry[b->carry_cur].p, b->carry[b->carry_cur ^ 1].p, S.cum_out.p,
+                                     cg, n_slots_c, B, s_peaks));
     }
     const int new_count = (count0 + n_frames) % SDR_CUMULATION_SIZE;
     // the carry buffer flips only when this batch wrote a new partial cumulation; if the batch ended
@@ -291,16 +355,20 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     if (new_count != 0)
         b->carry_cur ^= 1;
     if (b->find_peaks && n_chunks > 0) {
-        ProfScope ps(b, sdr::K_FIND_PEAKS);
+        HIP_TRY(hipStreamWaitEvent(s_peaks, S.done[S_NOISE], 0));  // needs the completing frame's peak threshold
+        ProfScope ps(b, sdr::K_FIND_PEAKS, s_peaks);
         sdr::PeakGeom pg{N, stride, count0, b->max_chunks, c.max_peaks};
-        HIP_TRY(sdr::launch_find_peaks(b->cum_out.p, b->recs.p, b->dev_peaks.p, b->peak_counts.p, pg, n_chunks, B,
-                                       b->stream));
+        HIP_TRY(sdr::launch_find_peaks(S.cum_out.p, S.recs.p, S.dev_peaks.p, S.peak_counts.p, pg, n_chunks, B, s_peaks));
     }
+    HIP_TRY(hipEventRecord(S.done[S_PEAKS], s_peaks));
+
     b->cum_count = new_count;
+    b->last_set = si;
     b->last_frames = n_frames;
     b->last_chunks = n_chunks;
     b->last_count0 = count0;
     b->total_frames += n_frames;
+    b->batch_index++;
     return SDR_OK;
 }
 
@@ -353,6 +421,14 @@ int sdr_create(const sdr_config *cfg, sdr_bank **out)
         }                                                                                              \
     } while (0)
 
+    for (int s = 1; s < N_STAGES; s++) {
+        hipError_t e = hipStreamCreateWithFlags(&b->stream[s], hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            sdr_destroy(b);
+            return fail(SDR_ERR_HIP, "hipStreamCreate failed");
+        }
+        b->own_stream[s] = true;
+    }
     // twiddles: go-dsp's table, re-laid-out per register pass
     {
         std::vector<double> wre, wim;
@@ -366,32 +442,43 @@ int sdr_create(const sdr_config *cfg, sdr_bank **out)
             return fail(SDR_ERR_HIP, "twiddle upload failed");
         }
     }
-    ALLOC(b->spectrum, B * F * N);
-    ALLOC(b->psd, B * F * N);
-    ALLOC(b->win_mean, B * F * 10);
-    ALLOC(b->recs, B * F);
+    for (int r = 0; r < RING; r++) {
+        BatchSet &S = b->set[r];
+        ALLOC(S.spectrum, B * F * N);
+        ALLOC(S.psd, B * F * N);
+        ALLOC(S.win_mean, B * F * 10);
+        ALLOC(S.recs, B * F);
+        ALLOC(S.raw_bits, B * L * (size_t)b->bit_words);
+        ALLOC(S.bits, B * L * (size_t)b->bit_words);
+        ALLOC(S.edges, B * L * (size_t)b->edge_cap);
+        ALLOC(S.edge_counts, B * L);
+        if (cfg->trace) {
+            ALLOC(S.tr_values, B * F * L);
+            ALLOC(S.tr_raw, B * F * L);
+            ALLOC(S.tr_deb, B * F * L);
+        }
+        ALLOC(S.cum_out, B * (size_t)b->max_chunks * N);
+        ALLOC(S.dev_peaks, B * (size_t)b->max_chunks * (size_t)cfg->max_peaks);
+        ALLOC(S.peak_counts, B * (size_t)b->max_chunks);
+        for (auto &e : S.done) {
+            hipError_t he = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            if (he != hipSuccess) {
+                sdr_destroy(b);
+                return fail(SDR_ERR_HIP, "hipEventCreate failed");
+            }
+        }
+    }
     ALLOC(b->band_state, B);
     ALLOC(b->slots, B * L);
     ALLOC(b->morse, cw::kMorseTableSize);
     ALLOC(b->text, B * L * (size_t)b->text_cap);
-    ALLOC(b->edges, B * L * (size_t)b->edge_cap);
-    ALLOC(b->bits, B * L * (size_t)b->bit_words);
-    ALLOC(b->raw_bits, B * L * (size_t)b->bit_words);
-    if (cfg->trace) {
-        ALLOC(b->tr_values, B * F * L);
-        ALLOC(b->tr_raw, B * F * L);
-        ALLOC(b->tr_deb, B * F * L);
-    }
     ALLOC(b->carry[0], B * N);
     ALLOC(b->carry[1], B * N);
-    ALLOC(b->cum_out, B * (size_t)b->max_chunks * N);
-    ALLOC(b->dev_peaks, B * (size_t)b->max_chunks * (size_t)cfg->max_peaks);
-    ALLOC(b->peak_counts, B * (size_t)b->max_chunks);
 #undef ALLOC
 
-    b->h_morse.resize(cw::kMorseTableSize);
-    cw::build_morse_table(b->h_morse.data());
-    hipError_t e = hipMemcpy(b->morse.p, b->h_morse.data(), sizeof(uint16_t) * cw::kMorseTableSize, hipMemcpyHostToDevice);
+    std::vector<uint16_t> h_morse(cw::kMorseTableSize);
+    cw::build_morse_table(h_morse.data());
+    hipError_t e = hipMemcpy(b->morse.p, h_morse.data(), sizeof(uint16_t) * cw::kMorseTableSize, hipMemcpyHostToDevice);
     b->h_band_state.assign(B, sdr::BandState{});
     for (auto &s : b->h_band_state)
         s.peak_threshold = cfg->peak_threshold;
@@ -414,29 +501,22 @@ int sdr_destroy(sdr_bank *b)
     if (!b)
         return SDR_OK;
     (void)hipSetDevice(b->device);
-    (void)hipStreamSynchronize(b->stream);
+    for (int s = 0; s < N_STAGES; s++)
+        (void)hipStreamSynchronize(b->stream[s]);
     resolve_profile(b);
     b->tw.release();
     b->iq_stage_dev.release();
-    b->spectrum.release();
-    b->psd.release();
-    b->win_mean.release();
-    b->recs.release();
+    for (auto &S : b->set)
+        S.release();
     b->band_state.release();
     b->slots.release();
     b->morse.release();
     b->text.release();
-    b->edges.release();
-    b->bits.release();
-    b->raw_bits.release();
-    b->tr_values.release();
-    b->tr_raw.release();
-    b->tr_deb.release();
     b->carry[0].release();
     b->carry[1].release();
-    b->cum_out.release();
-    b->dev_peaks.release();
-    b->peak_counts.release();
+    for (int s = 0; s < N_STAGES; s++)
+        if (b->own_stream[s] && b->stream[s])
+            (void)hipStreamDestroy(b->stream[s]);
     if (b->h_stage)
         (void)hipHostFree(b->h_stage);
     delete b;
@@ -450,7 +530,7 @@ int sdr_set_stream(sdr_bank *b, void *hip_stream)
     int rc = sync_bank(b);
     if (rc)
         return rc;
-    b->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    b->stream[S_FFT] = reinterpret_cast<hipStream_t>(hip_stream);
     return SDR_OK;
 }
 
@@ -510,13 +590,12 @@ int sdr_process_staged(sdr_bank *b, int *n_frames_out)
     for (int band = 0; band < c.n_bands; band++)
         HIP_TRY(hipMemcpyAsync(b->iq_stage_dev.p + (size_t)band * n * per,
                                b->h_stage + (size_t)band * c.max_batch_frames * per, sizeof(float) * per * (size_t)n,
-                               hipMemcpyHostToDevice, b->stream));
+                               hipMemcpyHostToDevice, b->stream[S_FFT]));
     int rc = process_device_impl(b, b->iq_stage_dev.p, n, n);
     if (rc)
         return rc;
-    // the pinned queue is reused: wait for the upload, then keep what was not consumed
-    HIP_TRY(hipStreamSynchronize(b->stream));
-    resolve_profile(b);
+    // the staging buffers are reused: wait for the upload and the FFT, then keep what was not consumed
+    HIP_TRY(hipStreamSynchronize(b->stream[S_FFT]));
     for (int band = 0; band < c.n_bands; band++) {
         const int left = b->staged[band] - n;
         if (left > 0) {
@@ -542,6 +621,8 @@ int sdr_sync(sdr_bank *b)
     return sync_bank(b);
 }
 
+// Control calls touch state owned by a pipeline stage: drain the pipeline first (they are rare, and
+// the reference also applies them between frames only, rx/receiver.go:166-172).
 int sdr_attach(sdr_bank *b, int band, int bin, int *listener_id)
 {
     int rc = check_band(b, band);
@@ -566,13 +647,13 @@ int sdr_attach(sdr_bank *b, int band, int bin, int *listener_id)
     memset(&s, 0, sizeof s);
     s.active = 1;
     s.bin = bin;
-    cw::debouncer_init(s.deb, c.signal_debounce);              // NewSpectralDemodulator, cw/spectral.go:25-33
-    cw::decoder_init(s.dec, c.sample_rate, c.block_size);      // NewDecoder, cw/decode.go:131-147
-    cw::decoder_reset(s.dec);                                  // Listener.Attach -> demodulator.Reset, listener.go:88
-    HIP_TRY(hipSetDevice(b->device));
-    // a reused slot may still hold unread text of its previous owner: wait and drop it
-    HIP_TRY(hipMemcpyAsync(b->slots.p + (size_t)band * c.max_listeners + lid, &s, sizeof s, hipMemcpyHostToDevice,
-                           b->stream));
+    cw::debouncer_init(s.deb, c.signal_debounce);          // NewSpectralDemodulator, cw/spectral.go:25-33
+    cw::decoder_init(s.dec, c.sample_rate, c.block_size);  // NewDecoder, cw/decode.go:131-147
+    cw::decoder_reset(s.dec);                              // Listener.Attach -> demodulator.Reset, listener.go:88
+    rc = sync_bank(b);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpy(b->slots.p + (size_t)band * c.max_listeners + lid, &s, sizeof s, hipMemcpyHostToDevice));
     if (listener_id)
         *listener_id = lid;
     return SDR_OK;
@@ -587,9 +668,11 @@ int sdr_detach(sdr_bank *b, int band, int lid)
     if (!s.active)
         return fail(SDR_ERR_STATE, "listener not attached");
     s.active = 0;
-    HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(hipMemcpyAsync(&b->slots.p[(size_t)band * b->cfg.max_listeners + lid].active, &s.active, sizeof(int32_t),
-                           hipMemcpyHostToDevice, b->stream));
+    rc = sync_bank(b);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpy(&b->slots.p[(size_t)band * b->cfg.max_listeners + lid].active, &s.active, sizeof(int32_t),
+                      hipMemcpyHostToDevice));
     return SDR_OK;
 }
 
@@ -610,7 +693,8 @@ int sdr_listener_stop(sdr_bank *b, int band, int lid)
         return rc;
     const size_t idx = (size_t)band * b->cfg.max_listeners + lid;
     HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(sdr::launch_listener_stop(b->slots.p + idx, b->morse.p, b->text.p + idx * b->text_cap, b->text_cap, b->stream));
+    HIP_TRY(sdr::launch_listener_stop(b->slots.p + idx, b->morse.p, b->text.p + idx * b->text_cap, b->text_cap,
+                                      b->stream[S_LISTEN]));
     return SDR_OK;
 }
 
@@ -620,9 +704,11 @@ int sdr_set_peak_threshold(sdr_bank *b, int band, float threshold)
     if (rc)
         return rc;
     b->h_band_state[band].peak_threshold = threshold;
-    HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(hipMemcpyAsync(&b->band_state.p[band].peak_threshold, &b->h_band_state[band].peak_threshold, sizeof(float),
-                           hipMemcpyHostToDevice, b->stream));
+    rc = sync_bank(b);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpy(&b->band_state.p[band].peak_threshold, &b->h_band_state[band].peak_threshold, sizeof(float),
+                      hipMemcpyHostToDevice));
     return SDR_OK;
 }
 
@@ -632,7 +718,7 @@ int sdr_set_edge_width(sdr_bank *b, int edge_width)
         return fail(SDR_ERR_BAD_ARG, "null bank");
     if (edge_width < 0 || b->cfg.block_size - 2 * edge_width < 10)
         return fail(SDR_ERR_BAD_ARG, "edge_width leaves fewer than 10 bins");
-    b->edge_width = edge_width;
+    b->edge_width = edge_width;  // a launch parameter: picked up by the next batch
     return SDR_OK;
 }
 
@@ -645,7 +731,7 @@ int sdr_set_signal_debounce(sdr_bank *b, int band, int debounce)
         return SDR_OK;
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(sdr::launch_set_debounce(b->slots.p + (size_t)band * b->cfg.max_listeners, b->n_slots[band], debounce,
-                                     b->stream));
+                                     b->stream[S_LISTEN]));
     return SDR_OK;
 }
 
@@ -681,6 +767,7 @@ int sdr_read_peaks(sdr_bank *b, int band, int chunk, sdr_peak *out, int max, int
     if (rc)
         return rc;
     const sdr_config &c = b->cfg;
+    const BatchSet &S = b->set[b->last_set];
     if (frame_in_batch)
         *frame_in_batch = (SDR_CUMULATION_SIZE - b->last_count0) + chunk * SDR_CUMULATION_SIZE - 1;
     if (!b->find_peaks) {
@@ -689,14 +776,14 @@ int sdr_read_peaks(sdr_bank *b, int band, int chunk, sdr_peak *out, int max, int
         return SDR_OK;
     }
     int count = 0;
-    HIP_TRY(hipMemcpy(&count, b->peak_counts.p + (size_t)band * b->max_chunks + chunk, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&count, S.peak_counts.p + (size_t)band * b->max_chunks + chunk, sizeof(int), hipMemcpyDeviceToHost));
     if (n_out)
         *n_out = count;
     const int n = std::min(std::min(count, c.max_peaks), max);
     if (n <= 0 || !out)
         return SDR_OK;
     std::vector<sdr::DevPeak> dp((size_t)n);
-    HIP_TRY(hipMemcpy(dp.data(), b->dev_peaks.p + ((size_t)band * b->max_chunks + chunk) * c.max_peaks,
+    HIP_TRY(hipMemcpy(dp.data(), S.dev_peaks.p + ((size_t)band * b->max_chunks + chunk) * c.max_peaks,
                       sizeof(sdr::DevPeak) * (size_t)n, hipMemcpyDeviceToHost));
     host::FrequencyMapping fm(c.sample_rate, c.block_size, b->center_frequency[band]);
     for (int i = 0; i < n; i++) {
@@ -724,7 +811,7 @@ int sdr_read_cumulation(sdr_bank *b, int band, int chunk, float *out)
     rc = sync_bank(b);
     if (rc)
         return rc;
-    HIP_TRY(hipMemcpy(out, b->cum_out.p + ((size_t)band * b->max_chunks + chunk) * b->cfg.block_size,
+    HIP_TRY(hipMemcpy(out, b->set[b->last_set].cum_out.p + ((size_t)band * b->max_chunks + chunk) * b->cfg.block_size,
                       sizeof(float) * (size_t)b->cfg.block_size, hipMemcpyDeviceToHost));
     return SDR_OK;
 }
@@ -775,13 +862,14 @@ int sdr_read_edges(sdr_bank *b, int band, int lid, sdr_edge *out, int max, int *
     if (rc)
         return rc;
     const size_t idx = (size_t)band * b->cfg.max_listeners + lid;
+    const BatchSet &S = b->set[b->last_set];
     uint32_t count = 0;
-    HIP_TRY(hipMemcpy(&count, &b->slots.p[idx].edge_count, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&count, S.edge_counts.p + idx, sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (n_out)
         *n_out = (int)count;
     const int n = std::min(std::min((int)count, b->edge_cap), max);
     if (n > 0 && out)
-        HIP_TRY(hipMemcpy(out, b->edges.p + idx * b->edge_cap, sizeof(sdr_edge) * (size_t)n, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out, S.edges.p + idx * b->edge_cap, sizeof(sdr_edge) * (size_t)n, hipMemcpyDeviceToHost));
     return SDR_OK;
 }
 
@@ -796,7 +884,8 @@ int sdr_read_keying_bits(sdr_bank *b, int band, int lid, uint64_t *out, int max_
     const size_t idx = (size_t)band * b->cfg.max_listeners + lid;
     const int words = std::min((b->last_frames + 63) / 64, max_words);
     if (words > 0 && out)
-        HIP_TRY(hipMemcpy(out, b->bits.p + idx * b->bit_words, sizeof(uint64_t) * (size_t)words, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out, b->set[b->last_set].bits.p + idx * b->bit_words, sizeof(uint64_t) * (size_t)words,
+                          hipMemcpyDeviceToHost));
     return SDR_OK;
 }
 
@@ -810,8 +899,8 @@ int sdr_read_frame_records(sdr_bank *b, int band, sdr_frame_rec *out, int max)
         return rc;
     const int n = std::min(b->last_frames, max);
     if (n > 0 && out)
-        HIP_TRY(hipMemcpy(out, b->recs.p + (size_t)band * b->cfg.max_batch_frames, sizeof(sdr_frame_rec) * (size_t)n,
-                          hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out, b->set[b->last_set].recs.p + (size_t)band * b->cfg.max_batch_frames,
+                          sizeof(sdr_frame_rec) * (size_t)n, hipMemcpyDeviceToHost));
     return SDR_OK;
 }
 
@@ -826,6 +915,7 @@ int sdr_read_trace(sdr_bank *b, int band, int lid, float *values, uint8_t *raw, 
     if (rc)
         return rc;
     const sdr_config &c = b->cfg;
+    const BatchSet &S = b->set[b->last_set];
     const int n = std::min(b->last_frames, max);
     if (n <= 0)
         return SDR_OK;
@@ -833,12 +923,12 @@ int sdr_read_trace(sdr_bank *b, int band, int lid, float *values, uint8_t *raw, 
     const size_t base = (size_t)band * c.max_batch_frames * L + lid;
     // strided gather: [frame][listener] -> per-listener row
     if (values)
-        HIP_TRY(hipMemcpy2D(values, sizeof(float), b->tr_values.p + base, sizeof(float) * L, sizeof(float), (size_t)n,
+        HIP_TRY(hipMemcpy2D(values, sizeof(float), S.tr_values.p + base, sizeof(float) * L, sizeof(float), (size_t)n,
                             hipMemcpyDeviceToHost));
     if (raw)
-        HIP_TRY(hipMemcpy2D(raw, 1, b->tr_raw.p + base, L, 1, (size_t)n, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy2D(raw, 1, S.tr_raw.p + base, L, 1, (size_t)n, hipMemcpyDeviceToHost));
     if (debounced)
-        HIP_TRY(hipMemcpy2D(debounced, 1, b->tr_deb.p + base, L, 1, (size_t)n, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy2D(debounced, 1, S.tr_deb.p + base, L, 1, (size_t)n, hipMemcpyDeviceToHost));
     return SDR_OK;
 }
 
@@ -854,10 +944,11 @@ int sdr_read_spectrum(sdr_bank *b, int band, int frame, float *spectrum, float *
         return rc;
     const size_t N = (size_t)b->cfg.block_size;
     const size_t off = ((size_t)band * b->cfg.max_batch_frames + frame) * N;
+    const BatchSet &S = b->set[b->last_set];
     if (spectrum)
-        HIP_TRY(hipMemcpy(spectrum, b->spectrum.p + off, sizeof(float) * N, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(spectrum, S.spectrum.p + off, sizeof(float) * N, hipMemcpyDeviceToHost));
     if (psd)
-        HIP_TRY(hipMemcpy(psd, b->psd.p + off, sizeof(float) * N, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(psd, S.psd.p + off, sizeof(float) * N, hipMemcpyDeviceToHost));
     return SDR_OK;
 }
 

@@ -78,8 +78,8 @@ hipError_t launch_listen_gather(const float *spectrum, const sdr_frame_rec *recs
                                 uint64_t *raw_bits, float *tr_values, uint8_t *tr_raw, ListenGeom g, int n_frames,
                                 int n_slots, int n_bands, hipStream_t stream);
 hipError_t launch_listen_decode(ListenerSlot *slots, const uint16_t *morse, const uint64_t *raw_bits,
-                                uint64_t *deb_bits, uint32_t *text, sdr_edge *edges, uint8_t *tr_deb, ListenGeom g,
-                                int n_frames, int n_bands, hipStream_t stream);
+                                uint64_t *deb_bits, uint32_t *text, sdr_edge *edges, uint32_t *edge_counts,
+                                uint8_t *tr_deb, ListenGeom g, int n_frames, int n_bands, hipStream_t stream);
 hipError_t launch_listener_stop(ListenerSlot *slot, const uint16_t *morse, uint32_t *text, int text_cap,
                                 hipStream_t stream);
 hipError_t launch_set_debounce(ListenerSlot *slots, int n, int threshold, hipStream_t stream);
