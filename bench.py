@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU work per core for the baseline")
     ap.add_argument("--kernel-breakdown", action="store_true", help="print per-kernel HIP-event times to stderr")
+    ap.add_argument("--serial", action="store_true",
+                    help="diagnostic: run all stages on one stream (no overlap) so per-kernel times are standalone")
     return ap.parse_args()
 
 
@@ -131,6 +133,8 @@ def cpu_baseline(rate, n, tones, free_last, seconds):
 
 def main():
     args = parse()
+    if args.serial:
+        os.environ["SDR_NO_OVERLAP"] = "1"
     import torch
 
     rank = int(os.environ.get("RANK", "0"))

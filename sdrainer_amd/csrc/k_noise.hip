@@ -4,11 +4,11 @@
 // FindNoiseFloor is two SEQUENTIAL float64 accumulations per frame (window sums, then the variance
 // about the winning window's mean): float64 addition is not associative, so to reproduce the
 // reference's bits each chain keeps its order — one lane per chain.  What is parallel is everything
-// around the chain: a workgroup owns 64 chains (64 consecutive frames); seven producer waves take turns
-// fetching each chain's next 64 values (one fully coalesced 256-byte load per chain, kept in flight
-// across six barrier steps), widen / subtract / square them in float64 and lay them down in LDS
-// transposed, double-buffered; the consumer wave's lane i then only reads row i and adds — the strictly
-// serial part is one ds_read_b64 + one v_add_f64 per term.
+// around the chain: a workgroup owns 64 chains (64 consecutive frames); seven producer waves take
+// turns fetching each chain's next 64 values (one fully coalesced 256-byte load per chain), widen /
+// subtract / square them in float64 and lay them down transposed in a four-slot LDS ring guarded by
+// flags; the consumer wave's lane i then only reads row i and adds — the strictly serial part is one
+// ds_read_b64 + one v_add_f64 per term.
 #include <hip/hip_runtime.h>
 
 #include "../../include/sdrainer_hip.h"
@@ -18,77 +18,91 @@
 namespace sdr {
 
 constexpr int TILE = 64;
-constexpr int N_PRODUCERS = 7;  // wave 0 = consumer (the chains), waves 1..7 = producers
-constexpr int CHAIN_THREADS = 64 * (1 + N_PRODUCERS);
+constexpr int N_PRODUCERS = 7;                         // wave 0 = consumer (the chains), waves 1..7 = producers
+constexpr int CHAIN_THREADS = 64 * (1 + N_PRODUCERS);  // 512 threads: 256 VGPRs per lane, nothing spills
+constexpr int RING_SLOTS = 4;                          // LDS tiles between producers and consumer
 
 struct ChainShared {
-    double term[2][TILE][TILE + 1];  // [buffer][chain][column], row stride 65 doubles: conflict-free both ways
-    double mean[TILE];               // per chain: value subtracted before squaring (variance pass)
-    int n_terms[TILE];               // per chain: number of leading terms that count
+    double term[RING_SLOTS][TILE][TILE + 1];  // [slot][chain][column]; row stride 65 doubles: conflict-free both ways
+    double mean[TILE];                        // per chain: value subtracted before squaring (variance pass)
+    int n_terms[TILE];                        // per chain: number of leading terms that count
+    int ready[RING_SLOTS];                    // ready[t % RING_SLOTS] == t + 1  <=>  tile t is published
+    int consumed;                             // tiles the consumer has finished with
 };
 
-constexpr int ROWS_PER = (TILE + N_PRODUCERS - 1) / N_PRODUCERS;  // rows p, p+7, ... of every tile: <= 10
-constexpr int DEPTH = 6;                                           // tiles a producer keeps in flight
+__device__ __forceinline__ int lds_flag_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_flag_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-// What a producer wave keeps about its own rows (p, p+7, ...) for the whole chain.
-struct ProducerRows {
-    int n_terms[ROWS_PER];
-    double mean[ROWS_PER];
-    unsigned row_off[ROWS_PER];  // r * row_stride: 32-bit offsets keep the address math on one VALU add
-};
-
-// Producer, step 1: issue this wave's coalesced row loads of tile `t` (row r = chain r's next 64 floats,
-// one 256-byte read) and keep them in flight in VGPRs.
-__device__ __forceinline__ void tile_issue(const float *__restrict__ base, const ProducerRows &pr, int rows, int n_cols,
-                                           int t, int p, int lane, float (&regs)[ROWS_PER])
-{
-    const unsigned col = (unsigned)(t * TILE + lane);
-    const bool in = (int)col < n_cols;
-#pragma unroll
-    for (int i = 0; i < ROWS_PER; i++) {
-        const int r = p + i * N_PRODUCERS;
-        regs[i] = (in && r < rows) ? base[pr.row_off[i] + col] : 0.f;
-    }
-}
-
-// Producer, step 2 (DEPTH barrier steps later): widen / subtract / square in float64 and lay the rows
-// down transposed.  Terms past a chain's own end are stored as +0.0: adding +0.0 to a non-negative
-// float64 sum leaves it bit-identical, so the consumer needs no per-lane predicate.  `full` (wave
-// uniform) says every chain still covers the whole tile, so the end test is skipped.
+// Producer wave p owns tiles t = p, p + 7, ...: it fetches all 64 chains' next 64 values (row r = chain
+// r, one coalesced 256-byte read per row, 64 loads in flight), widens / subtracts / squares them in
+// float64 and lays them down transposed in ring slot t % 4, then raises the slot's flag.  Memory latency
+// is hidden by the other six producers, not by software pipelining inside one wave.
+// Terms past a chain's own end are stored as +0.0: adding +0.0 to a non-negative float64 sum leaves it
+// bit-identical, so the consumer needs no per-lane predicate.
 template <bool VARIANCE>
-__device__ __forceinline__ void tile_publish(ChainShared &sh, const ProducerRows &pr, int buf, int t, int p, int lane,
-                                             bool full, const float (&regs)[ROWS_PER])
+__device__ __forceinline__ void chain_producer(ChainShared &sh, const float *__restrict__ base, unsigned row_stride,
+                                               int rows, int n_cols, int n_tiles, int min_terms, int p, int lane)
 {
-    const int col = t * TILE + lane;
+    // lane r keeps chain r's mean / length; rows read them with v_readlane (wave-uniform, no LDS traffic)
+    const double mean_of_lane = sh.mean[lane];
+    const int terms_of_lane = sh.n_terms[lane];
+    for (int t = p; t < n_tiles; t += N_PRODUCERS) {
+        const unsigned col = (unsigned)(t * TILE + lane);
+        // unconditional loads (a predicated load compiles to branch + load + vmcnt(0): 64 serial round
+        // trips): out-of-range rows / columns are clamped to a valid address and their values are
+        // discarded below by the chain-length test (such chains have n_terms <= col)
+        const unsigned ccol = min(col, (unsigned)(n_cols - 1));
+        float v[TILE];
 #pragma unroll
-    for (int i = 0; i < ROWS_PER; i++) {
-        const int r = p + i * N_PRODUCERS;
-        if (r >= TILE)
-            break;
-        double x = (double)regs[i];
-        if (VARIANCE) {
-            const double d = x - pr.mean[i];
-            x = d * d;  // math.Pow(d, 2)
+        for (int r = 0; r < TILE; r++)
+            v[r] = base[(unsigned)min(r, rows - 1) * row_stride + ccol];
+        const int slot = t % RING_SLOTS;
+        if (t >= RING_SLOTS)
+            while (lds_flag_load(&sh.consumed) < t - RING_SLOTS + 1)
+                __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const bool full = (t + 1) * TILE <= min_terms;  // every chain still covers the whole tile
+#pragma unroll
+        for (int r = 0; r < TILE; r++) {
+            double x = (double)v[r];
+            if (VARIANCE) {
+                const double d = x - __shfl(mean_of_lane, r);
+                x = d * d;  // math.Pow(d, 2)
+            }
+            if (!full && (int)col >= __shfl(terms_of_lane, r))
+                x = 0.0;
+            sh.term[slot][r][lane] = x;
         }
-        if (!full && col >= pr.n_terms[i])
-            x = 0.0;
-        sh.term[buf][r][lane] = x;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0)
+            lds_flag_store(&sh.ready[slot], t + 1);
     }
 }
 
-// Consumer: lane = chain; 64 strictly ordered float64 additions per tile.
-__device__ __forceinline__ double chain_consume(const ChainShared &sh, int buf, int lane, double sum)
+// Consumer: lane = chain; per tile 64 strictly ordered float64 additions (ds_read_b64 + v_add_f64 each).
+__device__ __forceinline__ double chain_consumer(ChainShared &sh, int n_tiles, int lane)
 {
+    double sum = 0;
+    __builtin_amdgcn_s_setprio(3);
+    for (int t = 0; t < n_tiles; t++) {
+        const int slot = t % RING_SLOTS;
+        while (lds_flag_load(&sh.ready[slot]) != t + 1)
+            __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
-    for (int j = 0; j < TILE; j++)
-        sum += sh.term[buf][lane][j];
+        for (int j = 0; j < TILE; j++)
+            sum += sh.term[slot][lane][j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0)
+            lds_flag_store(&sh.consumed, t + 1);
+    }
+    __builtin_amdgcn_s_setprio(0);
     return sum;
 }
 
 // Runs 64 chains (lane i of wave 0 owns chain i).  `my_terms` / `my_mean` are the consumer lane's chain
-// length and mean; returns the chain's sum in the consumer lanes.  At barrier step s the consumer adds
-// tile s while every producer publishes its rows of tile s+1 (loaded DEPTH steps earlier) and re-issues
-// the same register slot for tile s+1+DEPTH.
+// length and mean; returns the chain's sum in the consumer lanes.  All waits are on waves of the same
+// workgroup (co-resident by construction), so every spin terminates.
 template <bool VARIANCE>
 __device__ __forceinline__ double chain_run(ChainShared &sh, const float *__restrict__ base, size_t row_stride,
                                             int rows, int n_cols, int my_terms, double my_mean)
@@ -97,6 +111,10 @@ __device__ __forceinline__ double chain_run(ChainShared &sh, const float *__rest
     if (wave == 0) {
         sh.n_terms[lane] = my_terms;
         sh.mean[lane] = my_mean;
+        if (lane < RING_SLOTS)
+            sh.ready[lane] = 0;
+        if (lane == 0)
+            sh.consumed = 0;
     }
     __syncthreads();
     int max_terms = sh.n_terms[lane], min_terms = max_terms;
@@ -106,42 +124,11 @@ __device__ __forceinline__ double chain_run(ChainShared &sh, const float *__rest
         min_terms = min(min_terms, __shfl_xor(min_terms, o));
     }
     const int n_tiles = (max_terms + TILE - 1) / TILE;
-    const int p = wave - 1;
-    ProducerRows pr;
-    float ring[DEPTH][ROWS_PER];
-    if (wave > 0) {
-#pragma unroll
-        for (int i = 0; i < ROWS_PER; i++) {
-            const int r = min(p + i * N_PRODUCERS, TILE - 1);
-            pr.n_terms[i] = sh.n_terms[r];
-            pr.mean[i] = sh.mean[r];
-            pr.row_off[i] = (unsigned)r * (unsigned)row_stride;
-        }
-#pragma unroll
-        for (int d = 0; d < DEPTH; d++)
-            if (d < n_tiles)
-                tile_issue(base, pr, rows, n_cols, d, p, lane, ring[d]);
-    }
     double sum = 0;
-    for (int s0 = -1; s0 < n_tiles; s0 += DEPTH) {
-#pragma unroll
-        for (int k = 0; k < DEPTH; k++) {  // register slot k holds tile s+1 (== k mod DEPTH)
-            const int s = s0 + k;
-            if (s < n_tiles) {             // wave-uniform
-                if (wave == 0) {
-                    if (s >= 0)
-                        sum = chain_consume(sh, s & 1, lane, sum);
-                } else {
-                    const int t = s + 1;
-                    if (t < n_tiles)
-                        tile_publish<VARIANCE>(sh, pr, t & 1, t, p, lane, (t + 1) * TILE <= min_terms, ring[k]);
-                    if (t + DEPTH < n_tiles)
-                        tile_issue(base, pr, rows, n_cols, t + DEPTH, p, lane, ring[k]);
-                }
-                __syncthreads();
-            }
-        }
-    }
+    if (wave == 0)
+        sum = chain_consumer(sh, n_tiles, lane);
+    else
+        chain_producer<VARIANCE>(sh, base, (unsigned)row_stride, rows, n_cols, n_tiles, min_terms, wave - 1, lane);
     return sum;
 }
 

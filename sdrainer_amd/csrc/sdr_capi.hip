@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -421,7 +422,9 @@ int sdr_create(const sdr_config *cfg, sdr_bank **out)
         }                                                                                              \
     } while (0)
 
-    for (int s = 1; s < N_STAGES; s++) {
+    // SDR_NO_OVERLAP=1 runs every stage on the caller's stream (kernel-by-kernel profiling)
+    const char *no_overlap = getenv("SDR_NO_OVERLAP");
+    for (int s = 1; s < N_STAGES && !(no_overlap && no_overlap[0] == '1'); s++) {
         hipError_t e = hipStreamCreateWithFlags(&b->stream[s], hipStreamNonBlocking);
         if (e != hipSuccess) {
             sdr_destroy(b);
@@ -530,6 +533,9 @@ int sdr_set_stream(sdr_bank *b, void *hip_stream)
     int rc = sync_bank(b);
     if (rc)
         return rc;
+    for (int s = 1; s < N_STAGES; s++)
+        if (!b->own_stream[s])
+            b->stream[s] = reinterpret_cast<hipStream_t>(hip_stream);  // SDR_NO_OVERLAP: one stream for all
     b->stream[S_FFT] = reinterpret_cast<hipStream_t>(hip_stream);
     return SDR_OK;
 }
