@@ -130,6 +130,9 @@ int sdr_push_iq(sdr_bank *bank, int band, int sample_rate, const float *iq, size
 int sdr_staged_frames(sdr_bank *bank, int band);
 /* Uploads and processes min-over-bands staged frames; *n_frames_out = frames consumed per band. */
 int sdr_process_staged(sdr_bank *bank, int *n_frames_out);
+/* Same, but at most max_frames per band (lets a host stop at a cumulation boundary, where the
+ * reference attaches a new listener: rx/receiver.go:409-426). */
+int sdr_process_staged_limit(sdr_bank *bank, int max_frames, int *n_frames_out);
 /* Processes n_frames per band of IQ already in device memory, layout [band][frame][block_size][2]
  * float32 (band stride = n_frames*2*block_size floats).  Asynchronous on the bank's stream. */
 int sdr_process_device(sdr_bank *bank, const float *iq_dev, int n_frames);

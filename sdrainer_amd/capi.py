@@ -56,7 +56,7 @@ _lib = None
 # every symbol include/sdrainer_hip.h declares (tests/test_capi_symbols.py checks the header against this)
 SYMBOLS = (
     "sdr_last_error sdr_abi_version sdr_create sdr_destroy sdr_set_stream sdr_push_iq sdr_staged_frames "
-    "sdr_process_staged sdr_process_device sdr_sync sdr_attach sdr_detach sdr_listener_count sdr_listener_stop "
+    "sdr_process_staged sdr_process_staged_limit sdr_process_device sdr_sync sdr_attach sdr_detach sdr_listener_count sdr_listener_stop "
     "sdr_set_peak_threshold sdr_set_edge_width sdr_set_signal_debounce sdr_set_center_frequency sdr_set_find_peaks "
     "sdr_last_batch_frames sdr_total_frames sdr_last_batch_chunks sdr_read_peaks sdr_read_cumulation sdr_read_text "
     "sdr_read_edges sdr_read_keying_bits sdr_read_frame_records sdr_read_trace sdr_read_spectrum "
@@ -100,6 +100,7 @@ def load():
     sig("sdr_push_iq", C.c_int, vp, C.c_int, C.c_int, fp, C.c_size_t)
     sig("sdr_staged_frames", C.c_int, vp, C.c_int)
     sig("sdr_process_staged", C.c_int, vp, ip)
+    sig("sdr_process_staged_limit", C.c_int, vp, C.c_int, ip)
     sig("sdr_process_device", C.c_int, vp, vp, C.c_int)
     sig("sdr_sync", C.c_int, vp)
     sig("sdr_attach", C.c_int, vp, C.c_int, C.c_int, ip)
@@ -199,6 +200,11 @@ class Bank:
     def process_staged(self) -> int:
         n = C.c_int()
         _check(self._L.sdr_process_staged(self._h, C.byref(n)))
+        return n.value
+
+    def process_staged_limit(self, max_frames: int) -> int:
+        n = C.c_int()
+        _check(self._L.sdr_process_staged_limit(self._h, max_frames, C.byref(n)))
         return n.value
 
     def process_device(self, iq_dev_ptr: int, n_frames: int):

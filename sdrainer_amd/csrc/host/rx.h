@@ -1,0 +1,600 @@
+// rx.h — C++ host mirror of sdrainer's rx package for the hot path, written against the C ABI only
+// (include/sdrainer_hip.h).  Same names, argument meaning and error behaviour as the reference so the
+// tests read like rx/peaks_test.go, rx/listener_test.go:
+//
+//   rx::Clock / ManualClock      rx/receiver.go:29-55
+//   rx::Reporter                 rx/rx.go:11-17
+//   rx::PeaksTable               rx/peaks.go (whole file)
+//   rx::IDPool, ListenerPool     rx/listener.go:150-270
+//   rx::Listener                 rx/listener.go:19-148 (the demodulator lives on the GPU)
+//   rx::Receiver                 rx/receiver.go:64-500 (run loop = Process())
+//
+// Pure bookkeeping stays on the host exactly as in the reference: which peaks are known, which
+// listener is bound to which peak, time-outs.  Everything per frame is on the device.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../../include/sdrainer_hip.h"
+#include "frequency_mapping.h"
+
+namespace rx {
+
+// ---------------------------------------------------------------------------------------------
+// Clock (rx/receiver.go:29-55).  Time is in seconds.
+// ---------------------------------------------------------------------------------------------
+struct Clock {
+    virtual ~Clock() = default;
+    virtual double Now() const = 0;
+};
+struct ManualClock : Clock {  // rx/receiver.go:41-55
+    double now = 0;
+    double Now() const override { return now; }
+    void Set(double t) { now = t; }
+    void Add(double d) { now += d; }
+};
+
+// rx/receiver.go:15-27 and rx/listener.go:14-17, rx/peaks.go:10-12
+constexpr int kCumulationSize = SDR_CUMULATION_SIZE;
+constexpr int kPeakPadding = 0;
+constexpr double kDefaultPeakTimeout = 120.0;
+constexpr double kDefaultSilenceTimeout = 20.0;
+constexpr double kDefaultAttachmentTimeout = 120.0;
+
+using Peak = sdr_peak;  // dsp.Peak[float32,int] (dsp/fft.go:179-188)
+
+// rx/rx.go:11-17 (the three callsign callbacks belong to the out-of-scope TextProcessor)
+struct Reporter {
+    virtual ~Reporter() = default;
+    virtual void ListenerActivated(const std::string &listener, int64_t frequency) = 0;
+    virtual void ListenerDeactivated(const std::string &listener, int64_t frequency) = 0;
+};
+
+// ---------------------------------------------------------------------------------------------
+// PeaksTable (rx/peaks.go)
+// ---------------------------------------------------------------------------------------------
+enum PeakState { peakNone = 0, peakNew, peakActive, peakInactive };  // rx/peaks.go:23-28
+
+class PeaksTable {
+public:
+    struct Entry {  // rx/peaks.go:14-19
+        Peak peak;
+        PeakState state;
+        double since;
+    };
+    // FindNext picks a random new peak in the reference (unseeded math/rand, rx/peaks.go:185).  The
+    // probe sequence is injectable so runs are reproducible; nullptr = deterministic linear scan only.
+    using RandFn = std::function<int(int)>;
+
+    PeaksTable(int size, const Clock *clock) : bins_((size_t)size, nullptr), clock_(clock) {}
+
+    void SetRand(RandFn f) { rand_ = std::move(f); }
+    void SetPeakTimeout(double seconds) { peakTimeout_ = seconds; }
+
+    void ForcePut(const Peak &p) { put(p, true); }  // :46-71
+    void Put(const Peak &p) { put(p, false); }      // :73-103
+
+    const Peak *Get(int bin) const  // :107-117
+    {
+        if (bin < 0 || bin >= (int)bins_.size() || !bins_[bin])
+            return nullptr;
+        return &bins_[bin]->peak;
+    }
+    const Entry *GetEntry(int bin) const { return (bin < 0 || bin >= (int)bins_.size()) ? nullptr : bins_[bin].get(); }
+
+    void Cleanup()  // :127-147
+    {
+        const double now = clock_->Now();
+        int i = 0;
+        while (i < (int)bins_.size()) {
+            std::shared_ptr<Entry> p = bins_[i];
+            i++;
+            if (!p || p->state == peakActive || now - p->since < peakTimeout_)
+                continue;
+            clear(p->peak.from, p->peak.to);
+            i = p->peak.to + 1;
+        }
+    }
+    void Reset() { std::fill(bins_.begin(), bins_.end(), nullptr); }  // :149-151
+
+    void Activate(const Peak &p)  // :153-159 (the reference nil-derefs on an unknown peak, App. C4)
+    {
+        Entry *e = getInternal(p);
+        if (e && (e->state == peakNew || e->state == peakInactive))
+            e->state = peakActive;
+    }
+    void Deactivate(const Peak &p)  // :174-181
+    {
+        Entry *e = getInternal(p);
+        if (e && e->state == peakActive)
+            e->state = peakInactive;
+    }
+    const Peak *FindNext()  // :183-207
+    {
+        const int n = (int)bins_.size();
+        if (rand_)
+            for (int k = 0; k < n / 2; k++) {
+                const int i = rand_(n);
+                if (bins_[i] && bins_[i]->state == peakNew)
+                    return &bins_[i]->peak;
+            }
+        for (auto &p : bins_)
+            if (p && p->state == peakNew)
+                return &p->peak;
+        return nullptr;
+    }
+    int Size() const { return (int)bins_.size(); }
+
+private:
+    void put(const Peak &p, bool force)
+    {
+        const int n = (int)bins_.size();
+        int clearFrom = -1, clearTo = -1;
+        for (int i = std::max(0, (int)p.from); i <= std::min((int)p.to, n - 1); i++) {
+            const std::shared_ptr<Entry> &e = bins_[i];
+            if (!e)
+                continue;
+            if (!force && (e->state == peakActive || e->state == peakInactive))
+                return;
+            if (clearFrom == -1)
+                clearFrom = e->peak.from;
+            clearTo = e->peak.to;
+        }
+        if (clearFrom > -1 && clearTo > -1)
+            clear(clearFrom, clearTo);
+        auto e = std::make_shared<Entry>(Entry{p, peakNew, clock_->Now()});
+        for (int i = std::max(0, (int)p.from); i <= std::min((int)p.to, n - 1); i++)  // :105-109
+            bins_[i] = e;
+    }
+    void clear(int from, int to)  // :111-115
+    {
+        for (int i = std::max(0, from); i <= std::min(to, (int)bins_.size() - 1); i++)
+            bins_[i] = nullptr;
+    }
+    Entry *getInternal(const Peak &p)  // :161-172
+    {
+        if (p.from < 0 || p.from >= (int)bins_.size() || !bins_[p.from] || bins_[p.from]->peak.to != p.to)
+            return nullptr;
+        return bins_[p.from].get();
+    }
+
+    std::vector<std::shared_ptr<Entry>> bins_;
+    const Clock *clock_;
+    double peakTimeout_ = kDefaultPeakTimeout;
+    RandFn rand_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// IDPool / Listener / ListenerPool (rx/listener.go)
+// ---------------------------------------------------------------------------------------------
+class IDPool {  // :150-178
+public:
+    IDPool(int size, const std::string &prefix)
+    {
+        for (int i = 0; i < size; i++)
+            ids_.push_back(prefix + std::to_string(size - i));
+    }
+    void Push(const std::string &id) { ids_.push_back(id); }
+    bool Pop(std::string *out)
+    {
+        if (ids_.empty())
+            return false;
+        *out = ids_.back();
+        ids_.pop_back();
+        return true;
+    }
+    size_t Len() const { return ids_.size(); }
+
+private:
+    std::vector<std::string> ids_;
+};
+
+class Listener {  // :19-148
+public:
+    Listener(std::string id, const Clock *clock, Reporter *reporter)
+        : id_(std::move(id)), clock_(clock), reporter_(reporter), lastWrite_(clock ? clock->Now() : 0)
+    {
+    }
+    const std::string &ID() const { return id_; }
+    void SetSilenceTimeout(double s) { silenceTimeout_ = s; }
+    void SetAttachmentTimeout(double s) { attachmentTimeout_ = s; }
+
+    void Attach(const Peak &peak, int device_id)  // :84-94
+    {
+        peak_ = peak;
+        attached_ = true;
+        device_id_ = device_id;
+        lastAttach_ = clock_->Now();
+        lastWrite_ = clock_->Now();  // textProcessor.Restart(), rx/text_processor.go:175-182
+        text_.clear();
+        if (reporter_)
+            reporter_->ListenerActivated(id_, peak_.signal_frequency);
+    }
+    bool Attached() const { return attached_; }  // :96-98
+    void Detach()                                // :99-108
+    {
+        const int64_t f = peak_.signal_frequency;
+        attached_ = false;
+        if (reporter_)
+            reporter_->ListenerDeactivated(id_, f);
+    }
+    const Peak &GetPeak() const { return peak_; }
+    int SignalBin() const { return attached_ ? peak_.signal_bin : 0; }  // :119-124
+    int DeviceID() const { return device_id_; }
+    bool TimeoutExceeded() const  // :126-136
+    {
+        const double now = clock_->Now();
+        return (now - lastAttach_ > attachmentTimeout_) || (now - lastWrite_ > silenceTimeout_);
+    }
+    // The io.Writer the GPU decoder's runes arrive at (TextProcessor.Write, rx/text_processor.go:208-221)
+    void Write(const std::string &utf8)
+    {
+        if (utf8.empty())
+            return;
+        lastWrite_ = clock_->Now();
+        text_ += utf8;
+    }
+    const std::string &Text() const { return text_; }
+
+private:
+    std::string id_;
+    const Clock *clock_;
+    Reporter *reporter_;
+    Peak peak_{};
+    bool attached_ = false;
+    int device_id_ = -1;
+    double lastAttach_ = 0, lastWrite_ = 0;
+    double silenceTimeout_ = kDefaultSilenceTimeout, attachmentTimeout_ = kDefaultAttachmentTimeout;
+    std::string text_;
+};
+
+class ListenerPool {  // :180-270
+public:
+    using Factory = std::function<std::shared_ptr<Listener>(const std::string &id)>;
+    ListenerPool(int size, const std::string &prefix, Factory f) : size_(size), ids_(size, prefix), factory_(std::move(f)) {}
+    int Size() const { return size_; }
+    bool Available() const { return (int)listeners_.size() < size_; }
+    void Reset()
+    {
+        for (auto &l : listeners_) {
+            l->Detach();
+            ids_.Push(l->ID());
+        }
+        listeners_.clear();
+    }
+    std::shared_ptr<Listener> BindNext()  // :214-229
+    {
+        if ((int)listeners_.size() == size_)
+            return nullptr;
+        std::string id;
+        if (!ids_.Pop(&id))
+            return nullptr;
+        auto l = factory_(id);
+        listeners_.push_back(l);
+        return l;
+    }
+    void Release(const std::shared_ptr<Listener> &l)  // :237-248: swap-remove
+    {
+        int index = -1;
+        for (size_t i = 0; i < listeners_.size(); i++)
+            if (listeners_[i]->ID() == l->ID()) {
+                index = (int)i;
+                break;
+            }
+        if (index == -1)
+            return;
+        ids_.Push(l->ID());
+        if (listeners_.size() > 1)
+            listeners_[index] = listeners_.back();
+        listeners_.pop_back();
+    }
+    const std::vector<std::shared_ptr<Listener>> &Listeners() const { return listeners_; }
+    std::shared_ptr<Listener> First() const { return listeners_.empty() ? nullptr : listeners_[0]; }
+
+private:
+    int size_;
+    std::vector<std::shared_ptr<Listener>> listeners_;
+    IDPool ids_;
+    Factory factory_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Receiver (rx/receiver.go)
+// ---------------------------------------------------------------------------------------------
+enum ReceiverMode { DecodeMode, StrainMode };  // :57-62
+
+class Receiver {
+public:
+    // `clock` drives peak / listener time-outs.  The reference uses wall time; a stream clock (frames
+    // processed x blockSize / sampleRate) makes offline runs reproducible: pass nullptr to get one.
+    Receiver(std::string id, ReceiverMode mode, Clock *clock = nullptr, int listenerPoolSize = SDR_DEFAULT_LISTENER_POOL_SIZE)
+        : id_(std::move(id)), mode_(mode), clock_(clock ? clock : &streamClock_),
+          listeners_(mode == DecodeMode ? 1 : listenerPoolSize, id_, [this](const std::string &lid) { return newListener(lid); })
+    {
+    }
+    ~Receiver() { Stop(); }
+
+    void AddReporter(Reporter *r) { reporters_.push_back(r); }
+    // setters before Start are stored, after Start they are forwarded between batches (:166-172)
+    void SetPeakThreshold(float t)
+    {
+        peakThreshold_ = t;
+        if (bank_)
+            sdr_set_peak_threshold(bank_, 0, t);
+    }
+    void SetEdgeWidth(int e)
+    {
+        edgeWidth_ = e;
+        if (bank_)
+            sdr_set_edge_width(bank_, e);
+    }
+    void SetSilenceTimeout(double s)
+    {
+        silenceTimeout_ = s;
+        for (auto &l : listeners_.Listeners())
+            l->SetSilenceTimeout(s);
+    }
+    void SetAttachmentTimeout(double s)
+    {
+        attachmentTimeout_ = s;
+        for (auto &l : listeners_.Listeners())
+            l->SetAttachmentTimeout(s);
+    }
+    void SetSignalDebounce(int d)  // :238-244: applies to the CURRENT listeners only, as in the reference
+    {
+        if (bank_)
+            sdr_set_signal_debounce(bank_, 0, d);
+    }
+    void SetCenterFrequency(int64_t f)
+    {
+        centerFrequency_ = f;
+        if (bank_)
+            sdr_set_center_frequency(bank_, 0, f);
+    }
+    int64_t CenterFrequency() const { return centerFrequency_; }
+    void SetFindNextRand(PeaksTable::RandFn f)
+    {
+        rand_ = std::move(f);
+        if (peaks_)
+            peaks_->SetRand(rand_);
+    }
+
+    int Start(int sampleRate, int blockSize, int maxBatchFrames = 256, int deviceId = 0)  // :130-146
+    {
+        if (bank_)
+            return SDR_OK;
+        sdr_config cfg{};
+        cfg.struct_size = sizeof cfg;
+        cfg.n_bands = 1;
+        cfg.sample_rate = sampleRate;
+        cfg.block_size = blockSize;
+        cfg.edge_width = edgeWidth_;
+        cfg.peak_threshold = peakThreshold_;
+        cfg.signal_debounce = 1;  // NewSpectralDemodulator: defaultSignalDebounce (cw/spectral.go:14,27)
+        cfg.max_listeners = listeners_.Size();
+        cfg.max_batch_frames = maxBatchFrames;
+        cfg.max_peaks = blockSize / 2;
+        cfg.find_peaks = mode_ == StrainMode;
+        cfg.device_id = deviceId;
+        int rc = sdr_create(&cfg, &bank_);
+        if (rc != SDR_OK)
+            return rc;
+        sampleRate_ = sampleRate;
+        blockSize_ = blockSize;
+        sdr_set_center_frequency(bank_, 0, centerFrequency_);
+        peaks_.reset(new PeaksTable(blockSize, clock_));
+        peaks_->SetRand(rand_);
+        return SDR_OK;
+    }
+    void Stop()  // :148-164
+    {
+        if (!bank_)
+            return;
+        listeners_.Reset();
+        sdr_destroy(bank_);
+        bank_ = nullptr;
+    }
+
+    // :315-334 — never throws; wrong rate / size / full queue are logged and dropped
+    int IQData(int sampleRate, const float *data, size_t n_floats)
+    {
+        if (!bank_)
+            return SDR_OK;
+        const int rc = sdr_push_iq(bank_, 0, sampleRate, data, n_floats);
+        if (rc == SDR_ERR_BAD_RATE)
+            fprintf(stderr, "wrong incoming sample rate on receiver %s: %d instead of %d!\n", id_.c_str(), sampleRate, sampleRate_);
+        else if (rc == SDR_ERR_BAD_SIZE)
+            fprintf(stderr, "wrong incoming block size on receiver %s: %zu instead of %d\n", id_.c_str(), n_floats, blockSize_);
+        else if (rc == SDR_ERR_WOULD_DROP)
+            fprintf(stderr, "IQ data skipped on receiver %s\n", id_.c_str());
+        return rc;
+    }
+
+    // :272-313 SetVFOOffset, DecodeMode branch: force a peak at the VFO frequency and listen to it
+    int SetVFOOffset(int64_t offset)
+    {
+        vfoOffset_ = offset;
+        if (!bank_ || mode_ != DecodeMode)
+            return SDR_OK;
+        if (!listeners_.Available()) {
+            for (auto &l : listeners_.Listeners())
+                if (l->Attached())
+                    sdr_detach(bank_, 0, l->DeviceID());
+            listeners_.Reset();
+        }
+        auto listener = listeners_.BindNext();
+        if (!listener)
+            return SDR_ERR_NO_SLOT;
+        Peak peak = newPeakCenteredOnFrequency(vfoOffset_ + centerFrequency_);
+        peak.signal_value = 80;
+        peaks_->ForcePut(peak);
+        peaks_->Activate(peak);
+        return attach(listener, peak);
+    }
+
+    // The frame case of run() (:353-463) for everything staged so far.  In strain mode with a free
+    // listener the batch is cut at every cumulation boundary, because that is where the reference binds
+    // a new listener that must start listening with the very next frame (:409-426).
+    int Process()
+    {
+        if (!bank_)
+            return SDR_OK;
+        while (sdr_staged_frames(bank_, 0) > 0) {
+            const bool hunting = mode_ == StrainMode && listeners_.Available();
+            const int until_boundary = kCumulationSize - (int)(framesProcessed_ % kCumulationSize);
+            int n = 0;
+            sdr_set_find_peaks(bank_, hunting ? 1 : 0);  // :410: FindPeaks only while a listener is free
+            int rc = hunting ? sdr_process_staged_limit(bank_, until_boundary, &n) : sdr_process_staged(bank_, &n);
+            if (rc != SDR_OK)
+                return rc;
+            if (n == 0)
+                break;
+            framesProcessed_ += n;
+            streamClock_.Set((double)framesProcessed_ * (double)blockSize_ / (double)sampleRate_);
+            drainText();
+            checkTimeouts();
+            if (hunting && sdr_last_batch_chunks(bank_) > 0)
+                discover(sdr_last_batch_chunks(bank_) - 1);
+        }
+        return SDR_OK;
+    }
+
+    PeaksTable &Peaks() { return *peaks_; }
+    ListenerPool &Listeners() { return listeners_; }
+    sdr_bank *Bank() { return bank_; }
+    int64_t FramesProcessed() const { return framesProcessed_; }
+    const std::vector<Peak> &LastPeaks() const { return lastPeaks_; }
+
+    // :474-500 (peakPadding = 0: a found run is re-centred to its strongest bin)
+    Peak newPeakCenteredOnBin(int centerBin) const
+    {
+        host::FrequencyMapping fm(sampleRate_, blockSize_, centerFrequency_);
+        Peak p{};
+        p.from = std::max(0, centerBin - kPeakPadding);
+        p.to = std::min(centerBin + kPeakPadding, blockSize_ - 1);
+        p.from_frequency = fm.BinToFrequency(p.from, host::BinFrom);
+        p.to_frequency = fm.BinToFrequency(p.to, host::BinTo);
+        p.signal_frequency = p.from_frequency + (p.to_frequency - p.from_frequency) / 2;  // Peak.CenterFrequency
+        return p;
+    }
+    Peak newPeakCenteredOnSignal(const Peak &peak) const
+    {
+        Peak r = newPeakCenteredOnBin(peak.signal_bin);
+        r.signal_frequency = peak.signal_frequency;
+        r.signal_value = peak.signal_value;
+        r.signal_bin = peak.signal_bin;
+        return r;
+    }
+    Peak newPeakCenteredOnFrequency(int64_t frequency) const
+    {
+        host::FrequencyMapping fm(sampleRate_, blockSize_, centerFrequency_);
+        const int bin = fm.FrequencyToBin(frequency);
+        Peak r = newPeakCenteredOnBin(bin);
+        r.signal_bin = bin;
+        r.signal_frequency = frequency;
+        return r;
+    }
+
+private:
+    struct Fanout : Reporter {
+        Receiver *r;
+        void ListenerActivated(const std::string &l, int64_t f) override
+        {
+            for (auto *rep : r->reporters_)
+                rep->ListenerActivated(l, f);
+        }
+        void ListenerDeactivated(const std::string &l, int64_t f) override
+        {
+            for (auto *rep : r->reporters_)
+                rep->ListenerDeactivated(l, f);
+        }
+    };
+    std::shared_ptr<Listener> newListener(const std::string &lid)  // :120-126
+    {
+        fanout_.r = this;
+        auto l = std::make_shared<Listener>(lid, clock_, &fanout_);
+        l->SetAttachmentTimeout(attachmentTimeout_);
+        l->SetSilenceTimeout(silenceTimeout_);
+        return l;
+    }
+    int attach(const std::shared_ptr<Listener> &listener, const Peak &peak)
+    {
+        int dev = -1;
+        const int rc = sdr_attach(bank_, 0, peak.signal_bin, &dev);
+        if (rc != SDR_OK)
+            return rc;
+        listener->Attach(peak, dev);
+        return SDR_OK;
+    }
+    void drainText()
+    {
+        char buf[8192];
+        for (auto &l : listeners_.Listeners()) {
+            if (!l->Attached())
+                continue;
+            int nb = 0;
+            if (sdr_read_text(bank_, 0, l->DeviceID(), buf, (int)sizeof buf, &nb) == SDR_OK && nb > 0)
+                l->Write(std::string(buf, (size_t)nb));
+        }
+    }
+    void checkTimeouts()  // :396-402 (evaluated per processed segment instead of per frame)
+    {
+        if (mode_ != StrainMode)
+            return;
+        std::vector<std::shared_ptr<Listener>> detached;
+        for (auto &l : listeners_.Listeners())
+            if (l->Attached() && l->TimeoutExceeded()) {
+                peaks_->Deactivate(l->GetPeak());
+                sdr_detach(bank_, 0, l->DeviceID());
+                l->Detach();
+                detached.push_back(l);
+            }
+        for (auto &l : detached)
+            listeners_.Release(l);
+    }
+    void discover(int chunk)  // :409-426
+    {
+        std::vector<Peak> found((size_t)blockSize_ / 2);
+        int n = 0, frame = 0;
+        if (sdr_read_peaks(bank_, 0, chunk, found.data(), (int)found.size(), &n, &frame) != SDR_OK)
+            return;
+        found.resize((size_t)std::min(n, (int)found.size()));
+        lastPeaks_ = found;
+        for (const Peak &p : found)
+            peaks_->Put(newPeakCenteredOnSignal(p));
+        const Peak *selected = peaks_->FindNext();
+        if (!selected)
+            return;
+        auto listener = listeners_.BindNext();
+        if (!listener)
+            return;
+        const Peak chosen = *selected;
+        peaks_->Activate(chosen);
+        attach(listener, chosen);
+    }
+
+    std::string id_;
+    ReceiverMode mode_;
+    ManualClock streamClock_;
+    Clock *clock_;
+    std::vector<Reporter *> reporters_;
+    Fanout fanout_;
+    float peakThreshold_ = SDR_DEFAULT_PEAK_THRESHOLD;
+    int edgeWidth_ = SDR_DEFAULT_EDGE_WIDTH;
+    int sampleRate_ = 0, blockSize_ = 0;
+    int64_t centerFrequency_ = 0, vfoOffset_ = 0;
+    double silenceTimeout_ = kDefaultSilenceTimeout, attachmentTimeout_ = kDefaultAttachmentTimeout;
+    sdr_bank *bank_ = nullptr;
+    std::unique_ptr<PeaksTable> peaks_;
+    PeaksTable::RandFn rand_;
+    ListenerPool listeners_;
+    int64_t framesProcessed_ = 0;
+    std::vector<Peak> lastPeaks_;
+};
+
+}  // namespace rx

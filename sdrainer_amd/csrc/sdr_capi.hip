@@ -576,10 +576,15 @@ int sdr_staged_frames(sdr_bank *b, int band)
 
 int sdr_process_staged(sdr_bank *b, int *n_frames_out)
 {
+    return sdr_process_staged_limit(b, b ? b->cfg.max_batch_frames : 0, n_frames_out);
+}
+
+int sdr_process_staged_limit(sdr_bank *b, int max_frames, int *n_frames_out)
+{
     if (!b)
         return fail(SDR_ERR_BAD_ARG, "null bank");
     const sdr_config &c = b->cfg;
-    int n = c.max_batch_frames;
+    int n = std::min(c.max_batch_frames, std::max(max_frames, 0));
     for (int v : b->staged)
         n = std::min(n, v);
     if (n_frames_out)
