@@ -198,8 +198,8 @@ static int run_strain(const char *path, int rate, int n, int frames, int pool)
     if (fread(iq.data(), sizeof(float), iq.size(), f) != iq.size())
         return 2;
     fclose(f);
+    PrintReporter rep;  // must outlive the receiver: Stop() reports the final deactivations
     rx::Receiver r("rx", rx::StrainMode, nullptr, pool);
-    PrintReporter rep;
     r.AddReporter(&rep);
     r.SetCenterFrequency(7020000);
     r.SetSilenceTimeout(1e9);
