@@ -82,6 +82,81 @@ SDR_HD inline float psd_value_in_db(float psd, double inv_n2)
     return (float)(10.0 * gomath::log10(20.0 * (double)psd * inv_n2));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Certified fast path for psd_value_in_db.
+//
+// The result is a float32, but the reference computes it through a ~60-instruction float64 log.  The
+// fast path evaluates y ~= 10*log10(v) to an absolute error far below a float32 ulp (table of 64
+// mantissa intervals + degree-6 log1p polynomial, FMA allowed: only the error bound matters here),
+// rounds it to float32, and ACCEPTS the result only if y is farther than kDbGuard from the nearest
+// float32 rounding boundary.  Both y and the reference's value lie within ~2e-13 of the true
+// logarithm (tests/emu/emu_log.cpp measures it), kDbGuard is 1e-10, so an accepted result is the
+// float32 the reference would have produced; anything else (about one value in 10^5, zeros, NaNs,
+// exact powers of two) reports `false` and the caller runs the literal Go algorithm.
+// ---------------------------------------------------------------------------------------------
+struct LogTabEntry {
+    double inv_c;  // 1 / c_i,  c_i = 1 + (i + 0.5) / 64
+    double ln_c;   // ln(c_i)
+};
+constexpr int kLogTabSize = 64;
+constexpr double kDbGuard = 1e-10;
+
+// y ~= 10*log10(v) for a normal, positive, finite v
+SDR_HD inline double db_fast_y(double v, const LogTabEntry *tab)
+{
+    uint64_t bits;
+    __builtin_memcpy(&bits, &v, sizeof bits);
+    const int be = (int)((bits >> 52) & 0x7ff);
+    const int idx = (int)((bits >> 46) & 63);
+    const uint64_t mbits = (bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+    double m;
+    __builtin_memcpy(&m, &mbits, sizeof m);
+    const double r = __builtin_fma(m, tab[idx].inv_c, -1.0);  // |r| <= 1/128
+    // log1p(r) = r - r^2/2 + r^3/3 - r^4/4 + r^5/5 - r^6/6 (+ O(r^7) < 3e-16)
+    double p = -1.0 / 6.0;
+    p = __builtin_fma(p, r, 1.0 / 5.0);
+    p = __builtin_fma(p, r, -1.0 / 4.0);
+    p = __builtin_fma(p, r, 1.0 / 3.0);
+    p = __builtin_fma(p, r, -1.0 / 2.0);
+    p = __builtin_fma(p, r, 1.0);
+    const double ln_m = __builtin_fma(p, r, tab[idx].ln_c);
+    const double TenLog10Of2 = 3.01029995663981195213738894724493027;  // 10 * log10(2)
+    const double TenOverLn10 = 4.34294481903251827651128918916605082;  // 10 / ln(10)
+    return __builtin_fma((double)(be - 1023), TenLog10Of2, TenOverLn10 * ln_m);
+}
+
+SDR_HD inline bool psd_value_in_db_fast(float psd, double inv_n2, const LogTabEntry *tab, float *out)
+{
+    const double v = 20.0 * (double)psd * inv_n2;  // the same float64 the reference feeds to Log10
+    if (!(v >= 2.2250738585072014e-308) || !(v < INFINITY))
+        return false;  // zero, negative, NaN, subnormal, infinite
+    const double y = db_fast_y(v, tab);
+    const float y32 = (float)y;
+    uint32_t b32;
+    __builtin_memcpy(&b32, &y32, sizeof b32);
+    const uint32_t e32 = (b32 >> 23) & 0xff;
+    if (e32 < 64 || e32 == 0xff || (b32 & 0x007fffffu) == 0)
+        return false;  // tiny / non-finite / exact power of two (asymmetric rounding interval)
+    const uint32_t hb = (e32 - 24) << 23;  // half an ulp of y32 = 2^(e-24), as a float
+    float half_ulp;
+    __builtin_memcpy(&half_ulp, &hb, sizeof half_ulp);
+    const double d = y - (double)y32;
+    if (!((d < 0 ? -d : d) < (double)half_ulp - kDbGuard))
+        return false;
+    *out = y32;
+    return true;
+}
+
+// host: the table above
+inline void build_log_table(LogTabEntry *tab)
+{
+    for (int i = 0; i < kLogTabSize; i++) {
+        const double c = 1.0 + ((double)i + 0.5) / 64.0;
+        tab[i].inv_c = 1.0 / c;
+        tab[i].ln_c = ::log(c);
+    }
+}
+
 // (host only)
 // math.Sincos (src/math/sincos.go), |x| < 2^29 branch.  Host only: twiddle tables are built once on
 // the host and uploaded, exactly as go-dsp caches them.

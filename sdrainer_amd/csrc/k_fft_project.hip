@@ -51,7 +51,12 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T) void k_fft_project(const floa
     using PL = fft64::Plan<LOGN>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *lds = reinterpret_cast<double *>(smem);
+    // the 64-entry table of the certified fast dB path (gomath.h) follows the twiddles in HBM and sits
+    // behind the exchange area in LDS; the exchanges' barriers publish it long before the epilogue
+    gomath::LogTabEntry *ltab = reinterpret_cast<gomath::LogTabEntry *>(smem + PL::LDS_BYTES);
     const int t = threadIdx.x;
+    if (t < gomath::kLogTabSize)
+        ltab[t] = reinterpret_cast<const gomath::LogTabEntry *>(tw + PL::TW_TOTAL)[t];
     const size_t in_frame = (size_t)blockIdx.y * in_stride + blockIdx.x;
     const size_t out_frame = (size_t)blockIdx.y * out_stride + blockIdx.x;
     const float2 *x = reinterpret_cast<const float2 *>(iq) + in_frame * PL::N;
@@ -75,9 +80,14 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T) void k_fft_project(const floa
         const int k = (i + PL::N / 2) & (PL::N - 1);                  // dsp/fft.go:54-57
         const float p = (float)(xr[s] * xr[s] + xi[s] * xi[s]);       // dsp/fft.go:71-73 PSD[float32]
         pd[k] = p;
-        sp[k] = gomath::psd_value_in_db(p, inv_n2) + 120.0f;          // dsp/fft.go:79-81 + dBmShift
+        float db;                                                     // dsp/fft.go:79-81 MagnitudeIndB
+        if (!gomath::psd_value_in_db_fast(p, inv_n2, ltab, &db))      // certified shortcut, else the literal
+            db = gomath::psd_value_in_db(p, inv_n2);                  // Go algorithm (about 2 values in 10^4)
+        sp[k] = db + 120.0f;                                          // + dBmShift (rx/receiver.go:377)
     }
 }
+
+constexpr int kLogTabBytes = gomath::kLogTabSize * (int)sizeof(gomath::LogTabEntry);
 
 template <int LOGN>
 static hipError_t launch_fft_t(const float *iq, const fft64::cplx *tw, float *spectrum, float *psd, int n_frames,
@@ -87,13 +97,13 @@ static hipError_t launch_fft_t(const float *iq, const fft64::cplx *tw, float *sp
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_project<LOGN>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, PL::LDS_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, PL::LDS_BYTES + kLogTabBytes);
         if (e != hipSuccess)
             return e;
         attr_set = true;
     }
     const double inv_n2 = 1.0 / ((double)PL::N * (double)PL::N);
-    hipLaunchKernelGGL(k_fft_project<LOGN>, dim3(n_frames, n_bands), dim3(PL::T), PL::LDS_BYTES, stream, iq, tw,
+    hipLaunchKernelGGL(k_fft_project<LOGN>, dim3(n_frames, n_bands), dim3(PL::T), PL::LDS_BYTES + kLogTabBytes, stream, iq, tw,
                        spectrum, psd, inv_n2, in_stride, out_stride);
     return hipGetLastError();
 }

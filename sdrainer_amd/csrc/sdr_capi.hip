@@ -436,8 +436,12 @@ int sdr_create(const sdr_config *cfg, sdr_bank **out)
     {
         std::vector<double> wre, wim;
         fft64::radix2_factors(N, wre, wim);
-        std::vector<fft64::cplx> h((size_t)sdr::twiddle_count(b->logn));
+        // [twiddles][64-entry table of the fast dB path], both 16-byte entries
+        const size_t ntw = (size_t)sdr::twiddle_count(b->logn);
+        std::vector<fft64::cplx> h(ntw + gomath::kLogTabSize);
         sdr::build_twiddles(b->logn, wre.data(), wim.data(), h.data());
+        static_assert(sizeof(gomath::LogTabEntry) == sizeof(fft64::cplx), "table entries share the twiddle buffer");
+        gomath::build_log_table(reinterpret_cast<gomath::LogTabEntry *>(h.data() + ntw));
         ALLOC(b->tw, h.size());
         hipError_t e = hipMemcpy(b->tw.p, h.data(), h.size() * sizeof(fft64::cplx), hipMemcpyHostToDevice);
         if (e != hipSuccess) {

@@ -309,3 +309,31 @@ def test_peaks_table_find_next():
     assert t.find_next() == -1
     t.deactivate(234, 235)
     assert t.find_next() == -1
+
+
+def test_fast_db_path_is_certified(tmp_path):
+    """The FFT kernel's shortcut for the dB projection (gomath.h psd_value_in_db_fast) only ever returns
+    the float32 the literal Go algorithm returns: checked on the CPU over ~5M values."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "emu_log")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe,
+                           os.path.join(root, "tests", "emu", "emu_log.cpp")])
+    out = subprocess.run([exe, "2000000"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "mismatches 0" in out.stdout
+
+
+def test_fft_phase_functions_match_oracle_bit_for_bit(tmp_path):
+    """The register/LDS index math and per-pass twiddle layout of the FFT kernel (fft_f64.h), emulated
+    thread by thread on the CPU, against the oracle's stage-by-stage radix-2 FFT for every block size."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "emu_fft")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-o", exe,
+                           os.path.join(root, "tests", "emu", "emu_fft.cpp"), "-ldl"])
+    out = subprocess.run([exe, orc.build()], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count(": 0 mismatches") == 6
