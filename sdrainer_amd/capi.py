@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsdrainer_hip.so")
+LIB_PATH = os.environ.get("SDR_HIP_LIB") or os.path.join(_HERE, "csrc", "libsdrainer_hip.so")  # env: diagnostic builds
 
 OK, ERR_BAD_ARG, ERR_BAD_RATE, ERR_BAD_SIZE, ERR_WOULD_DROP, ERR_HIP, ERR_NO_SLOT, ERR_STATE = range(8)
 CUMULATION_SIZE = 100

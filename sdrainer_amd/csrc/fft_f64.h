@@ -31,6 +31,8 @@ struct cplx {
 template <int LOGN>
 struct Plan {
     static constexpr int N = 1 << LOGN;
+    // points per thread: 16 for N >= 1024 (radix-16 register passes), 8 at N = 512.  (32 points at
+    // N = 16384 would save an exchange, but its 31 twiddles per pass plus a prefetched frame spill.)
     static constexpr int LOGR = (LOGN >= 10) ? 4 : 3;
     static constexpr int R = 1 << LOGR;                       // points per thread
     static constexpr int T = N / R;                           // threads per frame
@@ -133,9 +135,14 @@ SDR_HD inline void butterfly_pass(double *xr, double *xi, int t, const cplx *tw)
                 const bool minus_i = (P == 0 && q >= 1 && mm == (1 << (q - 1)));
                 double wr = 1.0, wi = 0.0;
                 if (!one && !minus_i) {
+#if defined(SDR_ABLATE) && (SDR_ABLATE == 3)
+                    wr = 0.5 + 1e-9 * lo;  // timing-only build: no twiddle loads
+                    wi = 0.25;
+#else
                     const cplx w = tw[OFF + ((1 << q) - 1 + mm) * S + lo];
                     wr = w.x;
                     wi = w.y;
+#endif
                 }
 #if defined(__HIPCC__)
 #pragma unroll

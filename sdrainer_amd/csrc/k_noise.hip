@@ -4,7 +4,7 @@
 // FindNoiseFloor is two SEQUENTIAL float64 accumulations per frame (window sums, then the variance
 // about the winning window's mean): float64 addition is not associative, so to reproduce the
 // reference's bits each chain keeps its order — one lane per chain.  What is parallel is everything
-// around the chain: a workgroup owns 64 chains (64 consecutive frames); seven producer waves take
+// around the chain: a workgroup owns 64 chains (64 consecutive frames); fifteen producer waves take
 // turns fetching each chain's next 64 values (one fully coalesced 256-byte load per chain), widen /
 // subtract / square them in float64 and lay them down transposed in a four-slot LDS ring guarded by
 // flags; the consumer wave's lane i then only reads row i and adds — the strictly serial part is one
@@ -18,25 +18,27 @@
 namespace sdr {
 
 constexpr int TILE = 64;
-constexpr int N_PRODUCERS = 7;                         // wave 0 = consumer (the chains), waves 1..7 = producers
-constexpr int CHAIN_THREADS = 64 * (1 + N_PRODUCERS);  // 512 threads: 256 VGPRs per lane, nothing spills
+constexpr int HALF = TILE / 2;
+constexpr int N_PRODUCERS = 15;                        // wave 0 = consumer (the chains), waves 1..15 = producers
+constexpr int CHAIN_THREADS = 64 * (1 + N_PRODUCERS);  // 1024 threads, 128 VGPRs per lane
 constexpr int RING_SLOTS = 4;                          // LDS tiles between producers and consumer
 
 struct ChainShared {
     double term[RING_SLOTS][TILE][TILE + 1];  // [slot][chain][column]; row stride 65 doubles: conflict-free both ways
     double mean[TILE];                        // per chain: value subtracted before squaring (variance pass)
     int n_terms[TILE];                        // per chain: number of leading terms that count
-    int ready[RING_SLOTS];                    // ready[t % RING_SLOTS] == t + 1  <=>  tile t is published
+    int ready[RING_SLOTS][2];                 // ready[t % SLOTS][h] == t + 1  <=>  rows 32h..32h+31 of tile t are published
     int consumed;                             // tiles the consumer has finished with
 };
 
 __device__ __forceinline__ int lds_flag_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_flag_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-// Producer wave p owns tiles t = p, p + 7, ...: it fetches all 64 chains' next 64 values (row r = chain
-// r, one coalesced 256-byte read per row, 64 loads in flight), widens / subtracts / squares them in
-// float64 and lays them down transposed in ring slot t % 4, then raises the slot's flag.  Memory latency
-// is hidden by the other six producers, not by software pipelining inside one wave.
+// A work unit is half a tile: 32 chains x 64 columns.  Producer wave p owns units u = p, p + 15, ...
+// (unit u = rows 32*(u&1).. of tile u>>1): it fetches the 32 chains' next 64 values (row r = chain r, one
+// coalesced 256-byte read per row, 32 loads in flight), widens / subtracts / squares them in float64
+// and lays them down transposed in ring slot t % 4, then raises the half's flag.  Memory latency is
+// hidden by the other fourteen producers, not by software pipelining inside one wave.
 // Terms past a chain's own end are stored as +0.0: adding +0.0 to a non-negative float64 sum leaves it
 // bit-identical, so the consumer needs no per-lane predicate.
 template <bool VARIANCE>
@@ -46,36 +48,51 @@ __device__ __forceinline__ void chain_producer(ChainShared &sh, const float *__r
     // lane r keeps chain r's mean / length; rows read them with v_readlane (wave-uniform, no LDS traffic)
     const double mean_of_lane = sh.mean[lane];
     const int terms_of_lane = sh.n_terms[lane];
-    for (int t = p; t < n_tiles; t += N_PRODUCERS) {
+    for (int u = p; u < 2 * n_tiles; u += N_PRODUCERS) {
+        const int t = u >> 1, h = u & 1;
         const unsigned col = (unsigned)(t * TILE + lane);
-        // unconditional loads (a predicated load compiles to branch + load + vmcnt(0): 64 serial round
+        // unconditional loads (a predicated load compiles to branch + load + vmcnt(0): serial round
         // trips): out-of-range rows / columns are clamped to a valid address and their values are
         // discarded below by the chain-length test (such chains have n_terms <= col)
         const unsigned ccol = min(col, (unsigned)(n_cols - 1));
-        float v[TILE];
+        float v[HALF];
 #pragma unroll
-        for (int r = 0; r < TILE; r++)
-            v[r] = base[(unsigned)min(r, rows - 1) * row_stride + ccol];
+        for (int i = 0; i < HALF; i++)
+            v[i] = base[(unsigned)min(h * HALF + i, rows - 1) * row_stride + ccol];
         const int slot = t % RING_SLOTS;
         if (t >= RING_SLOTS)
             while (lds_flag_load(&sh.consumed) < t - RING_SLOTS + 1)
                 __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const bool full = (t + 1) * TILE <= min_terms;  // every chain still covers the whole tile
+        if (h == 0) {
 #pragma unroll
-        for (int r = 0; r < TILE; r++) {
-            double x = (double)v[r];
-            if (VARIANCE) {
-                const double d = x - __shfl(mean_of_lane, r);
-                x = d * d;  // math.Pow(d, 2)
+            for (int i = 0; i < HALF; i++) {
+                double x = (double)v[i];
+                if (VARIANCE) {
+                    const double d = x - __shfl(mean_of_lane, i);
+                    x = d * d;  // math.Pow(d, 2)
+                }
+                if (!full && (int)col >= __shfl(terms_of_lane, i))
+                    x = 0.0;
+                sh.term[slot][i][lane] = x;
             }
-            if (!full && (int)col >= __shfl(terms_of_lane, r))
-                x = 0.0;
-            sh.term[slot][r][lane] = x;
+        } else {
+#pragma unroll
+            for (int i = 0; i < HALF; i++) {
+                double x = (double)v[i];
+                if (VARIANCE) {
+                    const double d = x - __shfl(mean_of_lane, HALF + i);
+                    x = d * d;
+                }
+                if (!full && (int)col >= __shfl(terms_of_lane, HALF + i))
+                    x = 0.0;
+                sh.term[slot][HALF + i][lane] = x;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0)
-            lds_flag_store(&sh.ready[slot], t + 1);
+            lds_flag_store(&sh.ready[slot][h], t + 1);
     }
 }
 
@@ -86,12 +103,15 @@ __device__ __forceinline__ double chain_consumer(ChainShared &sh, int n_tiles, i
     __builtin_amdgcn_s_setprio(3);
     for (int t = 0; t < n_tiles; t++) {
         const int slot = t % RING_SLOTS;
-        while (lds_flag_load(&sh.ready[slot]) != t + 1)
+        while (lds_flag_load(&sh.ready[slot][0]) != t + 1 || lds_flag_load(&sh.ready[slot][1]) != t + 1)
             __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll 1
+        for (int j0 = 0; j0 < TILE; j0 += 16) {
 #pragma unroll
-        for (int j = 0; j < TILE; j++)
-            sum += sh.term[slot][lane][j];
+            for (int j = 0; j < 16; j++)
+                sum += sh.term[slot][lane][j0 + j];
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0)
             lds_flag_store(&sh.consumed, t + 1);
@@ -111,8 +131,10 @@ __device__ __forceinline__ double chain_run(ChainShared &sh, const float *__rest
     if (wave == 0) {
         sh.n_terms[lane] = my_terms;
         sh.mean[lane] = my_mean;
-        if (lane < RING_SLOTS)
-            sh.ready[lane] = 0;
+        if (lane < RING_SLOTS) {
+            sh.ready[lane][0] = 0;
+            sh.ready[lane][1] = 0;
+        }
         if (lane == 0)
             sh.consumed = 0;
     }

@@ -4,19 +4,20 @@
 // Scheduling.  The FFT/projection kernel is throughput work that fills the whole chip; everything
 // after it is a set of short, strictly ordered chains (float64 noise-floor sums, the rolling means,
 // the per-signal decoders) that occupy a handful of CUs for a long time.  Run back to back they would
-// leave the chip idle most of the step, so a bank is a four-stage software pipeline on four streams:
+// leave the chip idle most of the step, so a bank is a software pipeline over four streams (four is
+// also the number of hardware queues HIP maps streams to by default; more streams alias and serialise):
 //
 //   s_fft     k_fft_project(i)                                        (the caller's stream)
-//   s_noise   k_window_means(i) -> k_noise_stats(i) -> k_thresholds(i)
-//   s_listen  k_listen_gather(i) -> k_listen_decode(i)
+//   s_noise   k_window_means(i) -> k_noise_stats(i)
+//   s_listen  k_thresholds(i) -> k_listen_gather(i) -> k_listen_decode(i)
 //   s_peaks   k_cumulate(i) -> k_find_peaks(i)
 //
 // Batch i's per-batch buffers (spectrum, psd, frame records, keying bits, peaks ...) live in set
-// i % RING, and events order the stages: noise(i) after fft(i); listen(i) after noise(i); cumulate(i)
-// after fft(i), find_peaks(i) after noise(i); fft(i) after every reader of set i % RING from batch
-// i - RING.  State that is carried from frame to frame (rolling rings, cumulation carry, decoders) is
-// only ever touched by one stage, whose stream keeps it in batch order.  Results are read after
-// sdr_sync(), which drains all four streams.
+// i % RING, and events order the stages: noise(i) after fft(i); thresholds(i) after noise(i); listen(i)
+// after thresholds(i); cumulate(i) after fft(i), find_peaks(i) after thresholds(i); fft(i) after every
+// reader of set i % RING from batch i - RING.  State that is carried from frame to frame is only ever
+// touched by one stage, whose stream keeps it in batch order.  Results are read after sdr_sync(), which
+// drains every stream.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -84,6 +85,7 @@ const char *kKernelNames[sdr::K_COUNT] = {"k_fft_project",   "k_window_means", "
 
 constexpr int RING = 3;  // per-batch buffer sets in flight
 enum Stage { S_FFT = 0, S_NOISE, S_LISTEN, S_PEAKS, N_STAGES };
+constexpr int S_THR = N_STAGES;  // event slot of k_thresholds (it runs on the listen stream)
 
 // Everything one batch produces.
 struct BatchSet {
@@ -98,7 +100,7 @@ struct BatchSet {
     DevBuf<float> cum_out;            // [band][max_chunks][N]
     DevBuf<sdr::DevPeak> dev_peaks;   // [band][max_chunks][max_peaks]
     DevBuf<int> peak_counts;          // [band][max_chunks]
-    hipEvent_t done[N_STAGES] = {};   // recorded when the stage has finished with this set
+    hipEvent_t done[N_STAGES + 1] = {};  // recorded when the stage has finished with this set
     void release()
     {
         spectrum.release();
@@ -278,10 +280,10 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     const int si = (int)(b->batch_index % RING);
     BatchSet &S = b->set[si];
     hipStream_t s_fft = b->stream[S_FFT], s_noise = b->stream[S_NOISE], s_listen = b->stream[S_LISTEN],
-                s_peaks = b->stream[S_PEAKS];
+                s_peaks = b->stream[S_PEAKS], s_thr = s_listen;
 
     // stage 0: FFT + projection, once every reader of this set (batch i - RING) is done with it
-    HIP_TRY(hipStreamWaitEvent(s_fft, S.done[S_NOISE], 0));
+    HIP_TRY(hipStreamWaitEvent(s_fft, S.done[S_THR], 0));
     HIP_TRY(hipStreamWaitEvent(s_fft, S.done[S_LISTEN], 0));
     HIP_TRY(hipStreamWaitEvent(s_fft, S.done[S_PEAKS], 0));
     {
@@ -290,7 +292,7 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     }
     HIP_TRY(hipEventRecord(S.done[S_FFT], s_fft));
 
-    // stage 1: noise floor + thresholds
+    // stage 1: noise floor (stateless per batch)
     HIP_TRY(hipStreamWaitEvent(s_noise, S.done[S_FFT], 0));
     {
         ProfScope ps(b, sdr::K_WINDOW_MEANS, s_noise);
@@ -300,17 +302,21 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         ProfScope ps(b, sdr::K_NOISE_STATS, s_noise);
         HIP_TRY(sdr::launch_noise_stats(S.psd.p, S.win_mean.p, S.recs.p, ng, n_frames, B, stride, s_noise));
     }
-    {
-        ProfScope ps(b, sdr::K_THRESHOLDS, s_noise);
-        HIP_TRY(sdr::launch_thresholds(S.recs.p, b->band_state.p, n_frames, B, stride, s_noise));
-    }
     HIP_TRY(hipEventRecord(S.done[S_NOISE], s_noise));
+
+    // stage 1b: rolling means -> thresholds, in batch order
+    HIP_TRY(hipStreamWaitEvent(s_thr, S.done[S_NOISE], 0));
+    {
+        ProfScope ps(b, sdr::K_THRESHOLDS, s_thr);
+        HIP_TRY(sdr::launch_thresholds(S.recs.p, b->band_state.p, n_frames, B, stride, s_thr));
+    }
+    HIP_TRY(hipEventRecord(S.done[S_THR], s_thr));
 
     // stage 2: per-signal envelope + decoder
     int max_slots = 0;
     for (int i = 0; i < B; i++)
         max_slots = std::max(max_slots, b->n_slots[i]);
-    HIP_TRY(hipStreamWaitEvent(s_listen, S.done[S_NOISE], 0));
+    HIP_TRY(hipStreamWaitEvent(s_listen, S.done[S_THR], 0));
     if (max_slots > 0) {
         sdr::ListenGeom lg;
         lg.n = N;
@@ -356,7 +362,7 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     if (new_count != 0)
         b->carry_cur ^= 1;
     if (b->find_peaks && n_chunks > 0) {
-        HIP_TRY(hipStreamWaitEvent(s_peaks, S.done[S_NOISE], 0));  // needs the completing frame's peak threshold
+        HIP_TRY(hipStreamWaitEvent(s_peaks, S.done[S_THR], 0));  // needs the completing frame's peak threshold
         ProfScope ps(b, sdr::K_FIND_PEAKS, s_peaks);
         sdr::PeakGeom pg{N, stride, count0, b->max_chunks, c.max_peaks};
         HIP_TRY(sdr::launch_find_peaks(S.cum_out.p, S.recs.p, S.dev_peaks.p, S.peak_counts.p, pg, n_chunks, B, s_peaks));
