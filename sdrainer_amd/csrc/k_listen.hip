@@ -47,6 +47,8 @@ __global__ __launch_bounds__(64) void k_listen_gather(const float *__restrict__ 
     }
 }
 
+constexpr int DECODE_LANES = 16;
+
 struct TextSink {
     uint32_t *buf;
     uint32_t count, cap, dropped;
@@ -67,7 +69,11 @@ __global__ __launch_bounds__(64) void k_listen_decode(ListenerSlot *__restrict__
                                                       uint32_t *__restrict__ edge_counts, uint8_t *__restrict__ tr_deb,
                                                       ListenGeom g, int n_frames, int n_total)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (band, slot) flattened
+    // 16 signals per wave: the lanes of a wave advance in lockstep through the union of their edges, so
+    // fewer signals per wave means fewer wasted iterations (and the waves spread over more CUs)
+    if (threadIdx.x >= DECODE_LANES)
+        return;
+    const int idx = blockIdx.x * DECODE_LANES + threadIdx.x;  // (band, slot) flattened
     if (idx >= n_total)
         return;
     ListenerSlot *slot = &slots[idx];
@@ -157,7 +163,7 @@ hipError_t launch_listen_decode(ListenerSlot *slots, const uint16_t *morse, cons
                                 uint8_t *tr_deb, ListenGeom g, int n_frames, int n_bands, hipStream_t stream)
 {
     const int n_total = n_bands * g.max_listeners;
-    hipLaunchKernelGGL(k_listen_decode, dim3((n_total + 63) / 64), dim3(64), 0, stream, slots, morse, raw_bits,
+    hipLaunchKernelGGL(k_listen_decode, dim3((n_total + DECODE_LANES - 1) / DECODE_LANES), dim3(64), 0, stream, slots, morse, raw_bits,
                        deb_bits, text, edges, edge_counts, tr_deb, g, n_frames, n_total);
     return hipGetLastError();
 }

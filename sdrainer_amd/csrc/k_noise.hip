@@ -21,18 +21,31 @@ constexpr int TILE = 64;
 constexpr int HALF = TILE / 2;
 constexpr int N_PRODUCERS = 15;                        // wave 0 = consumer (the chains), waves 1..15 = producers
 constexpr int CHAIN_THREADS = 64 * (1 + N_PRODUCERS);  // 1024 threads, 128 VGPRs per lane
-constexpr int RING_SLOTS = 4;                          // LDS tiles between producers and consumer
 
+// SLOTS = LDS tiles between producers and consumer: 4 (133 KB, one workgroup per CU) for the long
+// variance chains, 2 (67 KB, two workgroups per CU) for the short window sums.
+template <int SLOTS>
 struct ChainShared {
-    double term[RING_SLOTS][TILE][TILE + 1];  // [slot][chain][column]; row stride 65 doubles: conflict-free both ways
+    static constexpr int RING_SLOTS = SLOTS;
+    double term[SLOTS][TILE][TILE + 1];  // [slot][chain][column]; row stride 65 doubles: conflict-free both ways
     double mean[TILE];                        // per chain: value subtracted before squaring (variance pass)
     int n_terms[TILE];                        // per chain: number of leading terms that count
-    int ready[RING_SLOTS][2];                 // ready[t % SLOTS][h] == t + 1  <=>  rows 32h..32h+31 of tile t are published
+    int ready[SLOTS][2];                      // ready[t % SLOTS][h] == t + 1  <=>  rows 32h..32h+31 of tile t are published
     int consumed;                             // tiles the consumer has finished with
 };
 
 __device__ __forceinline__ int lds_flag_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_flag_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// lane `src` (a compile-time constant after unrolling) -> wave-uniform SGPR value: v_readlane_b32, not the
+// LDS-crossbar ds_bpermute a generic __shfl lowers to
+__device__ __forceinline__ int readlane_i32(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ double readlane_f64(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
 
 // A work unit is half a tile: 32 chains x 64 columns.  Producer wave p owns units u = p, p + 15, ...
 // (unit u = rows 32*(u&1).. of tile u>>1): it fetches the 32 chains' next 64 values (row r = chain r, one
@@ -41,8 +54,8 @@ __device__ __forceinline__ void lds_flag_store(int *p, int v) { __hip_atomic_sto
 // hidden by the other fourteen producers, not by software pipelining inside one wave.
 // Terms past a chain's own end are stored as +0.0: adding +0.0 to a non-negative float64 sum leaves it
 // bit-identical, so the consumer needs no per-lane predicate.
-template <bool VARIANCE>
-__device__ __forceinline__ void chain_producer(ChainShared &sh, const float *__restrict__ base, unsigned row_stride,
+template <bool VARIANCE, class Shared>
+__device__ __forceinline__ void chain_producer(Shared &sh, const float *__restrict__ base, unsigned row_stride,
                                                int rows, int n_cols, int n_tiles, int min_terms, int p, int lane)
 {
     // lane r keeps chain r's mean / length; rows read them with v_readlane (wave-uniform, no LDS traffic)
@@ -59,6 +72,7 @@ __device__ __forceinline__ void chain_producer(ChainShared &sh, const float *__r
 #pragma unroll
         for (int i = 0; i < HALF; i++)
             v[i] = base[(unsigned)min(h * HALF + i, rows - 1) * row_stride + ccol];
+        constexpr int RING_SLOTS = Shared::RING_SLOTS;
         const int slot = t % RING_SLOTS;
         if (t >= RING_SLOTS)
             while (lds_flag_load(&sh.consumed) < t - RING_SLOTS + 1)
@@ -70,10 +84,10 @@ __device__ __forceinline__ void chain_producer(ChainShared &sh, const float *__r
             for (int i = 0; i < HALF; i++) {
                 double x = (double)v[i];
                 if (VARIANCE) {
-                    const double d = x - __shfl(mean_of_lane, i);
+                    const double d = x - readlane_f64(mean_of_lane, i);
                     x = d * d;  // math.Pow(d, 2)
                 }
-                if (!full && (int)col >= __shfl(terms_of_lane, i))
+                if (!full && (int)col >= readlane_i32(terms_of_lane, i))
                     x = 0.0;
                 sh.term[slot][i][lane] = x;
             }
@@ -82,10 +96,10 @@ __device__ __forceinline__ void chain_producer(ChainShared &sh, const float *__r
             for (int i = 0; i < HALF; i++) {
                 double x = (double)v[i];
                 if (VARIANCE) {
-                    const double d = x - __shfl(mean_of_lane, HALF + i);
+                    const double d = x - readlane_f64(mean_of_lane, HALF + i);
                     x = d * d;
                 }
-                if (!full && (int)col >= __shfl(terms_of_lane, HALF + i))
+                if (!full && (int)col >= readlane_i32(terms_of_lane, HALF + i))
                     x = 0.0;
                 sh.term[slot][HALF + i][lane] = x;
             }
@@ -97,8 +111,10 @@ __device__ __forceinline__ void chain_producer(ChainShared &sh, const float *__r
 }
 
 // Consumer: lane = chain; per tile 64 strictly ordered float64 additions (ds_read_b64 + v_add_f64 each).
-__device__ __forceinline__ double chain_consumer(ChainShared &sh, int n_tiles, int lane)
+template <class Shared>
+__device__ __forceinline__ double chain_consumer(Shared &sh, int n_tiles, int lane)
 {
+    constexpr int RING_SLOTS = Shared::RING_SLOTS;
     double sum = 0;
     __builtin_amdgcn_s_setprio(3);
     for (int t = 0; t < n_tiles; t++) {
@@ -123,15 +139,15 @@ __device__ __forceinline__ double chain_consumer(ChainShared &sh, int n_tiles, i
 // Runs 64 chains (lane i of wave 0 owns chain i).  `my_terms` / `my_mean` are the consumer lane's chain
 // length and mean; returns the chain's sum in the consumer lanes.  All waits are on waves of the same
 // workgroup (co-resident by construction), so every spin terminates.
-template <bool VARIANCE>
-__device__ __forceinline__ double chain_run(ChainShared &sh, const float *__restrict__ base, size_t row_stride,
+template <bool VARIANCE, class Shared>
+__device__ __forceinline__ double chain_run(Shared &sh, const float *__restrict__ base, size_t row_stride,
                                             int rows, int n_cols, int my_terms, double my_mean)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (wave == 0) {
         sh.n_terms[lane] = my_terms;
         sh.mean[lane] = my_mean;
-        if (lane < RING_SLOTS) {
+        if (lane < Shared::RING_SLOTS) {
             sh.ready[lane][0] = 0;
             sh.ready[lane][1] = 0;
         }
@@ -159,7 +175,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_window_means(const float *__r
                                                                 double *__restrict__ win_mean, NoiseGeom g,
                                                                 int n_frames, int stride)
 {
-    __shared__ ChainShared sh;
+    __shared__ ChainShared<2> sh;
     const int lane = threadIdx.x & 63;
     const int f0 = blockIdx.x * TILE, w = blockIdx.y, band = blockIdx.z;
     const int rows = min(TILE, n_frames - f0);
@@ -178,7 +194,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_noise_stats(const float *__re
                                                                sdr_frame_rec *__restrict__ recs, NoiseGeom g,
                                                                int n_frames, int stride)
 {
-    __shared__ ChainShared sh;
+    __shared__ ChainShared<4> sh;
     const int lane = threadIdx.x & 63;
     const bool consumer = threadIdx.x < TILE;
     const int f0 = blockIdx.x * TILE, band = blockIdx.y;

@@ -32,7 +32,21 @@ __global__ __launch_bounds__(256) void k_cumulate(const float *__restrict__ spec
         acc = reinterpret_cast<const float4 *>(carry_in + (size_t)band * g.n)[i4];
     const float4 *sp = reinterpret_cast<const float4 *>(spectrum + (size_t)band * g.stride * g.n) + i4;
     const size_t fstride = g.n / 4;
-    for (int f = begin; f < end; f++) {
+    int f = begin;
+    for (; f + 10 <= end; f += 10) {  // ten independent 16-byte loads in flight, then ten ORDERED adds
+        float4 v[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++)
+            v[k] = sp[(size_t)(f + k) * fstride];
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+            acc.x += v[k].x;
+            acc.y += v[k].y;
+            acc.z += v[k].z;
+            acc.w += v[k].w;
+        }
+    }
+    for (; f < end; f++) {
         const float4 v = sp[(size_t)f * fstride];
         acc.x += v.x;
         acc.y += v.y;
