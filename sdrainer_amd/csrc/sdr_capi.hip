@@ -8,8 +8,8 @@
 // also the number of hardware queues HIP maps streams to by default; more streams alias and serialise):
 //
 //   s_fft     k_fft_project(i)                                        (the caller's stream)
-//   s_noise   k_window_means(i) -> k_noise_stats(i)
-//   s_listen  k_thresholds(i) -> k_listen_gather(i) -> k_listen_decode(i)
+//   s_noise   k_window_means(i) -> k_noise_stats(i) -> k_thresholds(i) -> k_listen_gather(i)
+//   s_listen  k_listen_decode(i)        (the longest serial stage gets a stream of its own)
 //   s_peaks   k_cumulate(i) -> k_find_peaks(i)
 //
 // Batch i's per-batch buffers (spectrum, psd, frame records, keying bits, peaks ...) live in set
@@ -280,10 +280,10 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     const int si = (int)(b->batch_index % RING);
     BatchSet &S = b->set[si];
     hipStream_t s_fft = b->stream[S_FFT], s_noise = b->stream[S_NOISE], s_listen = b->stream[S_LISTEN],
-                s_peaks = b->stream[S_PEAKS], s_thr = s_listen;
+                s_peaks = b->stream[S_PEAKS], s_thr = s_noise, s_gather = s_noise;
 
     // stage 0: FFT + projection, once every reader of this set (batch i - RING) is done with it
-    HIP_TRY(hipStreamWaitEvent(s_fft, S.done[S_THR], 0));
+    HIP_TRY(hipStreamWaitEvent(s_fft, S.done[S_NOISE], 0));
     HIP_TRY(hipStreamWaitEvent(s_fft, S.done[S_LISTEN], 0));
     HIP_TRY(hipStreamWaitEvent(s_fft, S.done[S_PEAKS], 0));
     {
@@ -302,10 +302,7 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         ProfScope ps(b, sdr::K_NOISE_STATS, s_noise);
         HIP_TRY(sdr::launch_noise_stats(S.psd.p, S.win_mean.p, S.recs.p, ng, n_frames, B, stride, s_noise));
     }
-    HIP_TRY(hipEventRecord(S.done[S_NOISE], s_noise));
-
-    // stage 1b: rolling means -> thresholds, in batch order
-    HIP_TRY(hipStreamWaitEvent(s_thr, S.done[S_NOISE], 0));
+    // rolling means -> thresholds, in batch order (same stream)
     {
         ProfScope ps(b, sdr::K_THRESHOLDS, s_thr);
         HIP_TRY(sdr::launch_thresholds(S.recs.p, b->band_state.p, n_frames, B, stride, s_thr));
@@ -316,27 +313,27 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     int max_slots = 0;
     for (int i = 0; i < B; i++)
         max_slots = std::max(max_slots, b->n_slots[i]);
-    HIP_TRY(hipStreamWaitEvent(s_listen, S.done[S_THR], 0));
+    sdr::ListenGeom lg;
+    lg.n = N;
+    lg.stride = stride;
+    lg.max_listeners = c.max_listeners;
+    lg.text_cap = b->text_cap;
+    lg.edge_cap = b->edge_cap;
+    lg.bit_words = b->bit_words;
+    lg.trace = c.trace;
+    lg.frame_base = (uint32_t)b->total_frames;
+    HIP_TRY(hipStreamWaitEvent(s_gather, S.done[S_THR], 0));
     if (max_slots > 0) {
-        sdr::ListenGeom lg;
-        lg.n = N;
-        lg.stride = stride;
-        lg.max_listeners = c.max_listeners;
-        lg.text_cap = b->text_cap;
-        lg.edge_cap = b->edge_cap;
-        lg.bit_words = b->bit_words;
-        lg.trace = c.trace;
-        lg.frame_base = (uint32_t)b->total_frames;
-        {
-            ProfScope ps(b, sdr::K_LISTEN_GATHER, s_listen);
-            HIP_TRY(sdr::launch_listen_gather(S.spectrum.p, S.recs.p, b->slots.p, S.raw_bits.p, S.tr_values.p,
-                                              S.tr_raw.p, lg, n_frames, max_slots, B, s_listen));
-        }
-        {
-            ProfScope ps(b, sdr::K_LISTEN_DECODE, s_listen);
-            HIP_TRY(sdr::launch_listen_decode(b->slots.p, b->morse.p, S.raw_bits.p, S.bits.p, b->text.p, S.edges.p,
-                                              S.edge_counts.p, S.tr_deb.p, lg, n_frames, B, s_listen));
-        }
+        ProfScope ps(b, sdr::K_LISTEN_GATHER, s_gather);
+        HIP_TRY(sdr::launch_listen_gather(S.spectrum.p, S.recs.p, b->slots.p, S.raw_bits.p, S.tr_values.p, S.tr_raw.p,
+                                          lg, n_frames, max_slots, B, s_gather));
+    }
+    HIP_TRY(hipEventRecord(S.done[S_NOISE], s_gather));  // the noise stream is done with this set
+    HIP_TRY(hipStreamWaitEvent(s_listen, S.done[S_NOISE], 0));
+    if (max_slots > 0) {
+        ProfScope ps(b, sdr::K_LISTEN_DECODE, s_listen);
+        HIP_TRY(sdr::launch_listen_decode(b->slots.p, b->morse.p, S.raw_bits.p, S.bits.p, b->text.p, S.edges.p,
+                                          S.edge_counts.p, S.tr_deb.p, lg, n_frames, B, s_listen));
     }
     HIP_TRY(hipEventRecord(S.done[S_LISTEN], s_listen));
 
