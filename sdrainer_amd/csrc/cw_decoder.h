@@ -86,15 +86,21 @@ SDR_HD inline void at_put(AdaptiveThreshold &t, double duration)  // :392-411
     const double currentWeight = 1.0 - avgWeight;
     if (duration >= t.low * t.upperBound)
         return;
+    bool moved = false;
     if (t.last >= duration * highFactor) {
         t.low = avgWeight * t.low + currentWeight * duration;
         t.high = avgWeight * t.high + currentWeight * t.last;
+        moved = true;
     } else if (duration >= t.last * highFactor) {
         t.low = avgWeight * t.low + currentWeight * t.last;
         t.high = avgWeight * t.high + currentWeight * duration;
+        moved = true;
     }
     t.last = duration;
-    at_update(t);
+    // updateThreshold() recomputes sqrt(low*high) on every Put; when neither moved the value is the one
+    // already stored (sqrt is a function), so the ~30-instruction float64 sqrt is skipped
+    if (moved)
+        at_update(t);
 }
 
 // cw.Decoder state (cw/decode.go:108-129).  currentChar is packed: `len` symbols, bit i of `bits`

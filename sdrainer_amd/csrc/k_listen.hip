@@ -61,14 +61,19 @@ struct TextSink {
     }
 };
 
-__global__ __launch_bounds__(64) void k_listen_decode(ListenerSlot *__restrict__ slots,
-                                                      const uint16_t *__restrict__ morse,
+__global__ __launch_bounds__(64) void k_listen_decode(ListenerSlot *__restrict__ slots, const uint16_t *morse,
                                                       const uint64_t *__restrict__ raw_bits,
                                                       uint64_t *__restrict__ deb_bits, uint32_t *__restrict__ text,
                                                       sdr_edge *__restrict__ edges,
                                                       uint32_t *__restrict__ edge_counts, uint8_t *__restrict__ tr_deb,
                                                       ListenGeom g, int n_frames, int n_total)
 {
+    // the 512-entry code table is hit on every decoded character, on the serial path: keep it in LDS
+    __shared__ uint16_t s_morse[cw::kMorseTableSize];
+    for (int i = threadIdx.x; i < cw::kMorseTableSize; i += blockDim.x)
+        s_morse[i] = morse[i];
+    __syncthreads();
+    morse = s_morse;
     // 16 signals per wave: the lanes of a wave advance in lockstep through the union of their edges, so
     // fewer signals per wave means fewer wasted iterations (and the waves spread over more CUs)
     if (threadIdx.x >= DECODE_LANES)

@@ -167,23 +167,29 @@ __device__ __forceinline__ double chain_run(Shared &sh, const float *__restrict_
         sum = chain_consumer(sh, n_tiles, lane);
     else
         chain_producer<VARIANCE>(sh, base, (unsigned)row_stride, rows, n_cols, n_tiles, min_terms, wave - 1, lane);
+    __syncthreads();  // everyone is done with the ring before a caller re-initialises it
     return sum;
 }
 
-// pass 1: mean of window w of frame f = sequential float64 sum of psd[edge + w*W .. +W) / W (:239-241,:230)
+// pass 1: mean of window w of frame f = sequential float64 sum of psd[edge + w*W .. +W) / W (:239-241,:230).
+// A workgroup walks `windows_per_block` windows of its 64 frames back to back: with many bands there are
+// thousands of (frame group, window) chains, and one long-lived workgroup per CU beats ten short ones.
 __global__ __launch_bounds__(CHAIN_THREADS) void k_window_means(const float *__restrict__ psd,
                                                                 double *__restrict__ win_mean, NoiseGeom g,
-                                                                int n_frames, int stride)
+                                                                int n_frames, int stride, int windows_per_block)
 {
     __shared__ ChainShared<2> sh;
     const int lane = threadIdx.x & 63;
-    const int f0 = blockIdx.x * TILE, w = blockIdx.y, band = blockIdx.z;
+    const int f0 = blockIdx.x * TILE, band = blockIdx.z;
     const int rows = min(TILE, n_frames - f0);
     const size_t frame0 = (size_t)band * stride + f0;
-    const float *base = psd + frame0 * g.n + g.edge + (size_t)w * g.window;
-    const double sum = chain_run<false>(sh, base, g.n, rows, g.window, lane < rows ? g.window : 0, 0.0);
-    if (threadIdx.x < rows)
-        win_mean[(frame0 + lane) * 10 + w] = sum / (double)g.window;
+    const int w_end = min(g.n_windows, (int)(blockIdx.y + 1) * windows_per_block);
+    for (int w = blockIdx.y * windows_per_block; w < w_end; w++) {
+        const float *base = psd + frame0 * g.n + g.edge + (size_t)w * g.window;
+        const double sum = chain_run<false>(sh, base, g.n, rows, g.window, lane < rows ? g.window : 0, 0.0);
+        if (threadIdx.x < rows)
+            win_mean[(frame0 + lane) * 10 + w] = sum / (double)g.window;
+    }
 }
 
 // pass 2: pick the minimum window in the reference's order, then the variance chain over
@@ -332,8 +338,12 @@ __global__ __launch_bounds__(256) void k_thresholds(sdr_frame_rec *__restrict__ 
 hipError_t launch_window_means(const float *psd, double *win_mean, NoiseGeom g, int n_frames, int n_bands, int stride,
                                hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_window_means, dim3((n_frames + TILE - 1) / TILE, g.n_windows, n_bands), dim3(CHAIN_THREADS), 0, stream,
-                       psd, win_mean, g, n_frames, stride);
+    // enough workgroups to cover the chip (two fit per CU), but no more than needed
+    const int groups = ((n_frames + TILE - 1) / TILE) * n_bands;
+    int wpb = (groups * g.n_windows) / 512;
+    wpb = wpb < 1 ? 1 : (wpb > g.n_windows ? g.n_windows : wpb);
+    hipLaunchKernelGGL(k_window_means, dim3((n_frames + TILE - 1) / TILE, (g.n_windows + wpb - 1) / wpb, n_bands),
+                       dim3(CHAIN_THREADS), 0, stream, psd, win_mean, g, n_frames, stride, wpb);
     return hipGetLastError();
 }
 

@@ -338,3 +338,96 @@ def test_full_size_properties(capi):
         found = {p[6] for p in chunk}
         assert found <= want  # no spurious peaks: every reported signal bin is a transmitted carrier
         assert len(found) >= 0.9 * len(want)  # a carrier idling in a word gap for most of the 100 frames is skipped
+
+
+@pytest.mark.parametrize("n,rate,tones,frames,listeners", [(8192, 2000000, 16, 130, 16), (16384, 2000000, 64, 130, 64)])
+def test_receiver_run_bit_exact_large_blocks(capi, n, rate, tones, frames, listeners):
+    """The big block sizes of BASELINE configs 3-5 through the whole loop (noise chains span 190 tiles)."""
+    iq, bins, _ = synth.make_band(frames, rate, n, tones, seed=n + 5, free_last_window=True)
+    edge = synth.default_edge_width(n)
+    ref = orc.Receiver(rate, n, edge)
+    bank = capi.Bank(rate, n, edge_width=edge, max_batch_frames=frames, max_listeners=listeners, max_peaks=512)
+    for b in bins[:listeners]:
+        ref.attach(int(b))
+        bank.attach(0, int(b))
+    out = ref.process(iq)
+    assert bank.process_host(iq) == frames
+    _assert_records_equal(bank.read_frame_records(0), out["frames"])
+    for lid in range(listeners):
+        assert np.array_equal(bank.read_keying_bits(0, lid), out["deb"][:, lid])
+        assert bank.read_text(0, lid) == ref.text(lid)
+    assert _bits_equal(bank.read_cumulation(0, 0), out["cumulation"][0])
+    assert bank.read_peaks(0, 0)[0] == out["peaks"][0]
+    bank.close()
+
+
+def test_nine_window_geometry(capi):
+    """(N - 2*edge) % 10 == 0: the reference's loop never evaluates the tenth window (dsp/fft.go:226-238)."""
+    n, rate, edge = 512, 48000, 66  # span 380 = 10 * 38
+    iq, bins, _ = synth.make_band(140, rate, n, 3, seed=66, edge_width=edge)
+    ref = orc.Receiver(rate, n, edge)
+    bank = capi.Bank(rate, n, edge_width=edge, max_batch_frames=256, max_listeners=4, max_peaks=64)
+    for b in bins:
+        ref.attach(int(b))
+        bank.attach(0, int(b))
+    out = ref.process(iq)
+    bank.process_host(iq)
+    _assert_records_equal(bank.read_frame_records(0), out["frames"])
+    assert bank.read_peaks(0, 0)[0] == out["peaks"][0]
+    bank.close()
+
+
+def _nan_equal_bits(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    both_nan = np.isnan(a) & np.isnan(b)  # the sign / payload of a NaN is not part of the contract
+    u = {4: np.uint32, 8: np.uint64}[a.dtype.itemsize]
+    return np.array_equal(np.where(both_nan, 0, a.view(u)), np.where(both_nan, 0, b.view(u)))
+
+
+def test_degenerate_inputs_follow_the_reference(capi):
+    """Noise-only frames, then an all-zero frame: log10(0) = -Inf enters the running-sum means and turns
+    them into NaN forever (SURVEY §7 'degenerate inputs') — same on both sides, nothing crashes."""
+    n, rate = 512, 48000
+    rng = np.random.default_rng(8)
+    iq = (1e-3 * rng.standard_normal((90, 2 * n))).astype(np.float32)
+    iq[70] = 0.0
+    ref = orc.Receiver(rate, n, 70)
+    bank = capi.Bank(rate, n, max_batch_frames=128, max_listeners=2, trace=True)
+    ref.attach(200)
+    bank.attach(0, 200)
+    out = ref.process(iq, want_spectrum=True)
+    bank.process_host(iq)
+    got = bank.read_frame_records(0)
+    for f in REC_FIELDS:
+        assert _nan_equal_bits(got[f], out["frames"][f]), f
+    assert np.isnan(got["listen_thr"][71:]).all() and not np.isnan(got["listen_thr"][:70]).any()
+    sp, psd = bank.read_spectrum(0, 70)
+    assert np.all(psd == 0) and np.all(np.isneginf(sp))
+    v, r, d = bank.read_trace(0, 0)
+    assert np.array_equal(r, out["raw"][:, 0])
+    assert bank.read_text(0, 0) == ref.text(0)
+    bank.close()
+
+
+def test_detach_and_reattach_mid_stream(capi):
+    n, rate = 512, 48000
+    iq, bins, _ = synth.make_band(300, rate, n, 2, seed=123)
+    ref = orc.Receiver(rate, n, 70)
+    bank = capi.Bank(rate, n, max_batch_frames=128, max_listeners=2)
+    a = bank.attach(0, int(bins[0]))
+    ra = ref.attach(int(bins[0]))
+    out1 = ref.process(iq[:100])
+    bank.process_host(iq[:100])
+    assert np.array_equal(bank.read_keying_bits(0, a), out1["deb"][:, ra])
+    bank.detach(0, a)
+    ref.detach(ra)
+    ref.process(iq[100:200])
+    bank.process_host(iq[100:200])
+    b = bank.attach(0, int(bins[1]))  # slot of the detached listener is reused, with a brand-new decoder
+    rb = ref.attach(int(bins[1]))
+    assert b == a
+    out3 = ref.process(iq[200:])
+    bank.process_host(iq[200:])
+    assert np.array_equal(bank.read_keying_bits(0, b), out3["deb"][:, rb])
+    assert np.array_equal(bank.read_decoder_state(0, b), ref.decoder_state(rb))
+    bank.close()
