@@ -385,14 +385,15 @@ def _nan_equal_bits(a, b):
 
 
 def test_degenerate_inputs_follow_the_reference(capi):
-    """Noise-only frames, then an all-zero frame: log10(0) = -Inf enters the running-sum means and turns
-    them into NaN forever (SURVEY §7 'degenerate inputs') — same on both sides, nothing crashes."""
+    """Noise-only frames, then an all-zero frame: log10(0) = -Inf enters the running-sum means, which read
+    -Inf for 60 frames and NaN forever after the -Inf leaves the window (-Inf - -Inf; SURVEY §7
+    'degenerate inputs') — same on both sides, nothing crashes."""
     n, rate = 512, 48000
     rng = np.random.default_rng(8)
-    iq = (1e-3 * rng.standard_normal((90, 2 * n))).astype(np.float32)
+    iq = (1e-3 * rng.standard_normal((150, 2 * n))).astype(np.float32)
     iq[70] = 0.0
     ref = orc.Receiver(rate, n, 70)
-    bank = capi.Bank(rate, n, max_batch_frames=128, max_listeners=2, trace=True)
+    bank = capi.Bank(rate, n, max_batch_frames=256, max_listeners=2, trace=True)
     ref.attach(200)
     bank.attach(0, 200)
     out = ref.process(iq, want_spectrum=True)
@@ -400,7 +401,8 @@ def test_degenerate_inputs_follow_the_reference(capi):
     got = bank.read_frame_records(0)
     for f in REC_FIELDS:
         assert _nan_equal_bits(got[f], out["frames"][f]), f
-    assert np.isnan(got["listen_thr"][71:]).all() and not np.isnan(got["listen_thr"][:70]).any()
+    assert np.isfinite(got["listen_thr"][:70]).all()
+    assert np.isneginf(got["listen_thr"][70:130]).all() and np.isnan(got["listen_thr"][130:]).all()
     sp, psd = bank.read_spectrum(0, 70)
     assert np.all(psd == 0) and np.all(np.isneginf(sp))
     v, r, d = bank.read_trace(0, 0)
