@@ -83,7 +83,7 @@ int ilog2(int n)
 const char *kKernelNames[sdr::K_COUNT] = {"k_fft_project",   "k_window_means", "k_noise_stats", "k_thresholds",
                                           "k_listen_gather", "k_cumulate",     "k_find_peaks",  "k_listen_decode"};
 
-constexpr int RING = 3;  // per-batch buffer sets in flight
+constexpr int RING = 4;  // per-batch buffer sets in flight
 enum Stage { S_FFT = 0, S_NOISE, S_LISTEN, S_PEAKS, N_STAGES };
 constexpr int S_THR = N_STAGES;  // event slot of k_thresholds (it runs on the listen stream)
 
@@ -283,9 +283,11 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
                 s_peaks = b->stream[S_PEAKS], s_thr = s_noise, s_gather = s_noise;
 
     // stage 0: FFT + projection, once every reader of this set (batch i - RING) is done with it
-    HIP_TRY(hipStreamWaitEvent(s_fft, S.done[S_NOISE], 0));
-    HIP_TRY(hipStreamWaitEvent(s_fft, S.done[S_LISTEN], 0));
-    HIP_TRY(hipStreamWaitEvent(s_fft, S.done[S_PEAKS], 0));
+    // (with RING sets the previous user is four batches back and has almost always finished: ask the
+    // host first, a barrier packet in the FFT queue costs the command processor tens of microseconds)
+    for (int st : {(int)S_NOISE, (int)S_LISTEN, (int)S_PEAKS})
+        if (hipEventQuery(S.done[st]) != hipSuccess)
+            HIP_TRY(hipStreamWaitEvent(s_fft, S.done[st], 0));
     {
         ProfScope ps(b, sdr::K_FFT, s_fft);
         HIP_TRY(sdr::launch_fft(b->logn, iq_dev, b->tw.p, S.spectrum.p, S.psd.p, n_frames, B, in_stride, stride, s_fft));
