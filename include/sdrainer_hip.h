@@ -25,6 +25,7 @@
  *   sdr_read_text                   the io.Writer each Listener's Decoder writes to  cw/decode.go:352-355
  *   sdr_read_edges / _trace         what cw.SpectralDemodulator.Tick hands to Decoder.Tick  cw/spectral.go:48-54
  *   sdr_read_frame_records          locals of Receiver.run (noise floor, thresholds)  rx/receiver.go:381-385
+ *   sdr_push_kiwi_snd               decodeIQMessage + kiwi.Process.IQData       kiwi/client.go:284-308, kiwi/kiwi.go:94-105
  *   sdr_audio_*                     cw.AudioDemodulator (Goertzel audio path)   cw/audio.go:37-211
  *
  * Semantics kept from the reference: setters take effect between frames, never mid-frame (here: at
@@ -126,6 +127,12 @@ int sdr_set_stream(sdr_bank *bank, void *hip_stream);
 /* Copies n_floats/(2*block_size) interleaved I,Q float32 frames of `band` from host memory into the
  * bank's pinned staging queue (the input is borrowed only for the duration of the call). */
 int sdr_push_iq(sdr_bank *bank, int band, int sample_rate, const float *iq, size_t n_floats);
+/* KiwiSDR source: `payload` is one "SND" websocket message body (kiwi/client.go:284-308): a 17-byte
+ * header (flags, sequence number, S-meter, GPS) followed by big-endian int16 I,Q pairs.  The raw bytes
+ * are staged and unpacked ON THE DEVICE to float32 = float32(int16) / 32767 when the batch is processed;
+ * like kiwi.Process.IQData (kiwi/kiwi.go:94-105) the message must hold whole frames (BAD_SIZE
+ * otherwise).  A band's batch must not mix this with sdr_push_iq (SDR_ERR_STATE). */
+int sdr_push_kiwi_snd(sdr_bank *bank, int band, int sample_rate, const uint8_t *payload, size_t n_bytes);
 /* Frames currently staged for `band`. */
 int sdr_staged_frames(sdr_bank *bank, int band);
 /* Uploads and processes min-over-bands staged frames; *n_frames_out = frames consumed per band. */

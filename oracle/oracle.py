@@ -97,6 +97,7 @@ def lib():
     sig("orc_frequency_to_bin", C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64)
     sig("orc_peak_center_correction", C.c_double, C.c_int, fp, C.c_int)
     sig("orc_find_peaks", C.c_int, fp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int64, C.POINTER(Peak), C.c_int)
+    sig("orc_decode_iq_message", C.c_long, C.c_char_p, C.c_size_t, fp)
     sig("orc_rolling_mean_new", C.c_void_p, C.c_int)
     sig("orc_rolling_mean_put", C.c_float, C.c_void_p, C.c_float)
     sig("orc_rolling_mean_free", None, C.c_void_p)
@@ -219,6 +220,15 @@ def find_peaks(cum: np.ndarray, threshold: float, sample_rate: int, center: int 
     n = lib().orc_find_peaks(_p(cum, C.c_float), cum.size, cumulation_size, np.float32(threshold), sample_rate, center,
                              arr, max_peaks)
     return [arr[i].astuple() for i in range(min(n, max_peaks))]
+
+
+def decode_iq_message(payload: bytes) -> np.ndarray:
+    """kiwi/client.go:284-308: SND message body -> interleaved I,Q float32."""
+    out = np.empty(max(0, (len(payload) - 17) // 2), np.float32)
+    n = lib().orc_decode_iq_message(payload, len(payload), _p(out, C.c_float))
+    if n < 0:
+        raise ValueError("payload shorter than the 17-byte SND header")
+    return out[:n]
 
 
 class Decoder:

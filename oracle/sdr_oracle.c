@@ -526,6 +526,27 @@ ORC_API int orc_find_peaks(const float *spectrum, int n, int cumulation_size, fl
 }
 
 /* ------------------------------------------------------------------------ */
+/* kiwi/client.go:284-308 decodeIQMessage / decodeIQBytes (source wire format) */
+/* ------------------------------------------------------------------------ */
+
+/* payload = body of one SND message; returns the number of float32 values written
+ * (= (n_bytes - 17) / 2), or -1 if the payload is shorter than its 17-byte header.
+ * The reference holds no test vector for this function (parity unpinned); the arithmetic is one
+ * correctly rounded float32 division: float32(int16(be16)) / float32(math.MaxInt16). */
+ORC_API long orc_decode_iq_message(const uint8_t *payload, size_t n_bytes, float *iq)
+{
+    if (n_bytes < 17)
+        return -1;
+    const uint8_t *b = payload + 17;
+    size_t n = (n_bytes - 17) / 2;
+    for (size_t i = 0; i < n; i++) {
+        uint16_t raw = (uint16_t)((b[2 * i] << 8) | b[2 * i + 1]); /* binary.BigEndian.Uint16 */
+        iq[i] = (float)(int16_t)raw / 32767.0f;
+    }
+    return (long)n;
+}
+
+/* ------------------------------------------------------------------------ */
 /* dsp/dsp.go                                                                */
 /* ------------------------------------------------------------------------ */
 

@@ -55,7 +55,7 @@ _lib = None
 
 # every symbol include/sdrainer_hip.h declares (tests/test_capi_symbols.py checks the header against this)
 SYMBOLS = (
-    "sdr_last_error sdr_abi_version sdr_create sdr_destroy sdr_set_stream sdr_push_iq sdr_staged_frames "
+    "sdr_last_error sdr_abi_version sdr_create sdr_destroy sdr_set_stream sdr_push_iq sdr_push_kiwi_snd sdr_staged_frames "
     "sdr_process_staged sdr_process_staged_limit sdr_process_device sdr_sync sdr_attach sdr_detach sdr_listener_count sdr_listener_stop "
     "sdr_set_peak_threshold sdr_set_edge_width sdr_set_signal_debounce sdr_set_center_frequency sdr_set_find_peaks "
     "sdr_last_batch_frames sdr_total_frames sdr_last_batch_chunks sdr_read_peaks sdr_read_cumulation sdr_read_text "
@@ -98,6 +98,7 @@ def load():
     sig("sdr_destroy", C.c_int, vp)
     sig("sdr_set_stream", C.c_int, vp, vp)
     sig("sdr_push_iq", C.c_int, vp, C.c_int, C.c_int, fp, C.c_size_t)
+    sig("sdr_push_kiwi_snd", C.c_int, vp, C.c_int, C.c_int, C.c_char_p, C.c_size_t)
     sig("sdr_staged_frames", C.c_int, vp, C.c_int)
     sig("sdr_process_staged", C.c_int, vp, ip)
     sig("sdr_process_staged_limit", C.c_int, vp, C.c_int, ip)
@@ -190,7 +191,14 @@ class Bank:
         """Returns the status code (0 ok) instead of raising for the reference's log-and-drop cases."""
         iq = np.ascontiguousarray(iq, dtype=np.float32)
         rc = self._L.sdr_push_iq(self._h, band, sample_rate, iq.ctypes.data_as(C.POINTER(C.c_float)), iq.size)
-        if rc not in (OK, ERR_BAD_RATE, ERR_BAD_SIZE, ERR_WOULD_DROP):
+        if rc not in (OK, ERR_BAD_RATE, ERR_BAD_SIZE, ERR_WOULD_DROP, ERR_STATE):
+            _check(rc)
+        return rc
+
+    def push_kiwi_snd(self, band: int, sample_rate: int, payload: bytes) -> int:
+        """payload: body of one KiwiSDR SND message (17-byte header + big-endian int16 IQ)."""
+        rc = self._L.sdr_push_kiwi_snd(self._h, band, sample_rate, payload, len(payload))
+        if rc not in (OK, ERR_BAD_RATE, ERR_BAD_SIZE, ERR_WOULD_DROP, ERR_STATE):
             _check(rc)
         return rc
 

@@ -164,6 +164,10 @@ struct sdr_bank {
 
     float *h_stage = nullptr;  // pinned [band][max_batch][2N]
     std::vector<int> staged;
+    // KiwiSDR source: raw big-endian int16 payloads staged as bytes, unpacked on the device
+    uint8_t *h_raw = nullptr;      // pinned [band][max_batch][2N * 2 bytes]
+    DevBuf<uint8_t> raw_stage_dev;  // same layout, uploaded per batch
+    std::vector<int> staged_kind;   // per band: 0 nothing staged, 1 float32 frames, 2 int16be frames
 
     bool profiling = false;
     double prof_ms[sdr::K_COUNT] = {};
@@ -504,6 +508,7 @@ int sdr_create(const sdr_config *cfg, sdr_bank **out)
     b->n_slots.assign(B, 0);
     b->center_frequency.assign(B, 0);
     b->staged.assign(B, 0);
+    b->staged_kind.assign(B, 0);
     *out = b;
     return SDR_OK;
 }
@@ -531,6 +536,9 @@ int sdr_destroy(sdr_bank *b)
             (void)hipStreamDestroy(b->stream[s]);
     if (b->h_stage)
         (void)hipHostFree(b->h_stage);
+    if (b->h_raw)
+        (void)hipHostFree(b->h_raw);
+    b->raw_stage_dev.release();
     delete b;
     return SDR_OK;
 }
@@ -565,6 +573,9 @@ int sdr_push_iq(sdr_bank *b, int band, int sample_rate, const float *iq, size_t 
     const size_t nf = n_floats / per;
     if ((size_t)b->staged[band] + nf > (size_t)c.max_batch_frames)  // rx/receiver.go:328-333
         return fail(SDR_ERR_WOULD_DROP, "IQ data skipped: staging queue full");
+    if (b->staged[band] > 0 && b->staged_kind[band] != 1)
+        return fail(SDR_ERR_STATE, "band already holds raw KiwiSDR frames in this batch");
+    b->staged_kind[band] = 1;
     if (!b->h_stage) {
         HIP_TRY(hipSetDevice(b->device));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_stage),
@@ -572,6 +583,37 @@ int sdr_push_iq(sdr_bank *b, int band, int sample_rate, const float *iq, size_t 
     }
     float *dst = b->h_stage + ((size_t)band * c.max_batch_frames + (size_t)b->staged[band]) * per;
     memcpy(dst, iq, sizeof(float) * n_floats);  // copy on push: the caller may reuse its buffer (kiwi/client.go:203)
+    b->staged[band] += (int)nf;
+    return SDR_OK;
+}
+
+int sdr_push_kiwi_snd(sdr_bank *b, int band, int sample_rate, const uint8_t *payload, size_t n_bytes)
+{
+    int rc = check_band(b, band);
+    if (rc)
+        return rc;
+    if (!payload)
+        return fail(SDR_ERR_BAD_ARG, "null payload");
+    const sdr_config &c = b->cfg;
+    if (sample_rate != c.sample_rate)
+        return fail(SDR_ERR_BAD_RATE, "wrong incoming sample rate");
+    constexpr size_t kHeader = 17;  // flags, sequence, S-meter, GPS (kiwi/client.go:285-290)
+    const size_t per = 2 * (size_t)c.block_size * 2;  // bytes per frame: 2N int16
+    if (n_bytes <= kHeader || (n_bytes - kHeader) % per != 0)  // kiwi/kiwi.go:96-98 panics on a partial block
+        return fail(SDR_ERR_BAD_SIZE, "SND payload does not hold whole frames");
+    const size_t nf = (n_bytes - kHeader) / per;
+    if ((size_t)b->staged[band] + nf > (size_t)c.max_batch_frames)
+        return fail(SDR_ERR_WOULD_DROP, "IQ data skipped: staging queue full");
+    if (b->staged[band] > 0 && b->staged_kind[band] != 2)
+        return fail(SDR_ERR_STATE, "band already holds float32 frames in this batch");
+    b->staged_kind[band] = 2;
+    if (!b->h_raw) {
+        HIP_TRY(hipSetDevice(b->device));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_raw), per * (size_t)c.max_batch_frames * (size_t)c.n_bands,
+                              hipHostMallocDefault));
+    }
+    memcpy(b->h_raw + ((size_t)band * c.max_batch_frames + (size_t)b->staged[band]) * per, payload + kHeader,
+           n_bytes - kHeader);
     b->staged[band] += (int)nf;
     return SDR_OK;
 }
@@ -607,10 +649,24 @@ int sdr_process_staged_limit(sdr_bank *b, int max_frames, int *n_frames_out)
         if (e != hipSuccess)
             return fail(SDR_ERR_HIP, "hipMalloc iq staging failed");
     }
-    for (int band = 0; band < c.n_bands; band++)
-        HIP_TRY(hipMemcpyAsync(b->iq_stage_dev.p + (size_t)band * n * per,
-                               b->h_stage + (size_t)band * c.max_batch_frames * per, sizeof(float) * per * (size_t)n,
-                               hipMemcpyHostToDevice, b->stream[S_FFT]));
+    for (int band = 0; band < c.n_bands; band++) {
+        float *dst = b->iq_stage_dev.p + (size_t)band * n * per;
+        if (b->staged_kind[band] == 2) {
+            // raw int16be payload: upload half the bytes, unpack in HBM (k_unpack.hip)
+            if (!b->raw_stage_dev.p) {
+                hipError_t e = b->raw_stage_dev.alloc(2 * per * (size_t)c.max_batch_frames * (size_t)c.n_bands);
+                if (e != hipSuccess)
+                    return fail(SDR_ERR_HIP, "hipMalloc raw staging failed");
+            }
+            uint8_t *rdst = b->raw_stage_dev.p + (size_t)band * c.max_batch_frames * per * 2;
+            HIP_TRY(hipMemcpyAsync(rdst, b->h_raw + (size_t)band * c.max_batch_frames * per * 2, 2 * per * (size_t)n,
+                                   hipMemcpyHostToDevice, b->stream[S_FFT]));
+            HIP_TRY(sdr::launch_unpack_be16(rdst, dst, per * (size_t)n, b->stream[S_FFT]));
+        } else {
+            HIP_TRY(hipMemcpyAsync(dst, b->h_stage + (size_t)band * c.max_batch_frames * per, sizeof(float) * per * (size_t)n,
+                                   hipMemcpyHostToDevice, b->stream[S_FFT]));
+        }
+    }
     int rc = process_device_impl(b, b->iq_stage_dev.p, n, n);
     if (rc)
         return rc;
@@ -619,8 +675,15 @@ int sdr_process_staged_limit(sdr_bank *b, int max_frames, int *n_frames_out)
     for (int band = 0; band < c.n_bands; band++) {
         const int left = b->staged[band] - n;
         if (left > 0) {
-            float *base = b->h_stage + (size_t)band * c.max_batch_frames * per;
-            memmove(base, base + (size_t)n * per, sizeof(float) * per * (size_t)left);
+            if (b->staged_kind[band] == 2) {
+                uint8_t *base = b->h_raw + (size_t)band * c.max_batch_frames * per * 2;
+                memmove(base, base + (size_t)n * per * 2, per * 2 * (size_t)left);
+            } else {
+                float *base = b->h_stage + (size_t)band * c.max_batch_frames * per;
+                memmove(base, base + (size_t)n * per, sizeof(float) * per * (size_t)left);
+            }
+        } else {
+            b->staged_kind[band] = 0;
         }
         b->staged[band] = left;
     }

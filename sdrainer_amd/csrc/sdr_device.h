@@ -85,6 +85,7 @@ hipError_t launch_listener_stop(ListenerSlot *slot, const uint16_t *morse, uint3
 hipError_t launch_set_debounce(ListenerSlot *slots, int n, int threshold, hipStream_t stream);
 hipError_t launch_cumulate(const float *spectrum, const float *carry_in, float *carry_out, float *cum_out, CumGeom g,
                            int n_slots, int n_bands, hipStream_t stream);
+hipError_t launch_unpack_be16(const uint8_t *raw, float *out, size_t n_values, hipStream_t stream);
 hipError_t launch_find_peaks(const float *cum, const sdr_frame_rec *recs, DevPeak *peaks, int *counts, PeakGeom g,
                              int n_chunks, int n_bands, hipStream_t stream);
 

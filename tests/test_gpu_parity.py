@@ -433,3 +433,42 @@ def test_detach_and_reattach_mid_stream(capi):
     assert np.array_equal(bank.read_keying_bits(0, b), out3["deb"][:, rb])
     assert np.array_equal(bank.read_decoder_state(0, b), ref.decoder_state(rb))
     bank.close()
+
+
+def test_kiwi_snd_payload_unpacked_on_device(capi):
+    """Source wire format: raw KiwiSDR SND payloads (17-byte header + big-endian int16 IQ)
+    are unpacked in HBM; the result is what the reference's decodeIQBytes + Receiver.run produce."""
+    n, rate, frames = 512, 12000, 120
+    rng = np.random.default_rng(12)
+    iq16 = rng.integers(-3000, 3000, size=(frames, 2 * n)).astype(np.int16)
+    t = np.arange(n)
+    tone = (12000 * np.exp(2j * np.pi * 40 * t / n))
+    iq16[:, 0::2] += tone.real.astype(np.int16)
+    iq16[:, 1::2] += tone.imag.astype(np.int16)
+    bank = capi.Bank(rate, n, max_batch_frames=128, max_listeners=2, trace=True)
+    ref = orc.Receiver(rate, n, 70)
+    b = (40 + n // 2) % n
+    bank.attach(0, b)
+    ref.attach(b)
+    # messages of 1, 2, 5 ... frames each, like the websocket delivers them
+    ref_iq, f = [], 0
+    for k in [1, 2, 5, 12, 40, 60]:
+        payload = bytes([0x01] + [7] * 16) + iq16[f:f + k].astype(">i2").tobytes()
+        assert bank.push_kiwi_snd(0, rate, payload) == capi.OK
+        ref_iq.append(orc.decode_iq_message(payload).reshape(k, 2 * n))
+        f += k
+    assert f == frames and bank.staged_frames(0) == frames
+    # contract errors: partial frame, wrong rate, mixing float frames into a raw batch
+    assert bank.push_kiwi_snd(0, rate, bytes(17) + bytes(10)) == capi.ERR_BAD_SIZE
+    assert bank.push_kiwi_snd(0, rate + 1, bytes(17) + bytes(4 * n)) == capi.ERR_BAD_RATE
+    assert bank.push_iq(0, rate, np.zeros(2 * n, np.float32)) == capi.ERR_STATE
+    assert bank.process_staged() == frames
+    out = ref.process(np.concatenate(ref_iq), want_spectrum=True)
+    for fr in (0, 57, frames - 1):
+        sp, psd = bank.read_spectrum(0, fr)
+        assert _bits_equal(sp, out["spectrum"][fr]) and _bits_equal(psd, out["psd"][fr])
+    _assert_records_equal(bank.read_frame_records(0), out["frames"])
+    assert np.array_equal(bank.read_keying_bits(0, 0), out["deb"][:, 0])
+    # afterwards the band accepts float frames again
+    assert bank.push_iq(0, rate, np.zeros(2 * n, np.float32) + 1e-3) == capi.OK
+    bank.close()

@@ -337,3 +337,13 @@ def test_fft_phase_functions_match_oracle_bit_for_bit(tmp_path):
     out = subprocess.run([exe, orc.build()], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count(": 0 mismatches") == 6
+
+
+def test_kiwi_iq_bytes_decode():
+    # kiwi/client.go:298-308: big-endian int16 / 32767 in float32, after a 17-byte header
+    vals = np.array([0, 1, -1, 32767, -32768, 12345, -12345, 256, 255], np.int16)
+    payload = bytes(range(17)) + vals.astype(">i2").tobytes()
+    got = orc.decode_iq_message(payload)
+    want = vals.astype(np.float32) / np.float32(32767)
+    assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert got[3] == 1.0 and got[4] < -1.0  # -32768/32767: the reference does not clamp
