@@ -142,14 +142,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # rehearsal knobs (a one-GPU box cannot host two RCCL ranks): SDR_DIST_BACKEND=gloo runs the
+    # collectives on the CPU, SDR_FORCE_DEVICE pins every rank to one GPU
+    backend = os.environ.get("SDR_DIST_BACKEND", "nccl")
+    if "SDR_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["SDR_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
     dist = None
     if world > 1:
         import torch.distributed as dist  # noqa: F811
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from sdrainer_amd import capi, sharding, synth
 
@@ -160,7 +169,7 @@ def main():
     # the one genuinely shared piece of state: configuration / thresholds, broadcast from rank 0
     shared = sharding.SharedConfig(sample_rate=rate, block_size=n, edge_width=edge, peak_threshold=15.0,
                                    signal_debounce=1, max_listeners=max(tones, 1))
-    shared = sharding.broadcast_config(shared, dist, dev)
+    shared = sharding.broadcast_config(shared, dist, coll_dev)
     my_bands = sharding.bands_of_rank(bands_per_gpu * world, world, rank)
     assert len(my_bands) == bands_per_gpu
 
@@ -205,7 +214,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
