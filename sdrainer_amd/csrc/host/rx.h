@@ -22,6 +22,7 @@
 
 #include "../../../include/sdrainer_hip.h"
 #include "frequency_mapping.h"
+#include "text_processor.h"
 
 namespace rx {
 
@@ -48,11 +49,14 @@ constexpr double kDefaultAttachmentTimeout = 120.0;
 
 using Peak = sdr_peak;  // dsp.Peak[float32,int] (dsp/fft.go:179-188)
 
-// rx/rx.go:11-17 (the three callsign callbacks belong to the out-of-scope TextProcessor)
+// rx/rx.go:11-17
 struct Reporter {
     virtual ~Reporter() = default;
     virtual void ListenerActivated(const std::string &listener, int64_t frequency) = 0;
     virtual void ListenerDeactivated(const std::string &listener, int64_t frequency) = 0;
+    virtual void CallsignDecoded(const std::string &, const std::string &, int64_t, int, int) {}
+    virtual void CallsignSpotted(const std::string &, const std::string &, int64_t) {}
+    virtual void SpotTimeout(const std::string &, const std::string &, int64_t) {}
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -194,12 +198,15 @@ private:
     std::vector<std::string> ids_;
 };
 
-class Listener {  // :19-148
+class Listener : private CallsignReporter {  // :19-148
 public:
     Listener(std::string id, const Clock *clock, Reporter *reporter)
-        : id_(std::move(id)), clock_(clock), reporter_(reporter), lastWrite_(clock ? clock->Now() : 0)
+        : id_(std::move(id)), clock_(clock), reporter_(reporter),
+          textProcessor_([clock] { return clock ? clock->Now() : 0.0; }, this)
     {
     }
+    Listener(const Listener &) = delete;
+    Listener &operator=(const Listener &) = delete;
     const std::string &ID() const { return id_; }
     void SetSilenceTimeout(double s) { silenceTimeout_ = s; }
     void SetAttachmentTimeout(double s) { attachmentTimeout_ = s; }
@@ -210,7 +217,7 @@ public:
         attached_ = true;
         device_id_ = device_id;
         lastAttach_ = clock_->Now();
-        lastWrite_ = clock_->Now();  // textProcessor.Restart(), rx/text_processor.go:175-182
+        textProcessor_.Restart();  // :89
         text_.clear();
         if (reporter_)
             reporter_->ListenerActivated(id_, peak_.signal_frequency);
@@ -229,26 +236,59 @@ public:
     bool TimeoutExceeded() const  // :126-136
     {
         const double now = clock_->Now();
-        return (now - lastAttach_ > attachmentTimeout_) || (now - lastWrite_ > silenceTimeout_);
+        return (now - lastAttach_ > attachmentTimeout_) || (now - textProcessor_.LastWrite() > silenceTimeout_);
     }
-    // The io.Writer the GPU decoder's runes arrive at (TextProcessor.Write, rx/text_processor.go:208-221)
+    void CheckWriteTimeout() { textProcessor_.CheckWriteTimeout(); }  // :138-140
+    // The io.Writer the GPU decoder's runes arrive at (TextProcessor.Write, rx/text_processor.go:202-216);
+    // `text_` plays the part of the reference's `out` writer.
     void Write(const std::string &utf8)
     {
-        if (utf8.empty())
-            return;
-        lastWrite_ = clock_->Now();
+        // the decoder writes one rune per call (cw/decode.go:352); keep that granularity, the window's
+        // one-FindNext-per-Write cadence depends on it
+        for (size_t i = 0; i < utf8.size();) {
+            size_t len = 1;
+            const unsigned char c = (unsigned char)utf8[i];
+            if (c >= 0xF0)
+                len = 4;
+            else if (c >= 0xE0)
+                len = 3;
+            else if (c >= 0xC0)
+                len = 2;
+            len = std::min(len, utf8.size() - i);
+            textProcessor_.Write(utf8.substr(i, len));
+            i += len;
+        }
         text_ += utf8;
     }
     const std::string &Text() const { return text_; }
+    TextProcessor &Processor() { return textProcessor_; }
 
 private:
+    // :70-83 — the text processor's callbacks, forwarded with the listener's id and signal frequency
+    void CallsignDecoded(const std::string &callsign, int count, int weight) override
+    {
+        if (reporter_)
+            reporter_->CallsignDecoded(id_, callsign, peak_.signal_frequency, count, weight);
+    }
+    void CallsignSpotted(const std::string &callsign) override
+    {
+        if (reporter_)
+            reporter_->CallsignSpotted(id_, callsign, peak_.signal_frequency);
+    }
+    void SpotTimeout(const std::string &callsign) override
+    {
+        if (reporter_)
+            reporter_->SpotTimeout(id_, callsign, peak_.signal_frequency);
+    }
+
     std::string id_;
     const Clock *clock_;
     Reporter *reporter_;
+    TextProcessor textProcessor_;
     Peak peak_{};
     bool attached_ = false;
     int device_id_ = -1;
-    double lastAttach_ = 0, lastWrite_ = 0;
+    double lastAttach_ = 0;
     double silenceTimeout_ = kDefaultSilenceTimeout, attachmentTimeout_ = kDefaultAttachmentTimeout;
     std::string text_;
 };
@@ -457,6 +497,7 @@ public:
             framesProcessed_ += n;
             streamClock_.Set((double)framesProcessed_ * (double)blockSize_ / (double)sampleRate_);
             drainText();
+            housekeeping();
             checkTimeouts();
             if (hunting && sdr_last_batch_chunks(bank_) > 0)
                 discover(sdr_last_batch_chunks(bank_) - 1);
@@ -513,6 +554,21 @@ private:
             for (auto *rep : r->reporters_)
                 rep->ListenerDeactivated(l, f);
         }
+        void CallsignDecoded(const std::string &l, const std::string &c, int64_t f, int count, int weight) override
+        {
+            for (auto *rep : r->reporters_)
+                rep->CallsignDecoded(l, c, f, count, weight);
+        }
+        void CallsignSpotted(const std::string &l, const std::string &c, int64_t f) override
+        {
+            for (auto *rep : r->reporters_)
+                rep->CallsignSpotted(l, c, f);
+        }
+        void SpotTimeout(const std::string &l, const std::string &c, int64_t f) override
+        {
+            for (auto *rep : r->reporters_)
+                rep->SpotTimeout(l, c, f);
+        }
     };
     std::shared_ptr<Listener> newListener(const std::string &lid)  // :120-126
     {
@@ -541,6 +597,17 @@ private:
             if (sdr_read_text(bank_, 0, l->DeviceID(), buf, (int)sizeof buf, &nb) == SDR_OK && nb > 0)
                 l->Write(std::string(buf, (size_t)nb));
         }
+    }
+    void housekeeping()  // the cleanupTicker case, :359-363: once per second of clock time
+    {
+        const double now = clock_->Now();
+        if (now - lastCleanup_ < 1.0)
+            return;
+        lastCleanup_ = now;
+        for (auto &l : listeners_.Listeners())
+            l->CheckWriteTimeout();
+        if (peaks_)
+            peaks_->Cleanup();
     }
     void checkTimeouts()  // :396-402 (evaluated per processed segment instead of per frame)
     {
@@ -594,6 +661,7 @@ private:
     PeaksTable::RandFn rand_;
     ListenerPool listeners_;
     int64_t framesProcessed_ = 0;
+    double lastCleanup_ = 0;
     std::vector<Peak> lastPeaks_;
 };
 

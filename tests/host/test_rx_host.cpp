@@ -187,6 +187,20 @@ struct PrintReporter : rx::Reporter {
     std::vector<std::string> events;
     void ListenerActivated(const std::string &l, int64_t f) override { events.push_back("+" + l + "@" + std::to_string(f)); }
     void ListenerDeactivated(const std::string &l, int64_t f) override { events.push_back("-" + l + "@" + std::to_string(f)); }
+    // rx/rx.go:14-16
+    std::vector<std::string> callsigns;
+    void CallsignDecoded(const std::string &l, const std::string &c, int64_t f, int count, int weight) override
+    {
+        callsigns.push_back(l + " decoded " + c + " " + std::to_string(f) + " " + std::to_string(count) + " " + std::to_string(weight));
+    }
+    void CallsignSpotted(const std::string &l, const std::string &c, int64_t f) override
+    {
+        callsigns.push_back(l + " spotted " + c + " " + std::to_string(f));
+    }
+    void SpotTimeout(const std::string &l, const std::string &c, int64_t f) override
+    {
+        callsigns.push_back(l + " timeout " + c + " " + std::to_string(f));
+    }
 };
 
 static int run_strain(const char *path, int rate, int n, int frames, int pool)
@@ -228,6 +242,9 @@ static int run_strain(const char *path, int rate, int n, int frames, int pool)
     printf("{\"frames\": %lld, \"events\": [", (long long)r.FramesProcessed());
     for (size_t i = 0; i < rep.events.size(); i++)
         printf("%s\"%s\"", i ? ", " : "", rep.events[i].c_str());
+    printf("], \"callsigns\": [");
+    for (size_t i = 0; i < rep.callsigns.size(); i++)
+        printf("%s\"%s\"", i ? ", " : "", rep.callsigns[i].c_str());
     printf("], \"listeners\": [");
     bool first = true;
     for (auto &l : r.Listeners().Listeners()) {
@@ -242,6 +259,145 @@ static int run_strain(const char *path, int rate, int n, int frames, int pool)
     return 0;
 }
 
+
+// ---- rx/text_processor_test.go ---------------------------------------------------------------
+static void TestTextWindow_Write()  // :10-69
+{
+    struct Case {
+        const char *preset, *text, *expected;
+        int expectedN;
+        bool invalid;
+    } tt[] = {
+        {"", "", "", 0, false},
+        {"", "abc", "abc", 3, false},
+        {"123", "abc", "123abc", 3, false},
+        {"1234567", "abcdef", "1234567abc", 3, false},
+        {"1234567890", "abcdef", "1234567890", 0, true},
+    };
+    for (const Case &tc : tt) {
+        rx::TextWindow w(10);
+        w.Preset(tc.preset);
+        const int n = w.Write(tc.text);
+        CHECK((n < 0) == tc.invalid);
+        CHECK(std::max(n, 0) == tc.expectedN);
+        CHECK(w.String() == tc.expected);
+    }
+}
+
+static void TestTextWindow_Shift()  // :71-105
+{
+    rx::TextWindow w(10);
+    w.Shift();
+    CHECK(w.CurrentWindow() == 1 && w.String() == "");
+    CHECK(w.Write("1234") >= 0);
+    w.Shift();
+    CHECK(w.CurrentWindow() == 0 && w.String() == "1234");
+    CHECK(w.Write("123456") >= 0);
+    w.Shift();
+    CHECK(w.CurrentWindow() == 1 && w.String() == "23456");
+    CHECK(w.Write("abcdefg") >= 0);
+    w.Shift();
+    CHECK(w.CurrentWindow() == 0 && w.String() == "abcde");
+    CHECK(w.Write("fg") >= 0);
+    w.Shift();
+    CHECK(w.CurrentWindow() == 1 && w.String() == "cdefg");
+    w.Reset();
+    CHECK(w.CurrentWindow() == 0 && w.String() == "");
+}
+
+static void TestTextWindow_FindNext()  // :107-135
+{
+    rx::TextWindow w(10);
+    const std::regex aExp("a");
+    std::string out;
+    CHECK(!w.FindNext(aExp, true, &out));
+    CHECK(w.SearchPoint() == 0);
+    w.Write("abc");
+    CHECK(w.FindNext(aExp, true, &out));
+    CHECK(w.SearchPoint() == 1);
+    CHECK(!w.FindNext(aExp, true, &out));
+    CHECK(w.SearchPoint() == 1);
+    w.Write("1234567");
+    w.Shift();
+    CHECK(w.SearchPoint() == 0);
+    CHECK(w.String() == "34567");
+    w.Write("abc");
+    CHECK(w.FindNext(aExp, true, &out));
+    CHECK(w.SearchPoint() == 6);
+    w.Shift();
+    CHECK(w.SearchPoint() == 3);
+    CHECK(w.String() == "67abc");
+}
+
+static void TestTextWindow_FindNext_IncludeTail()  // :137-147
+{
+    rx::TextWindow w(10);
+    const std::regex abcExp("abc");
+    std::string out;
+    w.Write("12345abc");
+    CHECK(!w.FindNext(abcExp, false, &out));
+    CHECK(w.FindNext(abcExp, true, &out));
+    CHECK(out == "abc");
+}
+
+static void TestTextProcessor_CollectCallsign()  // :149-162
+{
+    rx::TextProcessor p([] { return 0.0; }, nullptr);
+    for (char c : std::string("cq cq cq de dl1abc dl1abc dl1abc pse k"))
+        p.Write(std::string(1, c));
+    CHECK(p.Count("DL1ABC") == 3);
+}
+
+static void TestTextProcessor_WriteTimeout()  // :164-179
+{
+    rx::TextProcessor p([] { return 0.0; }, nullptr);
+    for (char c : std::string("cq de dl1abc"))
+        p.Write(std::string(1, c));
+    CHECK(p.Count("DL1ABC") == 0);
+    p.WriteTimeout();
+    CHECK(p.Count("DL1ABC") == 1);
+}
+
+// `test_rx_host text`: replay a script from stdin through a TextProcessor and print its reporter
+// events, one per line.  Script lines: "W <text>" (written rune by rune), "B <text>" (one Write),
+// "A <seconds>" (advance the clock, then CheckWriteTimeout as the receiver's ticker does), "R" (Restart).
+static int run_text()
+{
+    struct Printer : rx::CallsignReporter {
+        void CallsignDecoded(const std::string &c, int count, int weight) override { printf("decoded %s %d %d\n", c.c_str(), count, weight); }
+        void CallsignSpotted(const std::string &c) override { printf("spotted %s\n", c.c_str()); }
+        void SpotTimeout(const std::string &c) override { printf("timeout %s\n", c.c_str()); }
+    } printer;
+    double now = 0;
+    rx::TextProcessor p([&now] { return now; }, &printer);
+    char line[65536];
+    while (fgets(line, sizeof line, stdin)) {
+        std::string s(line);
+        while (!s.empty() && (s.back() == '\n' || s.back() == '\r'))
+            s.pop_back();
+        if (s.empty())
+            continue;
+        const std::string arg = s.size() > 2 ? s.substr(2) : "";
+        switch (s[0]) {
+        case 'W':
+            for (char c : arg)
+                p.Write(std::string(1, c));
+            break;
+        case 'B':
+            p.Write(arg);
+            break;
+        case 'A':
+            now += atof(arg.c_str());
+            p.CheckWriteTimeout();
+            break;
+        case 'R':
+            p.Restart();
+            break;
+        }
+    }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc >= 2 && !strcmp(argv[1], "cpu")) {
@@ -253,11 +409,19 @@ int main(int argc, char **argv)
         TestPeaksTable_FindNext();
         TestListenerTimeouts();
         TestPeakCentering();
+        TestTextWindow_Write();
+        TestTextWindow_Shift();
+        TestTextWindow_FindNext();
+        TestTextWindow_FindNext_IncludeTail();
+        TestTextProcessor_CollectCallsign();
+        TestTextProcessor_WriteTimeout();
         printf("%s\n", failures ? "FAILED" : "ok");
         return failures ? 1 : 0;
     }
+    if (argc >= 2 && !strcmp(argv[1], "text"))
+        return run_text();
     if (argc >= 7 && !strcmp(argv[1], "strain"))
         return run_strain(argv[2], atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]));
-    fprintf(stderr, "usage: %s cpu | strain <iq.f32> <rate> <N> <frames> <pool>\n", argv[0]);
+    fprintf(stderr, "usage: %s cpu | text | strain <iq.f32> <rate> <N> <frames> <pool>\n", argv[0]);
     return 2;
 }

@@ -76,3 +76,39 @@ def test_strain_mode_receiver_against_oracle(exe, tmp_path):
         assert text == ref.text(lid)
         assert len(text) > 0
     assert got["events"] == [f"+rx{i + 1}@{a[2]}" for i, a in enumerate(attached)]
+
+
+@pytest.mark.gpu
+def test_strain_mode_spots_callsigns(exe, tmp_path):
+    """IQ in, spots out: the runes the GPU decoders emit go through rx::TextProcessor
+    (rx/text_processor.go) and reach the Reporter as CallsignDecoded / CallsignSpotted with the listener's
+    id and signal frequency (rx/listener.go:70-83).  Expected events: the text oracle fed with each
+    listener's text rune by rune, as cw/decode.go:352 writes it."""
+    from oracle import text_oracle
+    from sdrainer_amd import synth
+
+    rate, n, frames, pool, tones = 48000, 512, 4200, 2, 3
+    iq, bins, _ = synth.make_band(frames, rate, n, tones, seed=5)
+    path = tmp_path / "iq.f32"
+    iq.astype(np.float32).tofile(path)
+    out = subprocess.run([exe, "strain", str(path), str(rate), str(n), str(frames), str(pool)], capture_output=True,
+                         text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    got = json.loads(out.stdout)
+    assert got["frames"] == frames and len(got["listeners"]) == pool
+    spotted = 0
+    for l in got["listeners"]:
+        text = bytes(ord(ch) for ch in l["text"]).decode("utf-8")
+        p = text_oracle.TextProcessor()
+        for ch in text:
+            p.write(ch.encode("utf-8"))
+        want = []
+        for e in p.events:
+            if e[0] == "decoded":
+                want.append(f"{l['id']} decoded {e[1]} {l['frequency']} {e[2]} {e[3]}")
+            else:
+                want.append(f"{l['id']} {e[0]} {e[1]} {l['frequency']}")
+        mine = [c for c in got["callsigns"] if c.startswith(l["id"] + " ")]
+        assert mine == want
+        spotted += any(c == f"{l['id']} spotted DL1ABC {l['frequency']}" for c in mine)
+    assert spotted == pool
