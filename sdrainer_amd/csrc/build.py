@@ -18,6 +18,9 @@ HEADERS = ["sdr_device.h", "fft_f64.h", "gomath.h", "cw_decoder.h", "twiddles.h"
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
          "-DSDR_BUILD"]
+# k_fft_project: machine-LICM parks literal constants in VGPRs for the whole kernel; the FFT needs all 128
+# registers a 1024-thread workgroup leaves it, and four parked constants are four spilled data registers.
+EXTRA_FLAGS = {"k_fft_project.hip": ["-mllvm", "-disable-machine-licm"]}
 
 
 def hipcc() -> str:
@@ -45,7 +48,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if not os.path.exists(src):
             continue
         obj = os.path.join(HERE, s.replace(".hip", ".o"))
-        cmd = [cc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [cc] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

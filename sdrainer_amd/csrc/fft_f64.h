@@ -36,10 +36,14 @@ struct Plan {
     static constexpr int LOGR = (LOGN >= 10) ? 4 : 3;
     static constexpr int R = 1 << LOGR;                       // points per thread
     static constexpr int T = N / R;                           // threads per frame
+    static constexpr int LOGT = LOGN - LOGR;
+    static constexpr int LOGL = 6;                            // lane bits of a thread id (64-wide waves)
+    static constexpr int WB = LOGT - LOGL;                    // wave bits of a thread id
     static constexpr int NPASS = (LOGN + LOGR - 1) / LOGR;    // register passes
     static constexpr int LAST_LOG = LOGN - (NPASS - 1) * LOGR;
     static constexpr bool SPLIT = (N * 16 > 65536);           // exchange re / im separately through LDS
     static constexpr int LDS_BYTES = SPLIT ? N * 8 : N * 16;
+    static_assert(LOGT >= LOGL, "a frame needs at least one full wave");
 
     SDR_HD static constexpr int pass_log(int p) { return p < NPASS - 1 ? LOGR : LAST_LOG; }
     // offset (in entries) of pass p's twiddle block: block p holds (2^pass_log(p) - 1) * R^p entries
@@ -51,6 +55,10 @@ struct Plan {
         return o;
     }
     static constexpr int TW_TOTAL = tw_offset(NPASS);
+    // Exchange e (between pass e and e+1) moves data between waves only when the set of index bits
+    // held in the wave id changes; that happens once, after pass 1 (see make_layout).  Every other
+    // exchange stays inside a wave and needs no workgroup barrier.
+    SDR_HD static constexpr bool cross_wave(int e) { return WB > 0 && e == 1; }
 };
 
 SDR_HD inline unsigned brev_bits(unsigned v, int bits)
@@ -63,31 +71,158 @@ SDR_HD inline unsigned brev_bits(unsigned v, int bits)
     return r;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Who holds what.  During pass P the LOGN bits of an element's index i (in the bit-reversed work
+// array) are spread over the register slot (LOGR bits), the lane (6 bits) and the wave (WB bits):
+//
+//   slot : the bits the pass's stages pair up, [4P, 4P+pass_log); a short last pass fills the slot
+//          with the bits just below them
+//   wave : passes 0,1: bits [8, 8+WB); later passes: the WB bits below the last pass's slot bits,
+//          i.e. [8-WB, 8) (one lower when the last pass borrowed bit 7)
+//   lane : everything else.  Pass 0 orders them downwards (lane bit 0 = top index bit = lowest
+//          sample-number bit, so neighbouring lanes load neighbouring samples); later passes
+//          upwards (lane bits 0-3 = index bits 0-3: coalesced twiddle loads and output stores).
+//
+// With that choice passes 0 and 1 share their wave bits, and so do passes 2 and 3: only the exchange
+// after pass 1 crosses waves.
+// ---------------------------------------------------------------------------------------------
+struct Layout {
+    int sbit[4];   // index bit held by slot bit j
+    int tbit[10];  // index bit held by thread-id bit j (lanes first, then waves)
+};
+
+template <int LOGN>
+SDR_HD constexpr Layout make_layout(int P)
+{
+    using PL = Plan<LOGN>;
+    Layout L{};
+    bool used[16] = {};
+    const int plog = PL::pass_log(P);
+    const int base = P * PL::LOGR;
+    for (int j = 0; j < PL::LOGR; j++) {
+        L.sbit[j] = j < plog ? base + j : base - (PL::LOGR - plog) + (j - plog);
+        used[L.sbit[j]] = true;
+    }
+    const int wz_hi = (PL::NPASS == 3) ? 2 * PL::LOGR - (PL::LOGR - PL::LAST_LOG) : 2 * PL::LOGR;
+    const int wlo = (P <= 1) ? 2 * PL::LOGR : wz_hi - PL::WB;
+    for (int j = 0; j < PL::WB; j++) {
+        L.tbit[PL::LOGL + j] = wlo + j;
+        used[wlo + j] = true;
+    }
+    int k = 0;
+    if (P == 0) {
+        for (int b = LOGN - 1; b >= 0; b--)
+            if (!used[b])
+                L.tbit[k++] = b;
+    } else {
+        for (int b = 0; b < LOGN; b++)
+            if (!used[b])
+                L.tbit[k++] = b;
+    }
+    return L;
+}
+
+// index bits contributed by the thread id / by the register slot during pass P
+template <int LOGN, int P>
+SDR_HD inline int thread_part(int t)
+{
+    constexpr Layout L = make_layout<LOGN>(P);
+    int r = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int j = 0; j < Plan<LOGN>::LOGT; j++)
+        r |= ((t >> j) & 1) << L.tbit[j];
+    return r;
+}
+template <int LOGN, int P>
+SDR_HD constexpr int slot_part(int s)
+{
+    constexpr Layout L = make_layout<LOGN>(P);
+    int r = 0;
+    for (int j = 0; j < Plan<LOGN>::LOGR; j++)
+        r |= ((s >> j) & 1) << L.sbit[j];
+    return r;
+}
+
 // Index (in the bit-reversed work array r[]) of register slot (u, m) of thread t during pass P.
 template <int LOGN, int P>
 SDR_HD inline int elem_index(int t, int u, int m)
 {
-    using PL = Plan<LOGN>;
-    if (P == 0)
-        return (int)(brev_bits((unsigned)t, LOGN - PL::LOGR) << PL::LOGR) + m;
-    constexpr int SH = P * PL::LOGR;
-    constexpr int PLOG = PL::pass_log(P);
-    const int g = t + PL::T * u;
-    const int hi = g >> SH;
-    const int lo = g & ((1 << SH) - 1);
-    return (hi << (SH + PLOG)) + (m << SH) + lo;
+    return thread_part<LOGN, P>(t) | slot_part<LOGN, P>((u << Plan<LOGN>::pass_log(P)) + m);
 }
 
-// LDS swizzle of exchange E (between pass E and E+1).  Only the first exchange needs one: there a
-// thread writes 16 consecutive doubles (stride-16 across lanes) and consecutive lanes own groups that
-// differ in their TOP bits (g = bitrev(t)), so the low LOGR bits are XORed with the top LOGR bits.
-template <int LOGN, int E>
-SDR_HD inline int swz(int i)
+// ---------------------------------------------------------------------------------------------
+// LDS address (in doubles) of index i during exchange E: a bit permutation of i with a 4-bit XOR
+// swizzle, i.e. linear over GF(2), so addr(thread_part | slot_part) = addr(thread_part) ^ addr(slot_part)
+// and the slot half is a compile-time constant.  Chosen per exchange so that neither side has bank
+// conflicts (MI355X: a ds_write_b64 is served in groups of 16 consecutive lanes over 32 banks, a
+// ds_read_b64 in groups of 32 lanes over 64 banks):
+//   address bits 0-3 <- the index bits in the reader's lane bits 0-3, XORed with the index bits in the
+//                       writer's lane bits 0-3 where those differ (exchange 0 is a transpose: the reader's
+//                       low lane bits are the writer's slot bits)
+//   address bit 4    <- the index bit in the reader's lane bit 4
+//   the rest upwards.
+// ---------------------------------------------------------------------------------------------
+struct AddrMap {
+    int abit[14];  // address bit k <- index bit abit[k]
+    int xbit[4];   // address bit k (k < 4) additionally XORs index bit xbit[k] (-1: none)
+};
+
+// A wave-local exchange also puts the wave's bits at the top of the address: wave w then owns the
+// words [w * 2^(LOGN-WB), (w+1) * 2^(LOGN-WB)) in every wave-local exchange, whichever index bits its
+// id stands for at the time, so consecutive wave-local exchanges (also across frames of a persistent
+// workgroup) need no barrier between them.
+template <int LOGN>
+SDR_HD constexpr AddrMap make_addr(int E)
 {
-    return E == 0 ? (i ^ (i >> (LOGN - Plan<LOGN>::LOGR))) : i;
+    using PL = Plan<LOGN>;
+    AddrMap A{};
+    const Layout W = make_layout<LOGN>(E), Rd = make_layout<LOGN>(E + 1);
+    bool used[16] = {};
+    for (int k = 0; k < 5; k++) {
+        A.abit[k] = Rd.tbit[k];
+        used[Rd.tbit[k]] = true;
+    }
+    for (int k = 0; k < 4; k++) {
+        bool in_reader_low = false;
+        for (int j = 0; j < 4; j++)
+            in_reader_low = in_reader_low || (W.tbit[k] == Rd.tbit[j]);
+        A.xbit[k] = in_reader_low ? -1 : W.tbit[k];
+    }
+    if (!PL::cross_wave(E))
+        for (int j = 0; j < PL::WB; j++) {
+            A.abit[LOGN - PL::WB + j] = W.tbit[PL::LOGL + j];
+            used[W.tbit[PL::LOGL + j]] = true;
+        }
+    int k = 5;
+    for (int b = 0; b < LOGN; b++)
+        if (!used[b])
+            A.abit[k++] = b;
+    return A;
 }
 
-// Pass 0 input: slot m <- x[bitrev_LOGR(m) * T + t]  (coalesced across t), widened to float64
+template <int LOGN, int E>
+SDR_HD constexpr int lds_addr(int i)
+{
+    constexpr AddrMap A = make_addr<LOGN>(E);
+    int r = 0;
+    for (int k = 0; k < LOGN; k++)
+        r |= ((i >> A.abit[k]) & 1) << k;
+    for (int k = 0; k < 4; k++)
+        if (A.xbit[k] >= 0)
+            r ^= ((i >> A.xbit[k]) & 1) << k;
+    return r;
+}
+
+// Sample number (natural order) held in slot m of thread t at the start of pass 0.
+template <int LOGN>
+SDR_HD inline int input_sample(int t, int m)
+{
+    return (int)brev_bits((unsigned)elem_index<LOGN, 0>(t, 0, m), LOGN);
+}
+
+// Pass 0 input: slot m <- x[input_sample(t, m)], widened to float64
 // (dsp/fft.go:59-69 setSamplesFromIQ).
 template <int LOGN>
 SDR_HD inline void load_input(const float *iq, int t, double *xr, double *xi)
@@ -97,8 +232,7 @@ SDR_HD inline void load_input(const float *iq, int t, double *xr, double *xi)
 #pragma unroll
 #endif
     for (int m = 0; m < PL::R; m++) {
-        const int k = (int)brev_bits((unsigned)m, PL::LOGR);
-        const int n = k * PL::T + t;
+        const int n = input_sample<LOGN>(t, m);
         xr[m] = (double)iq[2 * n];
         xi[m] = (double)iq[2 * n + 1];
     }
@@ -119,7 +253,7 @@ SDR_HD inline void butterfly_pass(double *xr, double *xi, int t, const cplx *tw)
 #pragma unroll
 #endif
     for (int u = 0; u < G; u++) {
-        const int lo = (P == 0) ? 0 : ((t + PL::T * u) & (S - 1));
+        const int lo = (P == 0) ? 0 : (elem_index<LOGN, P>(t, u, 0) & (S - 1));
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
@@ -177,17 +311,12 @@ template <int LOGN, int E>
 SDR_HD inline void exchange_write(const double *x, int t, double *lds)
 {
     using PL = Plan<LOGN>;
-    constexpr int RP = 1 << PL::pass_log(E);
-    constexpr int G = PL::R / RP;
+    const int base = lds_addr<LOGN, E>(thread_part<LOGN, E>(t));
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (int u = 0; u < G; u++)
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-        for (int m = 0; m < RP; m++)
-            lds[swz<LOGN, E>(elem_index<LOGN, E>(t, u, m))] = x[u * RP + m];
+    for (int s = 0; s < PL::R; s++)
+        lds[base ^ lds_addr<LOGN, E>(slot_part<LOGN, E>(s))] = x[s];
 }
 
 // Exchange E, read side: gather the slots of pass E+1.
@@ -195,17 +324,12 @@ template <int LOGN, int E>
 SDR_HD inline void exchange_read(double *x, int t, const double *lds)
 {
     using PL = Plan<LOGN>;
-    constexpr int RP = 1 << PL::pass_log(E + 1);
-    constexpr int G = PL::R / RP;
+    const int base = lds_addr<LOGN, E>(thread_part<LOGN, E + 1>(t));
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (int u = 0; u < G; u++)
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-        for (int m = 0; m < RP; m++)
-            x[u * RP + m] = lds[swz<LOGN, E>(elem_index<LOGN, E + 1>(t, u, m))];
+    for (int s = 0; s < PL::R; s++)
+        x[s] = lds[base ^ lds_addr<LOGN, E>(slot_part<LOGN, E + 1>(s))];
 }
 
 // Natural-order DFT bin held in register slot s = u*RP+m after the last pass.

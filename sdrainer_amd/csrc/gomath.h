@@ -101,6 +101,17 @@ struct LogTabEntry {
 constexpr int kLogTabSize = 64;
 constexpr double kDbGuard = 1e-10;
 
+// On the device the 64-bit polynomial constants are re-made in SGPRs at every use: left to itself the
+// compiler hoists them out of the caller's loops into VGPR pairs that stay alive through the whole FFT
+// (which needs every register it can get) and end up spilled.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SDR_SGPR_CONST(name, value) \
+    double name = (value);          \
+    asm volatile("" : "+s"(name))
+#else
+#define SDR_SGPR_CONST(name, value) const double name = (value)
+#endif
+
 // y ~= 10*log10(v) for a normal, positive, finite v
 SDR_HD inline double db_fast_y(double v, const LogTabEntry *tab)
 {
@@ -113,16 +124,21 @@ SDR_HD inline double db_fast_y(double v, const LogTabEntry *tab)
     __builtin_memcpy(&m, &mbits, sizeof m);
     const double r = __builtin_fma(m, tab[idx].inv_c, -1.0);  // |r| <= 1/128
     // log1p(r) = r - r^2/2 + r^3/3 - r^4/4 + r^5/5 - r^6/6 (+ O(r^7) < 3e-16)
-    double p = -1.0 / 6.0;
-    p = __builtin_fma(p, r, 1.0 / 5.0);
+    // (first step as a separate multiply and add: one 64-bit constant per instruction, so both can sit in
+    // SGPRs instead of a VGPR pair that would stay alive across the whole kernel)
+    SDR_SGPR_CONST(c6, -1.0 / 6.0);
+    SDR_SGPR_CONST(c5, 1.0 / 5.0);
+    SDR_SGPR_CONST(c3, 1.0 / 3.0);
+    double p = r * c6 + c5;
     p = __builtin_fma(p, r, -1.0 / 4.0);
-    p = __builtin_fma(p, r, 1.0 / 3.0);
+    p = __builtin_fma(p, r, c3);
     p = __builtin_fma(p, r, -1.0 / 2.0);
     p = __builtin_fma(p, r, 1.0);
     const double ln_m = __builtin_fma(p, r, tab[idx].ln_c);
-    const double TenLog10Of2 = 3.01029995663981195213738894724493027;  // 10 * log10(2)
-    const double TenOverLn10 = 4.34294481903251827651128918916605082;  // 10 / ln(10)
-    return __builtin_fma((double)(be - 1023), TenLog10Of2, TenOverLn10 * ln_m);
+    SDR_SGPR_CONST(TenLog10Of2, 3.01029995663981195213738894724493027);  // 10 * log10(2)
+    SDR_SGPR_CONST(TenOverLn10, 4.34294481903251827651128918916605082);  // 10 / ln(10)
+    const double scaled = TenOverLn10 * ln_m;
+    return __builtin_fma((double)(be - 1023), TenLog10Of2, scaled);
 }
 
 SDR_HD inline bool psd_value_in_db_fast(float psd, double inv_n2, const LogTabEntry *tab, float *out)

@@ -8,39 +8,144 @@
 #include "gomath.h"
 #include "sdr_device.h"
 
+#if !defined(SDR_FFT_PREFETCH_DIST)
+#define SDR_FFT_PREFETCH_DIST 0
+#endif
+
 namespace sdr {
+
+// Development aid (tools/fft_trace.hip): per-wave time stamps of one workgroup's phases.
+#if defined(SDR_FFT_TRACE)
+#define SDR_STAMP(k)                                                                      \
+    do {                                                                                  \
+        if (blockIdx.x == SDR_FFT_TRACE && (threadIdx.x & 63) == 0)                       \
+            g_fft_trace[threadIdx.x >> 6][k] = wall_clock64();                            \
+    } while (0)
+#else
+#define SDR_STAMP(k) \
+    do {             \
+    } while (0)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // k_fft_project  (dsp/fft.go:23-37 IQToSpectrumAndPSD + rx/receiver.go:376-378 projection closure)
 // ---------------------------------------------------------------------------------------------
+// Orders one wave's LDS stores before its later LDS loads (and the reverse) without a workgroup
+// barrier: a wave's DS instructions execute in issue order, so the fences only pin the compiler.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int LOGN, int P>
 __device__ __forceinline__ void run_passes(double (&xr)[fft64::Plan<LOGN>::R], double (&xi)[fft64::Plan<LOGN>::R],
                                            int t, const fft64::cplx *__restrict__ tw, double *lds)
 {
     using PL = fft64::Plan<LOGN>;
+#if !(defined(SDR_ABLATE) && (SDR_ABLATE == 5))
     fft64::butterfly_pass<LOGN, P>(xr, xi, t, tw);
+#endif
+    SDR_STAMP(2 + 2 * P);
     if constexpr (P < PL::NPASS - 1) {
-        if constexpr (P > 0)
-            __syncthreads();  // everyone is done reading the previous exchange
+        // A wave-local exchange (fft_f64.h make_layout) only touches LDS words of the wave's own
+        // elements: no workgroup barrier, the waves drift apart and one wave's exchange overlaps the
+        // others' butterflies.  The single cross-wave exchange is fenced by barriers on both sides.
+        constexpr bool CROSS = PL::cross_wave(P);
+        auto sync = [] {
+            if constexpr (CROSS)
+                __syncthreads();
+            else
+                wave_sync();
+        };
+        if constexpr (CROSS)
+            __syncthreads();  // every wave is done with the words of its previous wave-local exchange
+#if defined(SDR_ABLATE) && (SDR_ABLATE == 2)
+        if (t < 0)  // timing-only build: no exchanges
+#endif
         if constexpr (PL::SPLIT) {
             fft64::exchange_write<LOGN, P>(xr, t, lds);
-            __syncthreads();
+            sync();
             fft64::exchange_read<LOGN, P>(xr, t, lds);
-            __syncthreads();
+            sync();
             fft64::exchange_write<LOGN, P>(xi, t, lds);
-            __syncthreads();
+            sync();
             fft64::exchange_read<LOGN, P>(xi, t, lds);
         } else {
             fft64::exchange_write<LOGN, P>(xr, t, lds);
             fft64::exchange_write<LOGN, P>(xi, t, lds + PL::N);
-            __syncthreads();
+            sync();
             fft64::exchange_read<LOGN, P>(xr, t, lds);
             fft64::exchange_read<LOGN, P>(xi, t, lds + PL::N);
         }
+        if constexpr (P + 1 < PL::NPASS - 1)
+            sync();  // reads done before the next exchange's writes (other waves' words if CROSS)
+        SDR_STAMP(3 + 2 * P);
         run_passes<LOGN, P + 1>(xr, xi, t, tw, lds);
     }
 }
 
+// Epilogue (dsp/fft.go:54-57 fftshift, :71-73 PSD[float32], :79-81 MagnitudeIndB, rx/receiver.go:377
+// +dBmShift).  The certified shortcut (gomath.h) settles all but about 2 values in 10^4; the rest are
+// redone with the literal Go algorithm in a rolled loop that re-reads the PSD value just stored, so the
+// long literal path exists once and holds no registers while the slots stream through.
+// `after_slot(s)` lets the persistent kernel slip its prefetch between slots.
+template <int LOGN, typename F>
+__device__ __forceinline__ void project_and_store(const double (&xr)[fft64::Plan<LOGN>::R],
+                                                  const double (&xi)[fft64::Plan<LOGN>::R], int t, float *__restrict__ sp,
+                                                  float *__restrict__ pd, double inv_n2,
+                                                  const gomath::LogTabEntry *ltab, F after_slot)
+{
+    using PL = fft64::Plan<LOGN>;
+    unsigned redo = 0;
+    const int tp = fft64::thread_part<LOGN, PL::NPASS - 1>(t);
+#pragma unroll
+    for (int s = 0; s < PL::R; s++) {
+        const int i = tp | fft64::slot_part<LOGN, PL::NPASS - 1>(s);
+        const int k = (i + PL::N / 2) & (PL::N - 1);
+        const float p = (float)(xr[s] * xr[s] + xi[s] * xi[s]);
+#if defined(SDR_ABLATE) && (SDR_ABLATE == 6 || SDR_ABLATE == 7)
+        float db = 0.0f;  // timing-only build: (almost) no stores
+        if (!gomath::psd_value_in_db_fast(p, inv_n2, ltab, &db))
+            redo |= 1u << s;
+        if (db == 1234.5f) {
+            pd[k] = p;
+            sp[k] = db;
+        }
+#elif defined(SDR_FFT_NT) && (SDR_FFT_NT & 2)
+        __builtin_nontemporal_store(p, pd + k);
+        float db = 0.0f;
+        if (!gomath::psd_value_in_db_fast(p, inv_n2, ltab, &db))
+            redo |= 1u << s;
+        __builtin_nontemporal_store(db + 120.0f, sp + k);
+#else
+        pd[k] = p;
+        float db = 0.0f;
+        if (!gomath::psd_value_in_db_fast(p, inv_n2, ltab, &db))
+            redo |= 1u << s;
+        sp[k] = db + 120.0f;
+#endif
+        after_slot(s);
+    }
+    while (redo) {
+        const int s = __builtin_ctz(redo);
+        redo &= redo - 1;
+        int sl = 0;
+        constexpr fft64::Layout L = fft64::make_layout<LOGN>(PL::NPASS - 1);
+#pragma unroll
+        for (int j = 0; j < PL::LOGR; j++)
+            sl |= ((s >> j) & 1) << L.sbit[j];
+        const int k = ((tp | sl) + PL::N / 2) & (PL::N - 1);
+        const float p = __builtin_nontemporal_load(pd + k);  // this thread's own store, re-read
+        sp[k] = gomath::psd_value_in_db(p, inv_n2) + 120.0f;
+    }
+}
+
+// One workgroup per frame.  (A persistent variant - the grid sized to the chip, each workgroup walking
+// over frames, the next frame's samples prefetched into the registers the projection frees, workgroups
+// started staggered or not - measured 5 % slower at N = 16384: 0.223 against 0.212 ms for 2048 frames,
+// and it keeps the other pipeline stages off the CUs: 0.46 against 0.36 ms per pipelined step.)
 template <int LOGN>
 __global__ __launch_bounds__(fft64::Plan<LOGN>::T) void k_fft_project(const float *__restrict__ iq,
                                                                       const fft64::cplx *__restrict__ tw,
@@ -52,39 +157,94 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T) void k_fft_project(const floa
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *lds = reinterpret_cast<double *>(smem);
     // the 64-entry table of the certified fast dB path (gomath.h) follows the twiddles in HBM and sits
-    // behind the exchange area in LDS; the exchanges' barriers publish it long before the epilogue
+    // behind the exchange area in LDS; the cross-wave exchange's barriers publish it long before the
+    // epilogue (a single-wave frame has none: it gets its own)
     gomath::LogTabEntry *ltab = reinterpret_cast<gomath::LogTabEntry *>(smem + PL::LDS_BYTES);
     const int t = threadIdx.x;
+    SDR_STAMP(0);
+#if defined(SDR_FFT_PRIO)
+    {
+        const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+        const int pr = SDR_FFT_PRIO == 1 ? (w >> 2) & 3 : w & 3;
+        if (pr == 1)
+            __builtin_amdgcn_s_setprio(1);
+        else if (pr == 2)
+            __builtin_amdgcn_s_setprio(2);
+        else if (pr == 3)
+            __builtin_amdgcn_s_setprio(3);
+    }
+#endif
     if (t < gomath::kLogTabSize)
         ltab[t] = reinterpret_cast<const gomath::LogTabEntry *>(tw + PL::TW_TOTAL)[t];
+    if constexpr (PL::WB == 0)
+        __syncthreads();
     const size_t in_frame = (size_t)blockIdx.y * in_stride + blockIdx.x;
     const size_t out_frame = (size_t)blockIdx.y * out_stride + blockIdx.x;
+#if defined(SDR_ABLATE) && (SDR_ABLATE == 8)
+    const float2 *x = reinterpret_cast<const float2 *>(iq) + (in_frame & 15) * PL::N;  // timing-only: 16 frames, L2-resident
+#elif defined(SDR_ABLATE) && (SDR_ABLATE == 9)
+    const float2 *x = reinterpret_cast<const float2 *>(iq) + ((in_frame * 7) & 2047) * PL::N;  // timing-only: scattered order
+#else
     const float2 *x = reinterpret_cast<const float2 *>(iq) + in_frame * PL::N;
+#endif
 
     double xr[PL::R], xi[PL::R];
 #pragma unroll
     for (int m = 0; m < PL::R; m++) {
-        // slot m <- x[bitrev(m) * T + t]: 512-byte contiguous segments per wave (fft_f64.h load_input)
-        const int k = (int)fft64::brev_bits((unsigned)m, PL::LOGR);
-        const float2 v = x[k * PL::T + t];
+        // four neighbouring lanes read 32 contiguous bytes (fft_f64.h make_layout, pass 0)
+#if defined(SDR_ABLATE) && (SDR_ABLATE == 1 || SDR_ABLATE == 7)
+        const float2 v = make_float2(1e-3f * (float)(t + m), 0.5f);  // timing-only build: no input loads
+#else
+#if defined(SDR_FFT_NT) && (SDR_FFT_NT & 1)
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const v2f nv = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(x + fft64::input_sample<LOGN>(t, m)));
+        const float2 v = make_float2(nv.x, nv.y);
+#else
+        const float2 v = x[fft64::input_sample<LOGN>(t, m)];
+#endif
+#endif
         xr[m] = (double)v.x;
         xi[m] = (double)v.y;
     }
+#if defined(SDR_FFT_TRACE)
+    asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+    SDR_STAMP(12);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    SDR_STAMP(13);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    SDR_STAMP(1);
+#if SDR_FFT_PREFETCH_DIST > 0 && !defined(SDR_FFT_TRACE)
+    // Warm L2 for a later workgroup: every thread touches one 128-byte line of the frame
+    // SDR_FFT_PREFETCH_DIST ahead (a multiple of 8, so it is dispatched to this XCD and its L2), as an
+    // LDS-DMA load of 4 bytes into a dump area: no register is held and nothing ever waits for it.  A
+    // frame read from HBM cold costs its workgroup about 4 us before the first butterfly; nothing else
+    // can cover that time on a CU that holds a single workgroup.
+    if (blockIdx.x + SDR_FFT_PREFETCH_DIST < gridDim.x) {
+        const float *ahead = reinterpret_cast<const float *>(x + (size_t)SDR_FFT_PREFETCH_DIST * PL::N) + t * 32;
+        __shared__ float dump[PL::T];
+        __builtin_amdgcn_global_load_lds(ahead, dump + (t & ~63), 4, 0, 0);
+    }
+#endif
     run_passes<LOGN, 0>(xr, xi, t, tw, lds);
 
     float *sp = spectrum + out_frame * PL::N;
     float *pd = psd + out_frame * PL::N;
+#if defined(SDR_ABLATE) && (SDR_ABLATE == 4)
 #pragma unroll
-    for (int s = 0; s < PL::R; s++) {
-        const int i = fft64::output_bin<LOGN>(t, s);
-        const int k = (i + PL::N / 2) & (PL::N - 1);                  // dsp/fft.go:54-57
-        const float p = (float)(xr[s] * xr[s] + xi[s] * xi[s]);       // dsp/fft.go:71-73 PSD[float32]
-        pd[k] = p;
-        float db;                                                     // dsp/fft.go:79-81 MagnitudeIndB
-        if (!gomath::psd_value_in_db_fast(p, inv_n2, ltab, &db))      // certified shortcut, else the literal
-            db = gomath::psd_value_in_db(p, inv_n2);                  // Go algorithm (about 2 values in 10^4)
-        sp[k] = db + 120.0f;                                          // + dBmShift (rx/receiver.go:377)
+    for (int s = 0; s < PL::R; s++) {  // timing-only build: no projection
+        const int k = fft64::output_bin<LOGN>(t, s);
+        pd[k] = (float)xr[s];
+        sp[k] = (float)xi[s];
     }
+#else
+    project_and_store<LOGN>(xr, xi, t, sp, pd, inv_n2, ltab, [](int) {});
+#endif
+    SDR_STAMP(10);
+#if defined(SDR_FFT_TRACE)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    SDR_STAMP(11);
 }
 
 constexpr int kLogTabBytes = gomath::kLogTabSize * (int)sizeof(gomath::LogTabEntry);

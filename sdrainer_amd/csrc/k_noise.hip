@@ -27,12 +27,43 @@ constexpr int CHAIN_THREADS = 64 * (1 + N_PRODUCERS);  // 1024 threads, 128 VGPR
 template <int SLOTS>
 struct ChainShared {
     static constexpr int RING_SLOTS = SLOTS;
-    double term[SLOTS][TILE][TILE + 1];  // [slot][chain][column]; row stride 65 doubles: conflict-free both ways
+    // [slot][chain][column]; row stride 66 doubles = 528 bytes: rows stay 16-byte aligned for the consumer's
+    // ds_read_b128 and consecutive rows shift by one 16-byte unit, so neither side has bank conflicts
+    alignas(16) double term[SLOTS][TILE][TILE + 2];
     double mean[TILE];                        // per chain: value subtracted before squaring (variance pass)
     int n_terms[TILE];                        // per chain: number of leading terms that count
     int ready[SLOTS][2];                      // ready[t % SLOTS][h] == t + 1  <=>  rows 32h..32h+31 of tile t are published
     int consumed;                             // tiles the consumer has finished with
+    int simd_of_wave[1 + N_PRODUCERS];        // which SIMD each wave landed on (see chain_run)
 };
+
+#if defined(SDR_NOISE_TRACE)
+// diagnostic builds (tools/abl): where does the consumer of workgroup 0 spend its time?
+__device__ unsigned long long g_noise_trace[8];  // [0] total, [1] waiting for tiles, [2] tiles, [3] spins
+extern "C" __attribute__((visibility("default"))) int sdr_debug_noise_trace(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_noise_trace), sizeof(g_noise_trace));
+}
+#endif
+
+// The rings live at file scope so that the consumer can be a function of its own (see chain_consumer).
+__shared__ ChainShared<2> g_ring2;
+__shared__ ChainShared<4> g_ring4;
+template <int SLOTS>
+__device__ __forceinline__ ChainShared<SLOTS> &ring()
+{
+    if constexpr (SLOTS == 2)
+        return g_ring2;
+    else
+        return g_ring4;
+}
+
+// Ordering between a wave's LDS accesses and its flag accesses.  A wave's DS instructions execute in issue
+// order and LDS is one memory for the whole workgroup, so "data before flag" (producer) and "flag before
+// data" (consumer) only need the COMPILER to keep the program order.  A real workgroup-scope fence compiles
+// to s_waitcnt vmcnt(0) lgkmcnt(0): it would drain the producer's global loads of the unit after next and
+// the consumer's reads of the next chunks, which is exactly the latency both sides run ahead to hide.
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
 
 __device__ __forceinline__ int lds_flag_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_flag_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -56,28 +87,33 @@ __device__ __forceinline__ double readlane_f64(double v, int src)
 // bit-identical, so the consumer needs no per-lane predicate.
 template <bool VARIANCE, class Shared>
 __device__ __forceinline__ void chain_producer(Shared &sh, const float *__restrict__ base, unsigned row_stride,
-                                               int rows, int n_cols, int n_tiles, int min_terms, int p, int lane)
+                                               int rows, int n_cols, int n_tiles, int min_terms, int p, int np,
+                                               int lane)
 {
     // lane r keeps chain r's mean / length; rows read them with v_readlane (wave-uniform, no LDS traffic)
     const double mean_of_lane = sh.mean[lane];
     const int terms_of_lane = sh.n_terms[lane];
-    for (int u = p; u < 2 * n_tiles; u += N_PRODUCERS) {
+    const int n_units = 2 * n_tiles;
+    // unconditional loads (a predicated load compiles to branch + load + vmcnt(0): serial round
+    // trips): out-of-range rows / columns / units are clamped to a valid address and their values are
+    // discarded below by the chain-length test (such chains have n_terms <= col) or never used
+    auto fetch = [&](float (&v)[HALF], int u) {
+        u = min(u, n_units - 1);
         const int t = u >> 1, h = u & 1;
-        const unsigned col = (unsigned)(t * TILE + lane);
-        // unconditional loads (a predicated load compiles to branch + load + vmcnt(0): serial round
-        // trips): out-of-range rows / columns are clamped to a valid address and their values are
-        // discarded below by the chain-length test (such chains have n_terms <= col)
-        const unsigned ccol = min(col, (unsigned)(n_cols - 1));
-        float v[HALF];
+        const unsigned ccol = min((unsigned)(t * TILE + lane), (unsigned)(n_cols - 1));
 #pragma unroll
         for (int i = 0; i < HALF; i++)
             v[i] = base[(unsigned)min(h * HALF + i, rows - 1) * row_stride + ccol];
+    };
+    auto publish = [&](const float (&v)[HALF], int u) {
+        const int t = u >> 1, h = u & 1;
+        const unsigned col = (unsigned)(t * TILE + lane);
         constexpr int RING_SLOTS = Shared::RING_SLOTS;
         const int slot = t % RING_SLOTS;
         if (t >= RING_SLOTS)
             while (lds_flag_load(&sh.consumed) < t - RING_SLOTS + 1)
                 __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        lds_order();
         const bool full = (t + 1) * TILE <= min_terms;  // every chain still covers the whole tile
         if (h == 0) {
 #pragma unroll
@@ -104,35 +140,119 @@ __device__ __forceinline__ void chain_producer(Shared &sh, const float *__restri
                 sh.term[slot][HALF + i][lane] = x;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        lds_order();
         if (lane == 0)
             lds_flag_store(&sh.ready[slot][h], t + 1);
+    };
+    // (Two units in flight per producer - the next unit's loads issued before this one is published - were
+    // measured after the fences were gone too: window means 0.058 instead of 0.047 ms, variance chain equal.)
+    float v[HALF];
+    for (int u = p; u < n_units; u += np) {
+        fetch(v, u);
+        publish(v, u);
     }
 }
 
-// Consumer: lane = chain; per tile 64 strictly ordered float64 additions (ds_read_b64 + v_add_f64 each).
-template <class Shared>
-__device__ __forceinline__ double chain_consumer(Shared &sh, int n_tiles, int lane)
+// Consumer: lane = chain; per tile 64 strictly ordered float64 additions.  Only the v_add_f64 chain is
+// serial (6.5 clk per term); the ds_read_b128 that feed it run 32 terms ahead, across tile boundaries too
+// (the next tile's flags are requested two chunks before they are needed), so no LDS latency sits
+// between two additions unless the producers are late.
+// Not inlined on purpose: inside the kernel the register allocator has the producers' half-tile of loads
+// and conversions in the same function and ends up spilling the chain's operands; as a function of its
+// own the consumer gets a clean allocation (about 70 VGPRs, nothing spilled).
+template <int SLOTS>
+__device__ __attribute__((noinline)) double chain_consumer(int n_tiles_any_lane, int lane)
 {
-    constexpr int RING_SLOTS = Shared::RING_SLOTS;
+    const int n_tiles = __builtin_amdgcn_readfirstlane(n_tiles_any_lane);  // wave-uniform: scalar loop control
+    ChainShared<SLOTS> &sh = ring<SLOTS>();
+    constexpr int RING_SLOTS = SLOTS;
+    constexpr int CH = 8;
     double sum = 0;
+    if (n_tiles <= 0)
+        return sum;
     __builtin_amdgcn_s_setprio(3);
-    for (int t = 0; t < n_tiles; t++) {
+#if defined(SDR_NOISE_TRACE)
+    unsigned long long tr_wait = 0, tr_spins = 0;
+    const unsigned long long tr_start = wall_clock64();
+#endif
+    auto wait_tile = [&](int t, int f0, int f1) {
         const int slot = t % RING_SLOTS;
-        while (lds_flag_load(&sh.ready[slot][0]) != t + 1 || lds_flag_load(&sh.ready[slot][1]) != t + 1)
+#if defined(SDR_NOISE_TRACE)
+        const unsigned long long w0 = wall_clock64();
+#endif
+        while (f0 != t + 1 || f1 != t + 1) {
             __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#pragma unroll 1
-        for (int j0 = 0; j0 < TILE; j0 += 16) {
-#pragma unroll
-            for (int j = 0; j < 16; j++)
-                sum += sh.term[slot][lane][j0 + j];
+            f0 = lds_flag_load(&sh.ready[slot][0]);
+            f1 = lds_flag_load(&sh.ready[slot][1]);
+#if defined(SDR_NOISE_TRACE)
+            tr_spins++;
+#endif
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#if defined(SDR_NOISE_TRACE)
+        tr_wait += wall_clock64() - w0;
+#endif
+        lds_order();
+    };
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    auto load = [&](double (&b)[CH], int t, int c) {
+        const d2 *row = reinterpret_cast<const d2 *>(&sh.term[t % RING_SLOTS][lane][c * CH]);
+#pragma unroll
+        for (int j = 0; j < CH / 2; j++) {
+            const d2 v = row[j];  // ds_read_b128
+            b[2 * j] = v.x;
+            b[2 * j + 1] = v.y;
+        }
+    };
+    auto add = [&](const double (&b)[CH]) {
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+            sum += b[j];
+    };
+    // Four 8-term buffers, each chunk read four chunks (32 terms, > 200 clocks of additions) before it is
+    // added: chunk c of a tile lives in buffer c % 4.  Entering tile t, its chunks 0-3 are already on
+    // their way (requested during the second half of tile t-1).
+    double q0[CH], q1[CH], q2[CH], q3[CH];
+    wait_tile(0, lds_flag_load(&sh.ready[0][0]), lds_flag_load(&sh.ready[0][1]));
+    load(q0, 0, 0);
+    load(q1, 0, 1);
+    load(q2, 0, 2);
+    load(q3, 0, 3);
+    for (int t = 0; t < n_tiles; t++) {
+        const bool more = t + 1 < n_tiles;
+        const int nslot = (t + 1) % RING_SLOTS;
+        // (each empty asm pins the running sum and memory: it keeps the reads where they are written -
+        // ahead of the additions they overlap - and stops the scheduler from sinking additions below later
+        // reads, which keeps a whole tile of operands alive and spills them)
+#define SDR_PIN asm volatile("" : "+v"(sum)::"memory")
+        add(q0); SDR_PIN; load(q0, t, 4); SDR_PIN;
+        add(q1); SDR_PIN; load(q1, t, 5); SDR_PIN;
+        int f0 = 0, f1 = 0;
+        if (more) {
+            f0 = lds_flag_load(&sh.ready[nslot][0]);
+            f1 = lds_flag_load(&sh.ready[nslot][1]);
+        }
+        add(q2); SDR_PIN; load(q2, t, 6); SDR_PIN;
+        add(q3); SDR_PIN; load(q3, t, 7); SDR_PIN;
+        if (more)
+            wait_tile(t + 1, f0, f1);
+        add(q0); SDR_PIN; if (more) load(q0, t + 1, 0); SDR_PIN;
+        add(q1); SDR_PIN; if (more) load(q1, t + 1, 1); SDR_PIN;
+        add(q2); SDR_PIN; if (more) load(q2, t + 1, 2); SDR_PIN;
+        add(q3); SDR_PIN; if (more) load(q3, t + 1, 3); SDR_PIN;
+#undef SDR_PIN
+        lds_order();
         if (lane == 0)
             lds_flag_store(&sh.consumed, t + 1);
     }
     __builtin_amdgcn_s_setprio(0);
+#if defined(SDR_NOISE_TRACE)
+    if (SLOTS == 4 && blockIdx.x == 7 && lane == 0) {
+        g_noise_trace[0] = wall_clock64() - tr_start;
+        g_noise_trace[1] = tr_wait;
+        g_noise_trace[2] = (unsigned long long)n_tiles;
+        g_noise_trace[3] = tr_spins;
+    }
+#endif
     return sum;
 }
 
@@ -143,7 +263,14 @@ template <bool VARIANCE, class Shared>
 __device__ __forceinline__ double chain_run(Shared &sh, const float *__restrict__ base, size_t row_stride,
                                             int rows, int n_cols, int my_terms, double my_mean)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (readfirstlane: the role split below becomes a scalar branch instead of an exec-masked region)
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // HW_REG_HW_ID bits 5:4 = SIMD this wave runs on.  The consumer's additions are a pure latency chain;
+    // a producer on the same SIMD puts its float64 instructions between them (measured: 13.5 instead of
+    // 6.5 clocks per term).  Producers that share the consumer's SIMD therefore sit the chain out.
+    const int my_simd = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
+    if (lane == 0)
+        sh.simd_of_wave[wave] = my_simd;
     if (wave == 0) {
         sh.n_terms[lane] = my_terms;
         sh.mean[lane] = my_mean;
@@ -161,12 +288,28 @@ __device__ __forceinline__ double chain_run(Shared &sh, const float *__restrict_
         max_terms = max(max_terms, __shfl_xor(max_terms, o));
         min_terms = min(min_terms, __shfl_xor(min_terms, o));
     }
-    const int n_tiles = (max_terms + TILE - 1) / TILE;
+    const int n_tiles = __builtin_amdgcn_readfirstlane((max_terms + TILE - 1) / TILE);
+    min_terms = __builtin_amdgcn_readfirstlane(min_terms);
+    // rank of this wave among the producers that are not on the consumer's SIMD, and their number
+    int p = 0, np = 0;
+    const int consumer_simd = sh.simd_of_wave[0];
+    for (int w = 1; w <= N_PRODUCERS; w++) {
+        const bool active = sh.simd_of_wave[w] != consumer_simd;
+        p += (active && w < wave) ? 1 : 0;
+        np += active ? 1 : 0;
+    }
+    p = __builtin_amdgcn_readfirstlane(p);
+    np = __builtin_amdgcn_readfirstlane(np);
+    const bool sits_out = np > 0 && my_simd == consumer_simd;  // (np == 0 cannot happen with 16 waves on 4 SIMDs)
+    if (np == 0) {
+        p = wave - 1;
+        np = N_PRODUCERS;
+    }
     double sum = 0;
     if (wave == 0)
-        sum = chain_consumer(sh, n_tiles, lane);
-    else
-        chain_producer<VARIANCE>(sh, base, (unsigned)row_stride, rows, n_cols, n_tiles, min_terms, wave - 1, lane);
+        sum = chain_consumer<Shared::RING_SLOTS>(n_tiles, lane);
+    else if (!sits_out)
+        chain_producer<VARIANCE>(sh, base, (unsigned)row_stride, rows, n_cols, n_tiles, min_terms, p, np, lane);
     __syncthreads();  // everyone is done with the ring before a caller re-initialises it
     return sum;
 }
@@ -178,7 +321,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_window_means(const float *__r
                                                                 double *__restrict__ win_mean, NoiseGeom g,
                                                                 int n_frames, int stride, int windows_per_block)
 {
-    __shared__ ChainShared<2> sh;
+    ChainShared<2> &sh = ring<2>();
     const int lane = threadIdx.x & 63;
     const int f0 = blockIdx.x * TILE, band = blockIdx.z;
     const int rows = min(TILE, n_frames - f0);
@@ -200,7 +343,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_noise_stats(const float *__re
                                                                sdr_frame_rec *__restrict__ recs, NoiseGeom g,
                                                                int n_frames, int stride)
 {
-    __shared__ ChainShared<4> sh;
+    ChainShared<4> &sh = ring<4>();
     const int lane = threadIdx.x & 63;
     const bool consumer = threadIdx.x < TILE;
     const int f0 = blockIdx.x * TILE, band = blockIdx.y;

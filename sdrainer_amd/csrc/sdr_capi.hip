@@ -283,6 +283,18 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     const sdr::NoiseGeom ng = b->noise_geom();
     const int si = (int)(b->batch_index % RING);
     BatchSet &S = b->set[si];
+#if defined(SDR_DIAG)
+    // diagnostic builds only (tools/abl): SDR_DIAG_SKIP = bit mask of kernel ids not to launch, to see
+    // which stage holds the pipelined step up.  Results are wrong by construction.
+    static const int diag_skip = getenv("SDR_DIAG_SKIP") ? atoi(getenv("SDR_DIAG_SKIP")) : 0;
+#define SDR_LAUNCH(id, call) \
+    do {                     \
+        if (!(diag_skip >> (id) & 1)) \
+            HIP_TRY(call);   \
+    } while (0)
+#else
+#define SDR_LAUNCH(id, call) HIP_TRY(call)
+#endif
     hipStream_t s_fft = b->stream[S_FFT], s_noise = b->stream[S_NOISE], s_listen = b->stream[S_LISTEN],
                 s_peaks = b->stream[S_PEAKS], s_thr = s_noise, s_gather = s_noise;
 
@@ -294,7 +306,7 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
             HIP_TRY(hipStreamWaitEvent(s_fft, S.done[st], 0));
     {
         ProfScope ps(b, sdr::K_FFT, s_fft);
-        HIP_TRY(sdr::launch_fft(b->logn, iq_dev, b->tw.p, S.spectrum.p, S.psd.p, n_frames, B, in_stride, stride, s_fft));
+        SDR_LAUNCH(sdr::K_FFT, sdr::launch_fft(b->logn, iq_dev, b->tw.p, S.spectrum.p, S.psd.p, n_frames, B, in_stride, stride, s_fft));
     }
     HIP_TRY(hipEventRecord(S.done[S_FFT], s_fft));
 
@@ -302,16 +314,16 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     HIP_TRY(hipStreamWaitEvent(s_noise, S.done[S_FFT], 0));
     {
         ProfScope ps(b, sdr::K_WINDOW_MEANS, s_noise);
-        HIP_TRY(sdr::launch_window_means(S.psd.p, S.win_mean.p, ng, n_frames, B, stride, s_noise));
+        SDR_LAUNCH(sdr::K_WINDOW_MEANS, sdr::launch_window_means(S.psd.p, S.win_mean.p, ng, n_frames, B, stride, s_noise));
     }
     {
         ProfScope ps(b, sdr::K_NOISE_STATS, s_noise);
-        HIP_TRY(sdr::launch_noise_stats(S.psd.p, S.win_mean.p, S.recs.p, ng, n_frames, B, stride, s_noise));
+        SDR_LAUNCH(sdr::K_NOISE_STATS, sdr::launch_noise_stats(S.psd.p, S.win_mean.p, S.recs.p, ng, n_frames, B, stride, s_noise));
     }
     // rolling means -> thresholds, in batch order (same stream)
     {
         ProfScope ps(b, sdr::K_THRESHOLDS, s_thr);
-        HIP_TRY(sdr::launch_thresholds(S.recs.p, b->band_state.p, n_frames, B, stride, s_thr));
+        SDR_LAUNCH(sdr::K_THRESHOLDS, sdr::launch_thresholds(S.recs.p, b->band_state.p, n_frames, B, stride, s_thr));
     }
     HIP_TRY(hipEventRecord(S.done[S_THR], s_thr));
 
@@ -331,14 +343,14 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     HIP_TRY(hipStreamWaitEvent(s_gather, S.done[S_THR], 0));
     if (max_slots > 0) {
         ProfScope ps(b, sdr::K_LISTEN_GATHER, s_gather);
-        HIP_TRY(sdr::launch_listen_gather(S.spectrum.p, S.recs.p, b->slots.p, S.raw_bits.p, S.tr_values.p, S.tr_raw.p,
+        SDR_LAUNCH(sdr::K_LISTEN_GATHER, sdr::launch_listen_gather(S.spectrum.p, S.recs.p, b->slots.p, S.raw_bits.p, S.tr_values.p, S.tr_raw.p,
                                           lg, n_frames, max_slots, B, s_gather));
     }
     HIP_TRY(hipEventRecord(S.done[S_NOISE], s_gather));  // the noise stream is done with this set
     HIP_TRY(hipStreamWaitEvent(s_listen, S.done[S_NOISE], 0));
     if (max_slots > 0) {
         ProfScope ps(b, sdr::K_LISTEN_DECODE, s_listen);
-        HIP_TRY(sdr::launch_listen_decode(b->slots.p, b->morse.p, S.raw_bits.p, S.bits.p, b->text.p, S.edges.p,
+        SDR_LAUNCH(sdr::K_LISTEN_DECODE, sdr::launch_listen_decode(b->slots.p, b->morse.p, S.raw_bits.p, S.bits.p, b->text.p, S.edges.p,
                                           S.edge_counts.p, S.tr_deb.p, lg, n_frames, B, s_listen));
     }
     HIP_TRY(hipEventRecord(S.done[S_LISTEN], s_listen));
@@ -356,7 +368,7 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     {
         ProfScope ps(b, sdr::K_CUMULATE, s_peaks);
         sdr::CumGeom cg{N, stride, n_frames, count0, b->max_chunks};
-        HIP_TRY(sdr::launch_cumulate(S.spectrum.p, b->carry[b->carry_cur].p, b->carry[b->carry_cur ^ 1].p, S.cum_out.p,
+        SDR_LAUNCH(sdr::K_CUMULATE, sdr::launch_cumulate(S.spectrum.p, b->carry[b->carry_cur].p, b->carry[b->carry_cur ^ 1].p, S.cum_out.p,
                                      cg, n_slots_c, B, s_peaks));
     }
     const int new_count = (count0 + n_frames) % SDR_CUMULATION_SIZE;
@@ -368,7 +380,7 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         HIP_TRY(hipStreamWaitEvent(s_peaks, S.done[S_THR], 0));  // needs the completing frame's peak threshold
         ProfScope ps(b, sdr::K_FIND_PEAKS, s_peaks);
         sdr::PeakGeom pg{N, stride, count0, b->max_chunks, c.max_peaks};
-        HIP_TRY(sdr::launch_find_peaks(S.cum_out.p, S.recs.p, S.dev_peaks.p, S.peak_counts.p, pg, n_chunks, B, s_peaks));
+        SDR_LAUNCH(sdr::K_FIND_PEAKS, sdr::launch_find_peaks(S.cum_out.p, S.recs.p, S.dev_peaks.p, S.peak_counts.p, pg, n_chunks, B, s_peaks));
     }
     HIP_TRY(hipEventRecord(S.done[S_PEAKS], s_peaks));
 
