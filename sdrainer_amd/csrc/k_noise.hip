@@ -485,6 +485,7 @@ hipError_t launch_window_means(const float *psd, double *win_mean, NoiseGeom g, 
     const int groups = ((n_frames + TILE - 1) / TILE) * n_bands;
     int wpb = (groups * g.n_windows) / 512;
     wpb = wpb < 1 ? 1 : (wpb > g.n_windows ? g.n_windows : wpb);
+
     hipLaunchKernelGGL(k_window_means, dim3((n_frames + TILE - 1) / TILE, (g.n_windows + wpb - 1) / wpb, n_bands),
                        dim3(CHAIN_THREADS), 0, stream, psd, win_mean, g, n_frames, stride, wpb);
     return hipGetLastError();
