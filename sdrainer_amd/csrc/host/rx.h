@@ -78,6 +78,11 @@ public:
     PeaksTable(int size, const Clock *clock) : bins_((size_t)size, nullptr), clock_(clock) {}
 
     void SetRand(RandFn f) { rand_ = std::move(f); }
+    // Selection among the new peaks: the reference's random probe followed by a linear scan (default; the
+    // scan alone when no RandFn is set), or the strongest new peak first (ties: lowest bin) - a policy
+    // whose runs are reproducible at hundreds of listeners without a seed.
+    enum Policy { ReferenceOrder, StrongestFirst };
+    void SetPolicy(Policy p) { policy_ = p; }
     void SetPeakTimeout(double seconds) { peakTimeout_ = seconds; }
 
     void ForcePut(const Peak &p) { put(p, true); }  // :46-71
@@ -121,6 +126,13 @@ public:
     const Peak *FindNext()  // :183-207
     {
         const int n = (int)bins_.size();
+        if (policy_ == StrongestFirst) {
+            const Entry *best = nullptr;
+            for (auto &p : bins_)
+                if (p && p->state == peakNew && (!best || p->peak.signal_value > best->peak.signal_value))
+                    best = p.get();
+            return best ? &best->peak : nullptr;
+        }
         if (rand_)
             for (int k = 0; k < n / 2; k++) {
                 const int i = rand_(n);
@@ -171,6 +183,7 @@ private:
     const Clock *clock_;
     double peakTimeout_ = kDefaultPeakTimeout;
     RandFn rand_;
+    Policy policy_ = ReferenceOrder;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -397,6 +410,12 @@ public:
             sdr_set_center_frequency(bank_, 0, f);
     }
     int64_t CenterFrequency() const { return centerFrequency_; }
+    void SetSelectionPolicy(PeaksTable::Policy p)
+    {
+        policy_ = p;
+        if (peaks_)
+            peaks_->SetPolicy(p);
+    }
     void SetFindNextRand(PeaksTable::RandFn f)
     {
         rand_ = std::move(f);
@@ -429,6 +448,7 @@ public:
         sdr_set_center_frequency(bank_, 0, centerFrequency_);
         peaks_.reset(new PeaksTable(blockSize, clock_));
         peaks_->SetRand(rand_);
+        peaks_->SetPolicy(policy_);
         return SDR_OK;
     }
     void Stop()  // :148-164
@@ -659,6 +679,7 @@ private:
     sdr_bank *bank_ = nullptr;
     std::unique_ptr<PeaksTable> peaks_;
     PeaksTable::RandFn rand_;
+    PeaksTable::Policy policy_ = PeaksTable::ReferenceOrder;
     ListenerPool listeners_;
     int64_t framesProcessed_ = 0;
     double lastCleanup_ = 0;

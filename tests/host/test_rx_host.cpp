@@ -151,6 +151,35 @@ static void TestPeaksTable_FindNext()  // rx/peaks_test.go:126-143
     CHECK(t.FindNext() == nullptr);
 }
 
+static void TestPeaksTable_StrongestFirst()  // reproducible selection without a seed
+{
+    rx::ManualClock clock;
+    rx::PeaksTable t(512, &clock);
+    t.SetPolicy(rx::PeaksTable::StrongestFirst);
+    rx::Peak a = mk(10, 12), b = mk(100, 101), c = mk(200, 205), d = mk(300, 300);
+    a.signal_value = 20.f;
+    b.signal_value = 35.f;
+    c.signal_value = 35.f;  // tie with b: the lower bin wins
+    d.signal_value = 50.f;
+    t.Put(a);
+    t.Put(b);
+    t.Put(c);
+    t.Put(d);
+    const rx::Peak *n = t.FindNext();
+    CHECK(n && n->from == 300);
+    t.Activate(*n);
+    n = t.FindNext();
+    CHECK(n && n->from == 100);
+    t.Activate(*n);
+    n = t.FindNext();
+    CHECK(n && n->from == 200);
+    t.Activate(*n);
+    n = t.FindNext();
+    CHECK(n && n->from == 10);
+    t.Activate(*n);
+    CHECK(t.FindNext() == nullptr);
+}
+
 static void TestListenerTimeouts()  // rx/listener.go:126-136
 {
     rx::ManualClock clock;
@@ -203,7 +232,7 @@ struct PrintReporter : rx::Reporter {
     }
 };
 
-static int run_strain(const char *path, int rate, int n, int frames, int pool)
+static int run_strain(const char *path, int rate, int n, int frames, int pool, bool strongest = false)
 {
     FILE *f = fopen(path, "rb");
     if (!f)
@@ -216,6 +245,8 @@ static int run_strain(const char *path, int rate, int n, int frames, int pool)
     rx::Receiver r("rx", rx::StrainMode, nullptr, pool);
     r.AddReporter(&rep);
     r.SetCenterFrequency(7020000);
+    if (strongest)
+        r.SetSelectionPolicy(rx::PeaksTable::StrongestFirst);
     r.SetSilenceTimeout(1e9);
     r.SetAttachmentTimeout(1e9);
     r.SetEdgeWidth(70 * n / 512);
@@ -407,6 +438,7 @@ int main(int argc, char **argv)
         TestPeaksTable_Put();
         TestPeaksTable_Cleanup();
         TestPeaksTable_FindNext();
+        TestPeaksTable_StrongestFirst();
         TestListenerTimeouts();
         TestPeakCentering();
         TestTextWindow_Write();
@@ -421,7 +453,8 @@ int main(int argc, char **argv)
     if (argc >= 2 && !strcmp(argv[1], "text"))
         return run_text();
     if (argc >= 7 && !strcmp(argv[1], "strain"))
-        return run_strain(argv[2], atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]));
+        return run_strain(argv[2], atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]),
+                          argc >= 8 && !strcmp(argv[7], "strongest"));
     fprintf(stderr, "usage: %s cpu | text | strain <iq.f32> <rate> <N> <frames> <pool>\n", argv[0]);
     return 2;
 }

@@ -112,3 +112,59 @@ def test_strain_mode_spots_callsigns(exe, tmp_path):
         assert mine == want
         spotted += any(c == f"{l['id']} spotted DL1ABC {l['frequency']}" for c in mine)
     assert spotted == pool
+
+
+@pytest.mark.gpu
+def test_strain_mode_strongest_first_many_listeners(exe, tmp_path):
+    """strain mode with the strongest-new-peak-first policy is reproducible without a seed.
+    C2 geometry (192 kS/s, N = 4096), 16 carriers of different strength, a pool of 16: one listener is bound
+    per cumulation, strongest carrier first - compared with the same policy simulated on the CPU oracle."""
+    from oracle import oracle as orc
+    from sdrainer_amd import synth
+
+    rate, n, pool, tones = 192000, 4096, 16, 16
+    frames = 100 * (pool + 2) + 37
+    iq, bins, key = synth.make_band(frames, rate, n, tones, seed=2024)
+    # give every carrier its own level: scale carrier k by (1 + k/8) in the frequency domain (exact bins)
+    spec = np.fft.fft(iq[:, 0::2].astype(np.float64) + 1j * iq[:, 1::2].astype(np.float64), axis=1)
+    for k, b in enumerate(bins):
+        spec[:, (int(b) + n // 2) % n] *= 1.0 + k / 8.0
+    t = np.fft.ifft(spec, axis=1)
+    iq = np.empty((frames, 2 * n), np.float32)
+    iq[:, 0::2] = t.real
+    iq[:, 1::2] = t.imag
+    path = tmp_path / "iq.f32"
+    iq.tofile(path)
+    out = subprocess.run([exe, "strain", str(path), str(rate), str(n), str(frames), str(pool), "strongest"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    got = json.loads(out.stdout)
+    assert got["frames"] == frames
+
+    ref = orc.Receiver(rate, n, 70 * n // 512, 15.0, 1, center_frequency=7020000)
+    table, attached = {}, []
+    for c in range(frames // 100 + 1):
+        chunk = iq[100 * c:100 * (c + 1)]
+        if len(chunk) == 0:
+            break
+        hunting = len(attached) < pool
+        ref.set_find_peaks(hunting)
+        res = ref.process(chunk)
+        if not hunting or res["n_chunks"] == 0:
+            continue
+        for p in res["peaks"][0]:
+            sb = p[6]
+            if table.get(sb) != "active":
+                table[sb] = ("new", p)
+        new = [(v[1][5], -b, b) for b, v in table.items() if v != "active" and v[0] == "new"]
+        if new:
+            _, _, sb = max(new)  # strongest signal value, ties: lowest bin
+            p = table[sb][1]
+            table[sb] = "active"
+            attached.append((ref.attach(sb), sb, p[4]))
+    assert len(attached) == pool == len(got["listeners"])
+    # the swap-remove pool keeps binding order while nothing is released
+    for (lid, sb, freq), l in zip(attached, got["listeners"]):
+        assert l["bin"] == sb and l["frequency"] == freq
+        assert bytes(ord(ch) for ch in l["text"]).decode("utf-8") == ref.text(lid)
+    assert len({a[1] for a in attached}) == pool  # sixteen different carriers
