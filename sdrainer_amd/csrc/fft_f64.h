@@ -215,6 +215,111 @@ SDR_HD constexpr int lds_addr(int i)
     return r;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Register exchange.  When exchange E only trades slot bits for the index bits held in lane bits 4
+// and 5 (everything else stays where it is), it needs no LDS at all: gfx950's v_permlane16_swap /
+// v_permlane32_swap exchange the upper half-rows / upper half of one register with the lower ones of
+// another, which IS the swap of a register-index bit with lane bit 4 / 5.  64 VALU instructions per
+// wave for the last exchange at N = 16384 instead of 64 LDS instructions, four dependent LDS round
+// trips and a barrier.
+// ---------------------------------------------------------------------------------------------
+struct SwapPlan {
+    bool ok;
+    int slot_bit_lane4;  // slot bit that trades places with lane bit 4 (-1: lane bit 4 keeps its index bit)
+    int slot_bit_lane5;
+};
+
+template <int LOGN>
+SDR_HD constexpr SwapPlan make_swap_plan(int E)
+{
+    using PL = Plan<LOGN>;
+    const Layout A = make_layout<LOGN>(E), B = make_layout<LOGN>(E + 1);
+    SwapPlan p{true, -1, -1};
+    for (int j = 0; j < PL::LOGT; j++)
+        if (j != 4 && j != 5 && A.tbit[j] != B.tbit[j])
+            p.ok = false;
+    for (int j = 0; j < PL::LOGR; j++) {
+        if (A.sbit[j] == B.sbit[j])
+            continue;
+        if (B.sbit[j] == A.tbit[4] && A.sbit[j] == B.tbit[4] && p.slot_bit_lane4 < 0)
+            p.slot_bit_lane4 = j;
+        else if (B.sbit[j] == A.tbit[5] && A.sbit[j] == B.tbit[5] && p.slot_bit_lane5 < 0)
+            p.slot_bit_lane5 = j;
+        else
+            p.ok = false;
+    }
+    if (p.slot_bit_lane4 < 0 && A.tbit[4] != B.tbit[4])
+        p.ok = false;
+    if (p.slot_bit_lane5 < 0 && A.tbit[5] != B.tbit[5])
+        p.ok = false;
+    if (p.slot_bit_lane4 < 0 && p.slot_bit_lane5 < 0)
+        p.ok = false;
+#if defined(SDR_FFT_NO_SWAP)
+    p.ok = false;  // diagnostic builds: every exchange through LDS
+#endif
+    return p;
+}
+
+// Host-side model of the same exchange for one wave (x[lane][slot]); tests/emu uses it.
+template <int LOGN, int E>
+inline void exchange_swap_wave(double (*x)[Plan<LOGN>::R])
+{
+    constexpr SwapPlan P = make_swap_plan<LOGN>(E);
+    static_assert(P.ok, "exchange is not a register swap");
+    for (int round = 0; round < 2; round++) {
+        const int sb = round == 0 ? P.slot_bit_lane4 : P.slot_bit_lane5;
+        const int half = round == 0 ? 16 : 32;
+        if (sb < 0)
+            continue;
+        for (int a = 0; a < Plan<LOGN>::R; a++) {
+            if ((a >> sb) & 1)
+                continue;
+            const int b = a | (1 << sb);
+            // v_permlaneNN_swap A, B: A's lanes with the bit set <-> B's lanes with the bit clear
+            for (int l = 0; l < 64; l++)
+                if (!(l & half)) {
+                    const double t = x[l + half][a];
+                    x[l + half][a] = x[l][b];
+                    x[l][b] = t;
+                }
+        }
+    }
+}
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ void swap_halves(double &a, double &b, bool rows16)
+{
+    unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+    unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    if (rows16) {
+        const auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        alo = lo[0], blo = lo[1], ahi = hi[0], bhi = hi[1];
+    } else {
+        const auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+        alo = lo[0], blo = lo[1], ahi = hi[0], bhi = hi[1];
+    }
+    a = __hiloint2double((int)ahi, (int)alo);
+    b = __hiloint2double((int)bhi, (int)blo);
+}
+
+template <int LOGN, int E>
+__device__ __forceinline__ void exchange_swap(double (&x)[Plan<LOGN>::R])
+{
+    constexpr SwapPlan P = make_swap_plan<LOGN>(E);
+    static_assert(P.ok, "exchange is not a register swap");
+#pragma unroll
+    for (int a = 0; a < Plan<LOGN>::R; a++)
+        if (P.slot_bit_lane4 >= 0 && !((a >> P.slot_bit_lane4) & 1))
+            swap_halves(x[a], x[a | (1 << P.slot_bit_lane4)], true);
+#pragma unroll
+    for (int a = 0; a < Plan<LOGN>::R; a++)
+        if (P.slot_bit_lane5 >= 0 && !((a >> P.slot_bit_lane5) & 1))
+            swap_halves(x[a], x[a | (1 << P.slot_bit_lane5)], false);
+}
+#endif
+
 // Sample number (natural order) held in slot m of thread t at the start of pass 0.
 template <int LOGN>
 SDR_HD inline int input_sample(int t, int m)
@@ -238,9 +343,11 @@ SDR_HD inline void load_input(const float *iq, int t, double *xr, double *xi)
     }
 }
 
-// Pass P: pass_log(P) radix-2 stages on the thread's registers.
-template <int LOGN, int P>
-SDR_HD inline void butterfly_pass(double *xr, double *xi, int t, const cplx *tw)
+// Pass P: pass_log(P) radix-2 stages on the thread's registers.  `tw_at(c, lo)` returns twiddle table
+// entry c + lo, where c is a compile-time constant and lo the only per-thread part (the kernel turns that
+// split into a buffer load with c in the scalar offset; the emulator indexes an array).
+template <int LOGN, int P, class TW>
+SDR_HD inline void butterfly_pass(double *xr, double *xi, int t, TW tw_at)
 {
     using PL = Plan<LOGN>;
     constexpr int PLOG = PL::pass_log(P);
@@ -273,7 +380,7 @@ SDR_HD inline void butterfly_pass(double *xr, double *xi, int t, const cplx *tw)
                     wr = 0.5 + 1e-9 * lo;  // timing-only build: no twiddle loads
                     wi = 0.25;
 #else
-                    const cplx w = tw[OFF + ((1 << q) - 1 + mm) * S + lo];
+                    const cplx w = tw_at(OFF + ((1 << q) - 1 + mm) * S, lo);
                     wr = w.x;
                     wi = w.y;
 #endif

@@ -88,8 +88,8 @@ SDR_HD inline float psd_value_in_db(float psd, double inv_n2)
 // The result is a float32, but the reference computes it through a ~60-instruction float64 log.  The
 // fast path evaluates y ~= 10*log10(v) to an absolute error far below a float32 ulp (table of 64
 // mantissa intervals + degree-6 log1p polynomial, FMA allowed: only the error bound matters here),
-// rounds it to float32, and ACCEPTS the result only if y is farther than kDbGuard from the nearest
-// float32 rounding boundary.  Both y and the reference's value lie within ~2e-13 of the true
+// and ACCEPTS float32(y) only if no float32 rounding boundary lies within kDbGuard of y (y - guard and
+// y + guard round to the same float32).  Both y and the reference's value lie within ~2e-13 of the true
 // logarithm (tests/emu/emu_log.cpp measures it), kDbGuard is 1e-10, so an accepted result is the
 // float32 the reference would have produced; anything else (about one value in 10^5, zeros, NaNs,
 // exact powers of two) reports `false` and the caller runs the literal Go algorithm.
@@ -147,19 +147,13 @@ SDR_HD inline bool psd_value_in_db_fast(float psd, double inv_n2, const LogTabEn
     if (!(v >= 2.2250738585072014e-308) || !(v < INFINITY))
         return false;  // zero, negative, NaN, subnormal, infinite
     const double y = db_fast_y(v, tab);
-    const float y32 = (float)y;
-    uint32_t b32;
-    __builtin_memcpy(&b32, &y32, sizeof b32);
-    const uint32_t e32 = (b32 >> 23) & 0xff;
-    if (e32 < 64 || e32 == 0xff || (b32 & 0x007fffffu) == 0)
-        return false;  // tiny / non-finite / exact power of two (asymmetric rounding interval)
-    const uint32_t hb = (e32 - 24) << 23;  // half an ulp of y32 = 2^(e-24), as a float
-    float half_ulp;
-    __builtin_memcpy(&half_ulp, &hb, sizeof half_ulp);
-    const double d = y - (double)y32;
-    if (!((d < 0 ? -d : d) < (double)half_ulp - kDbGuard))
+    // Rounding to float32 is monotone: if y - guard and y + guard round to the same float32, so does every
+    // value between them, the reference's among them.  (Covers asymmetric intervals at powers of two and
+    // values straddling zero without any bit tests.)
+    const float lo = (float)(y - kDbGuard), hi = (float)(y + kDbGuard);
+    if (!(lo == hi))
         return false;
-    *out = y32;
+    *out = lo;
     return true;
 }
 

@@ -30,6 +30,23 @@ namespace sdr {
 // ---------------------------------------------------------------------------------------------
 // k_fft_project  (dsp/fft.go:23-37 IQToSpectrumAndPSD + rx/receiver.go:376-378 projection closure)
 // ---------------------------------------------------------------------------------------------
+// Buffer addressing: address = descriptor base + per-thread 32-bit byte offset (a VGPR) + a scalar byte
+// offset.  Everything that is the same for all threads - which register slot, which twiddle row - goes into
+// the scalar offset, so a load or store costs no vector ALU instruction for its address.  The float64 VALU
+// is this kernel's busiest unit; flat 64-bit addressing spent about 150 vector instructions per thread on
+// address arithmetic.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base, unsigned bytes)
+{
+    // inputs are made provably wave-uniform first, otherwise the descriptor is rebuilt per lane (waterfall)
+    const unsigned long long b = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
 // Orders one wave's LDS stores before its later LDS loads (and the reverse) without a workgroup
 // barrier: a wave's DS instructions execute in issue order, so the fences only pin the compiler.
 __device__ __forceinline__ void wave_sync()
@@ -39,50 +56,75 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// does any exchange after E go through LDS?
+template <int LOGN>
+constexpr bool later_lds_exchange(int e)
+{
+    for (int k = e + 1; k < fft64::Plan<LOGN>::NPASS - 1; k++)
+        if (!fft64::make_swap_plan<LOGN>(k).ok)
+            return true;
+    return false;
+}
+
 template <int LOGN, int P>
 __device__ __forceinline__ void run_passes(double (&xr)[fft64::Plan<LOGN>::R], double (&xi)[fft64::Plan<LOGN>::R],
-                                           int t, const fft64::cplx *__restrict__ tw, double *lds)
+                                           int t, rsrc_t tw, const fft64::cplx *__restrict__ tw_ptr, double *lds)
 {
     using PL = fft64::Plan<LOGN>;
 #if !(defined(SDR_ABLATE) && (SDR_ABLATE == 5))
-    fft64::butterfly_pass<LOGN, P>(xr, xi, t, tw);
+    fft64::butterfly_pass<LOGN, P>(xr, xi, t, [tw, tw_ptr](int c, int lo) {
+        if constexpr (P == 0)
+            return tw_ptr[c];  // pass 0: the same entry for every thread, a scalar load
+        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(tw, (unsigned)lo * 16u, c * 16, 0);
+        fft64::cplx r;
+        r.x = __hiloint2double((int)w.y, (int)w.x);
+        r.y = __hiloint2double((int)w.w, (int)w.z);
+        return r;
+    });
 #endif
     SDR_STAMP(2 + 2 * P);
     if constexpr (P < PL::NPASS - 1) {
-        // A wave-local exchange (fft_f64.h make_layout) only touches LDS words of the wave's own
-        // elements: no workgroup barrier, the waves drift apart and one wave's exchange overlaps the
-        // others' butterflies.  The single cross-wave exchange is fenced by barriers on both sides.
-        constexpr bool CROSS = PL::cross_wave(P);
-        auto sync = [] {
-            if constexpr (CROSS)
-                __syncthreads();
-            else
-                wave_sync();
-        };
-        if constexpr (CROSS)
-            __syncthreads();  // every wave is done with the words of its previous wave-local exchange
-#if defined(SDR_ABLATE) && (SDR_ABLATE == 2)
-        if (t < 0)  // timing-only build: no exchanges
-#endif
-        if constexpr (PL::SPLIT) {
-            fft64::exchange_write<LOGN, P>(xr, t, lds);
-            sync();
-            fft64::exchange_read<LOGN, P>(xr, t, lds);
-            sync();
-            fft64::exchange_write<LOGN, P>(xi, t, lds);
-            sync();
-            fft64::exchange_read<LOGN, P>(xi, t, lds);
+        if constexpr (fft64::make_swap_plan<LOGN>(P).ok) {
+            // slot bits <-> lane bits 4/5 only: done in registers (fft_f64.h exchange_swap), no LDS
+            fft64::exchange_swap<LOGN, P>(xr);
+            fft64::exchange_swap<LOGN, P>(xi);
         } else {
-            fft64::exchange_write<LOGN, P>(xr, t, lds);
-            fft64::exchange_write<LOGN, P>(xi, t, lds + PL::N);
-            sync();
-            fft64::exchange_read<LOGN, P>(xr, t, lds);
-            fft64::exchange_read<LOGN, P>(xi, t, lds + PL::N);
+            // A wave-local exchange (fft_f64.h make_layout) only touches LDS words of the wave's own
+            // elements: no workgroup barrier, the waves drift apart and one wave's exchange overlaps the
+            // others' butterflies.  The single cross-wave exchange is fenced by barriers on both sides.
+            constexpr bool CROSS = PL::cross_wave(P);
+            auto sync = [] {
+                if constexpr (CROSS)
+                    __syncthreads();
+                else
+                    wave_sync();
+            };
+            if constexpr (CROSS)
+                __syncthreads();  // every wave is done with the words of its previous wave-local exchange
+#if defined(SDR_ABLATE) && (SDR_ABLATE == 2)
+            if (t < 0)  // timing-only build: no exchanges
+#endif
+            if constexpr (PL::SPLIT) {
+                fft64::exchange_write<LOGN, P>(xr, t, lds);
+                sync();
+                fft64::exchange_read<LOGN, P>(xr, t, lds);
+                sync();
+                fft64::exchange_write<LOGN, P>(xi, t, lds);
+                sync();
+                fft64::exchange_read<LOGN, P>(xi, t, lds);
+            } else {
+                fft64::exchange_write<LOGN, P>(xr, t, lds);
+                fft64::exchange_write<LOGN, P>(xi, t, lds + PL::N);
+                sync();
+                fft64::exchange_read<LOGN, P>(xr, t, lds);
+                fft64::exchange_read<LOGN, P>(xi, t, lds + PL::N);
+            }
+            // reads done before a later exchange writes LDS again (other waves' words if CROSS)
+            if constexpr (later_lds_exchange<LOGN>(P))
+                sync();
         }
-        if constexpr (P + 1 < PL::NPASS - 1)
-            sync();  // reads done before the next exchange's writes (other waves' words if CROSS)
         SDR_STAMP(3 + 2 * P);
-        run_passes<LOGN, P + 1>(xr, xi, t, tw, lds);
+        run_passes<LOGN, P + 1>(xr, xi, t, tw, tw_ptr, lds);
     }
 }
 
@@ -100,31 +142,36 @@ __device__ __forceinline__ void project_and_store(const double (&xr)[fft64::Plan
     using PL = fft64::Plan<LOGN>;
     unsigned redo = 0;
     const int tp = fft64::thread_part<LOGN, PL::NPASS - 1>(t);
+    // fft-shift = flip the top index bit: in the slot part it is a compile-time constant, in the thread part
+    // it is applied once; spectrum index k = tk | sk(s), and sk(s) goes into the scalar base pointer
+    constexpr int SLOT_MASK = fft64::slot_part<LOGN, PL::NPASS - 1>(PL::R - 1);
+    constexpr int H = PL::N / 2;
+    const unsigned tk = (unsigned)(tp ^ (H & ~SLOT_MASK));
+    const rsrc_t pdr = make_rsrc(pd, PL::N * 4u), spr = make_rsrc(sp, PL::N * 4u);
 #pragma unroll
     for (int s = 0; s < PL::R; s++) {
-        const int i = tp | fft64::slot_part<LOGN, PL::NPASS - 1>(s);
-        const int k = (i + PL::N / 2) & (PL::N - 1);
+        const int sk = fft64::slot_part<LOGN, PL::NPASS - 1>(s) ^ (H & SLOT_MASK);
         const float p = (float)(xr[s] * xr[s] + xi[s] * xi[s]);
 #if defined(SDR_ABLATE) && (SDR_ABLATE == 6 || SDR_ABLATE == 7)
         float db = 0.0f;  // timing-only build: (almost) no stores
         if (!gomath::psd_value_in_db_fast(p, inv_n2, ltab, &db))
             redo |= 1u << s;
         if (db == 1234.5f) {
-            pd[k] = p;
-            sp[k] = db;
+            pd[tk | sk] = p;
+            sp[tk | sk] = db;
         }
 #elif defined(SDR_FFT_NT) && (SDR_FFT_NT & 2)
-        __builtin_nontemporal_store(p, pd + k);
+        __builtin_nontemporal_store(p, pd + (tk | sk));
         float db = 0.0f;
         if (!gomath::psd_value_in_db_fast(p, inv_n2, ltab, &db))
             redo |= 1u << s;
-        __builtin_nontemporal_store(db + 120.0f, sp + k);
+        __builtin_nontemporal_store(db + 120.0f, sp + (tk | sk));
 #else
-        pd[k] = p;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(p), pdr, tk * 4u, sk * 4, 0);
         float db = 0.0f;
         if (!gomath::psd_value_in_db_fast(p, inv_n2, ltab, &db))
             redo |= 1u << s;
-        sp[k] = db + 120.0f;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(db + 120.0f), spr, tk * 4u, sk * 4, 0);
 #endif
         after_slot(s);
     }
@@ -189,19 +236,19 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T) void k_fft_project(const floa
 #endif
 
     double xr[PL::R], xi[PL::R];
+    // Addresses are split into a per-slot part that is the same for every thread (added to the pointer on
+    // the scalar unit) and one 32-bit per-thread offset: no vector instruction per load or store.
+    const unsigned n_thread = (unsigned)fft64::input_sample<LOGN>(t, 0);  // slot bits hold the top sample bits
+    const rsrc_t xrs = make_rsrc(x, PL::N * 8u);
 #pragma unroll
     for (int m = 0; m < PL::R; m++) {
         // four neighbouring lanes read 32 contiguous bytes (fft_f64.h make_layout, pass 0)
 #if defined(SDR_ABLATE) && (SDR_ABLATE == 1 || SDR_ABLATE == 7)
         const float2 v = make_float2(1e-3f * (float)(t + m), 0.5f);  // timing-only build: no input loads
 #else
-#if defined(SDR_FFT_NT) && (SDR_FFT_NT & 1)
-        typedef float v2f __attribute__((ext_vector_type(2)));
-        const v2f nv = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(x + fft64::input_sample<LOGN>(t, m)));
-        const float2 v = make_float2(nv.x, nv.y);
-#else
-        const float2 v = x[fft64::input_sample<LOGN>(t, m)];
-#endif
+        const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(
+            xrs, n_thread * 8u, (fft64::input_sample<LOGN>(0, m) - fft64::input_sample<LOGN>(0, 0)) * 8, 0);
+        const float2 v = make_float2(__uint_as_float(w.x), __uint_as_float(w.y));
 #endif
         xr[m] = (double)v.x;
         xi[m] = (double)v.y;
@@ -226,7 +273,7 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T) void k_fft_project(const floa
         __builtin_amdgcn_global_load_lds(ahead, dump + (t & ~63), 4, 0, 0);
     }
 #endif
-    run_passes<LOGN, 0>(xr, xi, t, tw, lds);
+    run_passes<LOGN, 0>(xr, xi, t, make_rsrc(tw, (unsigned)(PL::TW_TOTAL * sizeof(fft64::cplx))), tw, lds);
 
     float *sp = spectrum + out_frame * PL::N;
     float *pd = psd + out_frame * PL::N;

@@ -29,9 +29,17 @@ struct Passes {
     {
         using PL = Plan<LOGN>;
         for (int t = 0; t < PL::T; t++)
-            butterfly_pass<LOGN, P>(&xr[(size_t)t * PL::R], &xi[(size_t)t * PL::R], t, tw);
+            butterfly_pass<LOGN, P>(&xr[(size_t)t * PL::R], &xi[(size_t)t * PL::R], t,
+                                    [tw](int c, int lo) { return tw[c + lo]; });
         if (P < PL::NPASS - 1) {
             constexpr int E = (P < PL::NPASS - 1 ? P : 0);
+            if constexpr (make_swap_plan<LOGN>(E).ok) {
+                // register exchange (v_permlane16/32_swap on the GPU): modelled wave by wave
+                for (int t0 = 0; t0 < PL::T; t0 += 64) {
+                    exchange_swap_wave<LOGN, E>(reinterpret_cast<double (*)[PL::R]>(&xr[(size_t)t0 * PL::R]));
+                    exchange_swap_wave<LOGN, E>(reinterpret_cast<double (*)[PL::R]>(&xi[(size_t)t0 * PL::R]));
+                }
+            } else {
             // LDS starts each exchange poisoned, so a read of a word nobody wrote yet cannot pass
             std::fill(lds_re.begin(), lds_re.end(), std::nan(""));
             std::fill(lds_im.begin(), lds_im.end(), std::nan(""));
@@ -57,6 +65,7 @@ struct Passes {
                     exchange_read<LOGN, E>(&xr[(size_t)t * PL::R], t, lds_re.data());
                     exchange_read<LOGN, E>(&xi[(size_t)t * PL::R], t, lds_im.data());
                 }
+            }
             }
             Passes<LOGN, (P < PL::NPASS - 1 ? P + 1 : P)>::run_next(xr, xi, tw, lds_re, lds_im);
         }
@@ -101,10 +110,15 @@ struct Audit {
     {
         int w, r, rc = 0;
         audit<LOGN, E>(&w, &r);
-        printf("LOGN=%d exchange %d (%s): worst write %d-way, worst read %d-way\n", LOGN, E,
-               Plan<LOGN>::cross_wave(E) ? "cross-wave" : "wave-local", w, r);
-        if (LOGN >= 10 && (w > 1 || r > 1))
-            rc = 1;  // N = 512 keeps a 2-way write conflict; every other size must be conflict-free
+        if (make_swap_plan<LOGN>(E).ok) {
+            printf("LOGN=%d exchange %d: in registers (lane bit 4 <-> slot bit %d, lane bit 5 <-> slot bit %d)\n", LOGN, E,
+                   make_swap_plan<LOGN>(E).slot_bit_lane4, make_swap_plan<LOGN>(E).slot_bit_lane5);
+        } else {
+            printf("LOGN=%d exchange %d (%s): worst write %d-way, worst read %d-way\n", LOGN, E,
+                   Plan<LOGN>::cross_wave(E) ? "cross-wave" : "wave-local", w, r);
+            if (LOGN >= 10 && (w > 1 || r > 1))
+                rc = 1;  // N = 512 keeps a 2-way write conflict; every other size must be conflict-free
+        }
         if constexpr (E + 1 < Plan<LOGN>::NPASS - 1)
             rc |= Audit<LOGN, E + 1>::run();
         return rc;
