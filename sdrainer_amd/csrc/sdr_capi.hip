@@ -85,7 +85,8 @@ const char *kKernelNames[sdr::K_COUNT] = {"k_fft_project",   "k_window_means", "
 
 constexpr int RING = 4;  // per-batch buffer sets in flight
 enum Stage { S_FFT = 0, S_NOISE, S_LISTEN, S_PEAKS, N_STAGES };
-constexpr int S_THR = N_STAGES;  // event slot of k_thresholds (it runs on the listen stream)
+constexpr int S_THR = N_STAGES;          // event slot of k_thresholds
+constexpr int S_NSTATS = N_STAGES + 1;  // event slot of k_noise_stats
 
 // Everything one batch produces.
 struct BatchSet {
@@ -100,7 +101,7 @@ struct BatchSet {
     DevBuf<float> cum_out;            // [band][max_chunks][N]
     DevBuf<sdr::DevPeak> dev_peaks;   // [band][max_chunks][max_peaks]
     DevBuf<int> peak_counts;          // [band][max_chunks]
-    hipEvent_t done[N_STAGES + 1] = {};  // recorded when the stage has finished with this set
+    hipEvent_t done[N_STAGES + 2] = {};  // recorded when the stage has finished with this set
     void release()
     {
         spectrum.release();
@@ -296,7 +297,26 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
 #define SDR_LAUNCH(id, call) HIP_TRY(call)
 #endif
     hipStream_t s_fft = b->stream[S_FFT], s_noise = b->stream[S_NOISE], s_listen = b->stream[S_LISTEN],
-                s_peaks = b->stream[S_PEAKS], s_thr = s_noise, s_gather = s_noise;
+                s_peaks = b->stream[S_PEAKS], s_thr = s_peaks, s_gather = s_peaks;
+    // Stream plan (the step is as long as the longest stream; in-situ durations, config 3):
+    //   fft    : k_fft_project                                        0.30 ms
+    //   noise  : window means -> noise stats                           0.22 ms
+    //   peaks  : thresholds -> gather -> cumulate -> find peaks        0.23 ms
+    //   listen : decode                                                0.18 ms
+    // With thresholds and gather behind the noise stats on the noise stream, that stream was as long as the
+    // FFT's and set the step (0.311 ms against 0.300 ms).  The cumulation deliberately stays BEHIND them in
+    // the peaks stream although it only needs the spectrum: enqueued first it runs straight after the FFT,
+    // beside the window means, and the step is back at 0.313 ms.
+#if defined(SDR_DIAG)
+    {
+        static const int thr_on = getenv("SDR_DIAG_THR") ? atoi(getenv("SDR_DIAG_THR")) : S_PEAKS;
+        static const int gat_on = getenv("SDR_DIAG_GATHER") ? atoi(getenv("SDR_DIAG_GATHER")) : S_PEAKS;
+        s_thr = b->stream[thr_on];
+        s_gather = b->stream[gat_on];
+        static const int dec_on = getenv("SDR_DIAG_DECODE") ? atoi(getenv("SDR_DIAG_DECODE")) : S_LISTEN;
+        s_listen = b->stream[dec_on];
+    }
+#endif
 
     // stage 0: FFT + projection, once every reader of this set (batch i - RING) is done with it
     // (with RING sets the previous user is four batches back and has almost always finished: ask the
@@ -320,7 +340,10 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         ProfScope ps(b, sdr::K_NOISE_STATS, s_noise);
         SDR_LAUNCH(sdr::K_NOISE_STATS, sdr::launch_noise_stats(S.psd.p, S.win_mean.p, S.recs.p, ng, n_frames, B, stride, s_noise));
     }
-    // rolling means -> thresholds, in batch order (same stream)
+    HIP_TRY(hipEventRecord(S.done[S_NSTATS], s_noise));
+    // rolling means -> thresholds, in batch order (always the same stream)
+    if (s_thr != s_noise)
+        HIP_TRY(hipStreamWaitEvent(s_thr, S.done[S_NSTATS], 0));
     {
         ProfScope ps(b, sdr::K_THRESHOLDS, s_thr);
         SDR_LAUNCH(sdr::K_THRESHOLDS, sdr::launch_thresholds(S.recs.p, b->band_state.p, n_frames, B, stride, s_thr));
