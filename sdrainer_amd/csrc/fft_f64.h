@@ -327,6 +327,82 @@ SDR_HD inline int input_sample(int t, int m)
     return (int)brev_bits((unsigned)elem_index<LOGN, 0>(t, 0, m), LOGN);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Input staging through LDS.  Pass 0 wants lane neighbours 32 bytes apart in memory at best (make_layout),
+// which costs the texture unit four times the cache-line look-ups of a contiguous read.  So the frame is
+// first copied global -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, each wave instruction one
+// contiguous 1 KB row of 128 samples) and then read from LDS in the pass-0 layout.  LDS-DMA writes lane l's
+// 16 bytes at row base + 16*l, so the image is shaped through the SOURCE address: lane p of row r fetches
+// granule g = in_granule(p, r) (a granule = 2 samples = 16 bytes); the XOR swizzle spreads the rows and
+// row halves that the 32 lanes of a ds_read_b64 group touch over the LDS banks.
+//   sample n  ->  row r = n >> 7, granule g = (n >> 1) & 63, byte address r*1024 + in_pos(g, r)*16 + (n & 1)*8
+// ---------------------------------------------------------------------------------------------
+struct InSwz {
+    int src[3];  // position bit 1+k is XORed with: -1 nothing, 0..5 granule bit, 8+j row bit j
+};
+
+template <int LOGN>
+SDR_HD constexpr InSwz make_in_swz()
+{
+    const Layout L0 = make_layout<LOGN>(0);
+    InSwz z{{-1, -1, -1}};
+    for (int k = 0; k < 3; k++) {
+        const int nb = LOGN - 1 - L0.tbit[2 + k];  // sample-number bit behind lane bit 2+k
+        if (nb >= 7)
+            z.src[k] = 8 + (nb - 7);
+        else if (nb - 1 != 1 + k)
+            z.src[k] = nb - 1;
+    }
+    return z;
+}
+
+template <int LOGN>
+SDR_HD constexpr bool in_swz_solvable()
+{
+    const InSwz z = make_in_swz<LOGN>();
+    for (int k = 0; k < 3; k++)
+        if (z.src[k] >= 0 && z.src[k] < 8 && z.src[k] <= 1 + k)
+            return false;  // a position bit may only depend on higher granule bits (in_granule solves downwards)
+    return true;
+}
+
+template <int LOGN>
+SDR_HD inline int in_pos(int g, int r)
+{
+    constexpr InSwz Z = make_in_swz<LOGN>();
+    int p = g;
+    for (int k = 0; k < 3; k++) {
+        if (Z.src[k] >= 8)
+            p ^= ((r >> (Z.src[k] - 8)) & 1) << (1 + k);
+        else if (Z.src[k] >= 0)
+            p ^= ((g >> Z.src[k]) & 1) << (1 + k);
+    }
+    return p;
+}
+
+template <int LOGN>
+SDR_HD inline int in_granule(int p, int r)
+{
+    static_assert(in_swz_solvable<LOGN>(), "input swizzle is not triangular");
+    constexpr InSwz Z = make_in_swz<LOGN>();
+    int g = p;
+    for (int k = 2; k >= 0; k--) {
+        if (Z.src[k] >= 8)
+            g ^= ((r >> (Z.src[k] - 8)) & 1) << (1 + k);
+        else if (Z.src[k] >= 0)
+            g ^= ((g >> Z.src[k]) & 1) << (1 + k);  // bit src[k] > 1+k is final already
+    }
+    return g;
+}
+
+// byte address in the staging image of sample n
+template <int LOGN>
+SDR_HD inline int in_lds_byte(int n)
+{
+    const int r = n >> 7, g = (n >> 1) & 63;
+    return r * 1024 + in_pos<LOGN>(g, r) * 16 + (n & 1) * 8;
+}
+
 // Pass 0 input: slot m <- x[input_sample(t, m)], widened to float64
 // (dsp/fft.go:59-69 setSamplesFromIQ).
 template <int LOGN>

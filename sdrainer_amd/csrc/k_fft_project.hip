@@ -236,23 +236,51 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T) void k_fft_project(const floa
 #endif
 
     double xr[PL::R], xi[PL::R];
-    // Addresses are split into a per-slot part that is the same for every thread (added to the pointer on
-    // the scalar unit) and one 32-bit per-thread offset: no vector instruction per load or store.
+#if defined(SDR_FFT_DIRECT_LOADS)
+    // (diagnostic builds) straight into registers: four neighbouring lanes read 32 contiguous bytes
     const unsigned n_thread = (unsigned)fft64::input_sample<LOGN>(t, 0);  // slot bits hold the top sample bits
     const rsrc_t xrs = make_rsrc(x, PL::N * 8u);
 #pragma unroll
     for (int m = 0; m < PL::R; m++) {
-        // four neighbouring lanes read 32 contiguous bytes (fft_f64.h make_layout, pass 0)
-#if defined(SDR_ABLATE) && (SDR_ABLATE == 1 || SDR_ABLATE == 7)
-        const float2 v = make_float2(1e-3f * (float)(t + m), 0.5f);  // timing-only build: no input loads
-#else
         const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(
             xrs, n_thread * 8u, (fft64::input_sample<LOGN>(0, m) - fft64::input_sample<LOGN>(0, 0)) * 8, 0);
-        const float2 v = make_float2(__uint_as_float(w.x), __uint_as_float(w.y));
-#endif
-        xr[m] = (double)v.x;
-        xi[m] = (double)v.y;
+        xr[m] = (double)__uint_as_float(w.x);
+        xi[m] = (double)__uint_as_float(w.y);
     }
+#else
+    // Frame -> LDS by LDS-DMA, one contiguous 1 KB row per wave instruction, shaped through the source address
+    // (fft_f64.h "Input staging"); then every thread picks its 16 samples out of LDS in the pass-0 layout.  The
+    // staging image lives in the exchange area, which nobody needs before the first exchange.
+    {
+        constexpr int ROWS_PER_WAVE = PL::R / 2;
+        const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+        const float *xf = reinterpret_cast<const float *>(x);
+#pragma unroll
+        for (int j = 0; j < ROWS_PER_WAVE; j++) {
+            const int r = wave * ROWS_PER_WAVE + j;
+            const int g = fft64::in_granule<LOGN>(lane, r);
+            __builtin_amdgcn_global_load_lds(xf + ((size_t)r * 128 + 2 * g) * 2, smem + r * 1024, 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int n_thread = fft64::input_sample<LOGN>(t, 0);
+        const int thread_byte = fft64::in_lds_byte<LOGN>(n_thread);
+#pragma unroll
+        for (int m = 0; m < PL::R; m++) {
+#if defined(SDR_ABLATE) && (SDR_ABLATE == 1 || SDR_ABLATE == 7)
+            const float2 v = make_float2(1e-3f * (float)(t + m), 0.5f);  // timing-only build: no input
+#else
+            // sample number -> image address is linear over GF(2): thread part and slot part combine by XOR,
+            // and the slot part is a compile-time constant
+            const int slot_byte = fft64::in_lds_byte<LOGN>(fft64::input_sample<LOGN>(0, m));
+            const float2 v = *reinterpret_cast<const float2 *>(smem + (thread_byte ^ slot_byte));
+#endif
+            xr[m] = (double)v.x;
+            xi[m] = (double)v.y;
+        }
+        __syncthreads();  // everyone has its samples: the exchange area may be written again
+    }
+#endif
 #if defined(SDR_FFT_TRACE)
     asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
     SDR_STAMP(12);

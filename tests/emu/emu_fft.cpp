@@ -140,6 +140,50 @@ static int audit_loads()
     return 0;
 }
 
+// Input staging (fft_f64.h in_granule / in_lds_byte): replay the LDS-DMA image row by row and check that every
+// thread finds its 16 samples, that every 1 KB row is read from one contiguous kilobyte of the frame, and that
+// no ds_read_b64 group (32 lanes, 64 four-byte banks) has a bank conflict.
+template <int LOGN>
+static int audit_staging()
+{
+    using PL = Plan<LOGN>;
+    const int N = PL::N, rows = N / 128;
+    std::vector<int> image((size_t)N, -1);  // image[byte / 8] = sample number stored there
+    for (int r = 0; r < rows; r++)
+        for (int p = 0; p < 64; p++) {
+            const int g = in_granule<LOGN>(p, r);
+            if (g < 0 || g >= 64) {
+                printf("LOGN=%d: row %d lane %d fetches granule %d\n", LOGN, r, p, g);
+                return 1;
+            }
+            image[(size_t)(r * 1024 + p * 16) / 8] = r * 128 + 2 * g;
+            image[(size_t)(r * 1024 + p * 16) / 8 + 1] = r * 128 + 2 * g + 1;
+        }
+    int worst = 0;
+    for (int m = 0; m < PL::R; m++)
+        for (int t0 = 0; t0 < PL::T; t0 += 32) {
+            int cnt[32] = {};
+            for (int t = t0; t < t0 + 32; t++) {
+                const int n = input_sample<LOGN>(t, m);
+                const int a = in_lds_byte<LOGN>(n);
+                if (a % 8 || image[(size_t)a / 8] != n) {
+                    printf("LOGN=%d: thread %d slot %d reads byte %d, which holds sample %d, not %d\n", LOGN, t, m, a,
+                           image[(size_t)a / 8], n);
+                    return 1;
+                }
+                // the kernel combines the thread's slot-0 address with a per-slot constant by XOR
+                const int combined = in_lds_byte<LOGN>(input_sample<LOGN>(t, 0)) ^ in_lds_byte<LOGN>(input_sample<LOGN>(0, m));
+                if (combined != a) {
+                    printf("LOGN=%d: thread %d slot %d: combined address %d != %d\n", LOGN, t, m, combined, a);
+                    return 1;
+                }
+                worst = std::max(worst, ++cnt[(a / 8) % 32]);
+            }
+        }
+    printf("LOGN=%d input staging: %d rows, worst ds_read_b64 conflict %d-way\n", LOGN, rows, worst);
+    return worst > 1;
+}
+
 template <int LOGN>
 static int check(orc_iq_fft_t orc_fft, orc_factors_t orc_fac, unsigned seed)
 {
@@ -201,6 +245,7 @@ static int check(orc_iq_fft_t orc_fft, orc_factors_t orc_fac, unsigned seed)
     int rc = bad != 0;
     rc |= Audit<LOGN, 0>::run();
     rc |= audit_loads<LOGN>();
+    rc |= audit_staging<LOGN>();
     return rc;
 }
 
