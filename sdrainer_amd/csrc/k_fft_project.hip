@@ -8,8 +8,8 @@
 #include "gomath.h"
 #include "sdr_device.h"
 
-#if !defined(SDR_FFT_PREFETCH_DIST)
-#define SDR_FFT_PREFETCH_DIST 0
+#if !defined(SDR_FFT_DMA_AUX)
+#define SDR_FFT_DMA_AUX 2  // cache policy bits of the input LDS-DMA: nt - a frame is read once, by one CU (0.198 vs 0.202 ms)
 #endif
 
 namespace sdr {
@@ -259,10 +259,12 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T) void k_fft_project(const floa
         for (int j = 0; j < ROWS_PER_WAVE; j++) {
             const int r = wave * ROWS_PER_WAVE + j;
             const int g = fft64::in_granule<LOGN>(lane, r);
-            __builtin_amdgcn_global_load_lds(xf + ((size_t)r * 128 + 2 * g) * 2, smem + r * 1024, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(xf + ((size_t)r * 128 + 2 * g) * 2, smem + r * 1024, 16, 0, SDR_FFT_DMA_AUX);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SDR_STAMP(12);  // this wave's rows have landed
         __syncthreads();
+        SDR_STAMP(13);  // everybody's have
         const int n_thread = fft64::input_sample<LOGN>(t, 0);
         const int thread_byte = fft64::in_lds_byte<LOGN>(n_thread);
 #pragma unroll
@@ -281,26 +283,7 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T) void k_fft_project(const floa
         __syncthreads();  // everyone has its samples: the exchange area may be written again
     }
 #endif
-#if defined(SDR_FFT_TRACE)
-    asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-    SDR_STAMP(12);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    SDR_STAMP(13);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     SDR_STAMP(1);
-#if SDR_FFT_PREFETCH_DIST > 0 && !defined(SDR_FFT_TRACE)
-    // Warm L2 for a later workgroup: every thread touches one 128-byte line of the frame
-    // SDR_FFT_PREFETCH_DIST ahead (a multiple of 8, so it is dispatched to this XCD and its L2), as an
-    // LDS-DMA load of 4 bytes into a dump area: no register is held and nothing ever waits for it.  A
-    // frame read from HBM cold costs its workgroup about 4 us before the first butterfly; nothing else
-    // can cover that time on a CU that holds a single workgroup.
-    if (blockIdx.x + SDR_FFT_PREFETCH_DIST < gridDim.x) {
-        const float *ahead = reinterpret_cast<const float *>(x + (size_t)SDR_FFT_PREFETCH_DIST * PL::N) + t * 32;
-        __shared__ float dump[PL::T];
-        __builtin_amdgcn_global_load_lds(ahead, dump + (t & ~63), 4, 0, 0);
-    }
-#endif
     run_passes<LOGN, 0>(xr, xi, t, make_rsrc(tw, (unsigned)(PL::TW_TOTAL * sizeof(fft64::cplx))), tw, lds);
 
     float *sp = spectrum + out_frame * PL::N;

@@ -58,7 +58,7 @@ int main()
         if (tr[w][0] < t0)
             t0 = tr[w][0];
     const char *names[12] = {"start", "loaded", "pass0", "ex0", "pass1", "ex1", "pass2", "ex2", "pass3", "-", "stored", "drained"};
-    printf("input loads: first / ninth / last sample back, per wave (us):\n");
+    printf("input staging: own rows landed / all rows landed / samples in registers, per wave (us):\n");
     for (int w = 0; w < 16; w++)
         printf("  wave %2d: %6.2f %6.2f %6.2f\n", w, (double)(tr[w][12] - t0) / 100.0, (double)(tr[w][13] - t0) / 100.0,
                (double)(tr[w][1] - t0) / 100.0);
