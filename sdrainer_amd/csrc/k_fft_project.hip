@@ -2,6 +2,8 @@
 // Compiled with -ffp-contract=off (see gomath.h).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/sdrainer_hip.h"
 #include "cw_decoder.h"
 #include "fft_f64.h"
@@ -66,7 +68,7 @@ constexpr bool later_lds_exchange(int e)
     return false;
 }
 
-template <int LOGN, int P>
+template <int LOGN, int P, bool FRAME_FOLLOWS = false>
 __device__ __forceinline__ void run_passes(double (&xr)[fft64::Plan<LOGN>::R], double (&xi)[fft64::Plan<LOGN>::R],
                                            int t, rsrc_t tw, const fft64::cplx *__restrict__ tw_ptr, double *lds)
 {
@@ -120,11 +122,12 @@ __device__ __forceinline__ void run_passes(double (&xr)[fft64::Plan<LOGN>::R], d
                 fft64::exchange_read<LOGN, P>(xi, t, lds + PL::N);
             }
             // reads done before a later exchange writes LDS again (other waves' words if CROSS)
-            if constexpr (later_lds_exchange<LOGN>(P))
+            // ... or the next frame's staging does
+            if constexpr (later_lds_exchange<LOGN>(P) || FRAME_FOLLOWS)
                 sync();
         }
         SDR_STAMP(3 + 2 * P);
-        run_passes<LOGN, P + 1>(xr, xi, t, tw, tw_ptr, lds);
+        run_passes<LOGN, P + 1, FRAME_FOLLOWS>(xr, xi, t, tw, tw_ptr, lds);
     }
 }
 
@@ -193,78 +196,72 @@ __device__ __forceinline__ void project_and_store(const double (&xr)[fft64::Plan
 // over frames, the next frame's samples prefetched into the registers the projection frees, workgroups
 // started staggered or not - measured 5 % slower at N = 16384: 0.223 against 0.212 ms for 2048 frames,
 // and it keeps the other pipeline stages off the CUs: 0.46 against 0.36 ms per pipelined step.)
-template <int LOGN>
+// FPW frames per workgroup, one after the other; the default is 1.  With FPW = 2 (SDR_FFT_FPW=2) the second
+// frame's LDS-DMA is issued when the first frame's last butterfly pass is done (LDS is idle from the cross-wave
+// exchange on, the DMA needs no registers, and the projection that follows has no loads the DMA could hold
+// up), so its HBM latency is covered by the first frame's projection, and there is one dispatch gap per two
+// frames.  Measured at N = 16384: 0.189 against 0.192 ms standalone, but 0.282 against 0.275 ms per pipelined
+// step (the tail stages get a CU only every other frame) - hence the default.
+template <int LOGN, int FPW>
 __global__ __launch_bounds__(fft64::Plan<LOGN>::T) void k_fft_project(const float *__restrict__ iq,
                                                                       const fft64::cplx *__restrict__ tw,
                                                                       float *__restrict__ spectrum,
                                                                       float *__restrict__ psd, double inv_n2,
-                                                                      int in_stride, int out_stride)
+                                                                      int in_stride, int out_stride, int n_frames)
 {
     using PL = fft64::Plan<LOGN>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *lds = reinterpret_cast<double *>(smem);
     // the 64-entry table of the certified fast dB path (gomath.h) follows the twiddles in HBM and sits
-    // behind the exchange area in LDS; the cross-wave exchange's barriers publish it long before the
-    // epilogue (a single-wave frame has none: it gets its own)
+    // behind the exchange area in LDS; the staging barriers publish it long before the epilogue
     gomath::LogTabEntry *ltab = reinterpret_cast<gomath::LogTabEntry *>(smem + PL::LDS_BYTES);
-    const int t = threadIdx.x;
     SDR_STAMP(0);
-#if defined(SDR_FFT_PRIO)
-    {
-        const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-        const int pr = SDR_FFT_PRIO == 1 ? (w >> 2) & 3 : w & 3;
-        if (pr == 1)
-            __builtin_amdgcn_s_setprio(1);
-        else if (pr == 2)
-            __builtin_amdgcn_s_setprio(2);
-        else if (pr == 3)
-            __builtin_amdgcn_s_setprio(3);
-    }
-#endif
-    if (t < gomath::kLogTabSize)
-        ltab[t] = reinterpret_cast<const gomath::LogTabEntry *>(tw + PL::TW_TOTAL)[t];
-    if constexpr (PL::WB == 0)
-        __syncthreads();
-    const size_t in_frame = (size_t)blockIdx.y * in_stride + blockIdx.x;
-    const size_t out_frame = (size_t)blockIdx.y * out_stride + blockIdx.x;
-#if defined(SDR_ABLATE) && (SDR_ABLATE == 8)
-    const float2 *x = reinterpret_cast<const float2 *>(iq) + (in_frame & 15) * PL::N;  // timing-only: 16 frames, L2-resident
-#elif defined(SDR_ABLATE) && (SDR_ABLATE == 9)
-    const float2 *x = reinterpret_cast<const float2 *>(iq) + ((in_frame * 7) & 2047) * PL::N;  // timing-only: scattered order
-#else
-    const float2 *x = reinterpret_cast<const float2 *>(iq) + in_frame * PL::N;
-#endif
+    if (threadIdx.x < gomath::kLogTabSize)
+        ltab[threadIdx.x] = reinterpret_cast<const gomath::LogTabEntry *>(tw + PL::TW_TOTAL)[threadIdx.x];
+    const int frame0 = blockIdx.x * FPW;
+    const size_t in_band = (size_t)blockIdx.y * in_stride, out_band = (size_t)blockIdx.y * out_stride;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
 
-    double xr[PL::R], xi[PL::R];
-#if defined(SDR_FFT_DIRECT_LOADS)
-    // (diagnostic builds) straight into registers: four neighbouring lanes read 32 contiguous bytes
-    const unsigned n_thread = (unsigned)fft64::input_sample<LOGN>(t, 0);  // slot bits hold the top sample bits
-    const rsrc_t xrs = make_rsrc(x, PL::N * 8u);
-#pragma unroll
-    for (int m = 0; m < PL::R; m++) {
-        const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(
-            xrs, n_thread * 8u, (fft64::input_sample<LOGN>(0, m) - fft64::input_sample<LOGN>(0, 0)) * 8, 0);
-        xr[m] = (double)__uint_as_float(w.x);
-        xi[m] = (double)__uint_as_float(w.y);
-    }
-#else
     // Frame -> LDS by LDS-DMA, one contiguous 1 KB row per wave instruction, shaped through the source address
-    // (fft_f64.h "Input staging"); then every thread picks its 16 samples out of LDS in the pass-0 layout.  The
-    // staging image lives in the exchange area, which nobody needs before the first exchange.
-    {
+    // (fft_f64.h "Input staging").  The staging image lives in the exchange area.
+    auto stage_frame = [&](int frame, int tid) {
         constexpr int ROWS_PER_WAVE = PL::R / 2;
-        const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
-        const float *xf = reinterpret_cast<const float *>(x);
+        const int lane = tid & 63;
+#if defined(SDR_ABLATE) && (SDR_ABLATE == 8)
+        const size_t fr = (in_band + frame) & 15;  // timing-only: 16 frames, L2-resident
+#else
+        const size_t fr = in_band + frame;
+#endif
+        // buffer form: row in the scalar offset, granule in one 32-bit VGPR - no 64-bit per-lane addresses
+        const rsrc_t xrs = make_rsrc(iq + fr * PL::N * 2, PL::N * 8u);
 #pragma unroll
         for (int j = 0; j < ROWS_PER_WAVE; j++) {
             const int r = wave * ROWS_PER_WAVE + j;
             const int g = fft64::in_granule<LOGN>(lane, r);
-            __builtin_amdgcn_global_load_lds(xf + ((size_t)r * 128 + 2 * g) * 2, smem + r * 1024, 16, 0, SDR_FFT_DMA_AUX);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void *)(smem + r * 1024), 16,
+                                                     (unsigned)g * 16u, r * 1024, 0, SDR_FFT_DMA_AUX);
         }
+    };
+    stage_frame(frame0, threadIdx.x);
+
+#pragma nounroll
+    for (int k = 0; k < FPW; k++) {
+        const int frame = frame0 + k;
+        if (frame >= n_frames)
+            break;
+        // (with more than one frame per workgroup everything derived from the thread id is loop-invariant and the
+        // compiler would hoist - and spill - it: make the thread id opaque per frame)
+        int t = threadIdx.x;
+        if constexpr (FPW > 1)
+            asm volatile("" : "+v"(t));
+        // loads and stores share one counter and may complete out of order with respect to each other, so the
+        // wait for the DMA is a full drain (for the second frame that includes the first frame's last stores)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         SDR_STAMP(12);  // this wave's rows have landed
         __syncthreads();
         SDR_STAMP(13);  // everybody's have
+
+        double xr[PL::R], xi[PL::R];
         const int n_thread = fft64::input_sample<LOGN>(t, 0);
         const int thread_byte = fft64::in_lds_byte<LOGN>(n_thread);
 #pragma unroll
@@ -281,24 +278,31 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T) void k_fft_project(const floa
             xi[m] = (double)v.y;
         }
         __syncthreads();  // everyone has its samples: the exchange area may be written again
-    }
-#endif
-    SDR_STAMP(1);
-    run_passes<LOGN, 0>(xr, xi, t, make_rsrc(tw, (unsigned)(PL::TW_TOTAL * sizeof(fft64::cplx))), tw, lds);
+        SDR_STAMP(1);
+        run_passes<LOGN, 0, (FPW > 1)>(xr, xi, t, make_rsrc(tw, (unsigned)(PL::TW_TOTAL * sizeof(fft64::cplx))), tw, lds);
 
-    float *sp = spectrum + out_frame * PL::N;
-    float *pd = psd + out_frame * PL::N;
+        if constexpr (FPW > 1) {
+            // the butterflies are done (their twiddle loads with them); nobody touches the exchange area any more
+            // (run_passes ends its last LDS exchange with a barrier when a frame follows)
+            // (no scheduling pin here: the compiler keeps the DMA behind the exchanges' LDS accesses and behind the
+            // twiddle loads already issued, which it waits for with counted vmcnt; a "memory" pin cost 46 spills)
+            if (k + 1 < FPW && frame + 1 < n_frames)
+                stage_frame(frame + 1, t);
+        }
+        float *sp = spectrum + (out_band + frame) * PL::N;
+        float *pd = psd + (out_band + frame) * PL::N;
 #if defined(SDR_ABLATE) && (SDR_ABLATE == 4)
 #pragma unroll
-    for (int s = 0; s < PL::R; s++) {  // timing-only build: no projection
-        const int k = fft64::output_bin<LOGN>(t, s);
-        pd[k] = (float)xr[s];
-        sp[k] = (float)xi[s];
-    }
+        for (int s = 0; s < PL::R; s++) {  // timing-only build: no projection
+            const int kk = fft64::output_bin<LOGN>(t, s);
+            pd[kk] = (float)xr[s];
+            sp[kk] = (float)xi[s];
+        }
 #else
-    project_and_store<LOGN>(xr, xi, t, sp, pd, inv_n2, ltab, [](int) {});
+        project_and_store<LOGN>(xr, xi, t, sp, pd, inv_n2, ltab, [](int) {});
 #endif
-    SDR_STAMP(10);
+        SDR_STAMP(10);
+    }
 #if defined(SDR_FFT_TRACE)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -313,16 +317,27 @@ static hipError_t launch_fft_t(const float *iq, const fft64::cplx *tw, float *sp
 {
     using PL = fft64::Plan<LOGN>;
     static bool attr_set = false;
+    static int fpw = 1;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_project<LOGN>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, PL::LDS_BYTES + kLogTabBytes);
-        if (e != hipSuccess)
-            return e;
+        for (const void *k : {reinterpret_cast<const void *>(&k_fft_project<LOGN, 1>),
+                              reinterpret_cast<const void *>(&k_fft_project<LOGN, 2>)}) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, PL::LDS_BYTES + kLogTabBytes);
+            if (e != hipSuccess)
+                return e;
+        }
+        if (const char *e = getenv("SDR_FFT_FPW"))  // frames per workgroup: 1 (default) or 2
+            fpw = atoi(e) == 2 ? 2 : 1;
         attr_set = true;
     }
     const double inv_n2 = 1.0 / ((double)PL::N * (double)PL::N);
-    hipLaunchKernelGGL(k_fft_project<LOGN>, dim3(n_frames, n_bands), dim3(PL::T), PL::LDS_BYTES + kLogTabBytes, stream, iq, tw,
-                       spectrum, psd, inv_n2, in_stride, out_stride);
+    if (n_frames <= 0 || n_bands <= 0)
+        return hipSuccess;
+    if (fpw == 2)
+        hipLaunchKernelGGL((k_fft_project<LOGN, 2>), dim3((n_frames + 1) / 2, n_bands), dim3(PL::T), PL::LDS_BYTES + kLogTabBytes,
+                           stream, iq, tw, spectrum, psd, inv_n2, in_stride, out_stride, n_frames);
+    else
+        hipLaunchKernelGGL((k_fft_project<LOGN, 1>), dim3(n_frames, n_bands), dim3(PL::T), PL::LDS_BYTES + kLogTabBytes, stream, iq,
+                           tw, spectrum, psd, inv_n2, in_stride, out_stride, n_frames);
     return hipGetLastError();
 }
 
