@@ -57,5 +57,5 @@ json.dump(doc, open(tpath, "w"), indent=1)
 shutil.copy(os.path.join(G, "bench_full.log"), os.path.join(P, f"{tag}_bench_{key}.json"))
 shutil.copy(os.path.join(G, "bench_serial.err"), os.path.join(P, f"{tag}_kernel_breakdown_serial.txt"))
 for r in out[1:]:
-    print(r[0].split("(")[0][-28:], "calls", r[1], "avg_ns", r[3])
+    print(r[0].split("(")[0].replace("void ", "")[:40], "calls", r[1], "avg_ns", r[3])
 print(json.dumps(tab[fft]))
