@@ -10,6 +10,12 @@
 #include "gomath.h"
 #include "sdr_device.h"
 
+#if !defined(SDR_FFT_PSD_AUX)
+#define SDR_FFT_PSD_AUX 0  // cache policy bits of the psd / spectrum stores (2 = nt)
+#endif
+#if !defined(SDR_FFT_SPEC_AUX)
+#define SDR_FFT_SPEC_AUX 0
+#endif
 #if !defined(SDR_FFT_DMA_AUX)
 #define SDR_FFT_DMA_AUX 2  // cache policy bits of the input LDS-DMA: nt - a frame is read once, by one CU (0.198 vs 0.202 ms)
 #endif
@@ -163,18 +169,12 @@ __device__ __forceinline__ void project_and_store(const double (&xr)[fft64::Plan
             pd[tk | sk] = p;
             sp[tk | sk] = db;
         }
-#elif defined(SDR_FFT_NT) && (SDR_FFT_NT & 2)
-        __builtin_nontemporal_store(p, pd + (tk | sk));
-        float db = 0.0f;
-        if (!gomath::psd_value_in_db_fast(p, inv_n2, ltab, &db))
-            redo |= 1u << s;
-        __builtin_nontemporal_store(db + 120.0f, sp + (tk | sk));
 #else
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(p), pdr, tk * 4u, sk * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(p), pdr, tk * 4u, sk * 4, SDR_FFT_PSD_AUX);
         float db = 0.0f;
         if (!gomath::psd_value_in_db_fast(p, inv_n2, ltab, &db))
             redo |= 1u << s;
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(db + 120.0f), spr, tk * 4u, sk * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(db + 120.0f), spr, tk * 4u, sk * 4, SDR_FFT_SPEC_AUX);
 #endif
         after_slot(s);
     }
