@@ -6,8 +6,8 @@
 // over a bit-reversed copy of the input.  Any schedule that evaluates that same graph with the same
 // IEEE operations (complex multiply as (ac-bd, ad+bc), no FMA contraction) and the same twiddle
 // VALUES produces the same bits.  So each thread keeps R = 16 (8 for N=512) points in VGPRs and runs
-// LOGR consecutive stages on them (a "pass"), then the workgroup transposes through LDS for the next
-// pass.  Twiddles are never recomputed on the device: the host builds go-dsp's table (radix2 factors
+// LOGR consecutive stages on them (a "pass"), then the data is exchanged for the next pass - inside a
+// wave's own block of LDS, across waves through LDS (once), or in registers (make_layout, make_swap_plan).  Twiddles are never recomputed on the device: the host builds go-dsp's table (radix2 factors
 // via math.Sincos, even entries copied from the half-size table) and uploads it re-laid-out per pass
 // so a wave reads them with coalesced 16-byte loads.
 //

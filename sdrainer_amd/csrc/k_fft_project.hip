@@ -192,10 +192,11 @@ __device__ __forceinline__ void project_and_store(const double (&xr)[fft64::Plan
     }
 }
 
-// One workgroup per frame.  (A persistent variant - the grid sized to the chip, each workgroup walking
-// over frames, the next frame's samples prefetched into the registers the projection frees, workgroups
-// started staggered or not - measured 5 % slower at N = 16384: 0.223 against 0.212 ms for 2048 frames,
-// and it keeps the other pipeline stages off the CUs: 0.46 against 0.36 ms per pipelined step.)
+// (A persistent variant - the grid sized to the chip, each workgroup walking over frames, the next frame's
+// samples prefetched into the registers the projection frees, workgroups started staggered or not - measured
+// 5 % slower at N = 16384: 0.223 against 0.212 ms for 2048 frames, and it keeps the other pipeline stages off
+// the CUs: 0.46 against 0.36 ms per pipelined step.)
+//
 // FPW frames per workgroup, one after the other; the default is 1.  With FPW = 2 (SDR_FFT_FPW=2) the second
 // frame's LDS-DMA is issued when the first frame's last butterfly pass is done (LDS is idle from the cross-wave
 // exchange on, the DMA needs no registers, and the projection that follows has no loads the DMA could hold
