@@ -24,10 +24,11 @@ namespace sdr {
 
 // Development aid (tools/fft_trace.hip): per-wave time stamps of one workgroup's phases.
 #if defined(SDR_FFT_TRACE)
-#define SDR_STAMP(k)                                                                      \
-    do {                                                                                  \
-        if (blockIdx.x == SDR_FFT_TRACE && (threadIdx.x & 63) == 0)                       \
-            g_fft_trace[threadIdx.x >> 6][k] = wall_clock64();                            \
+__shared__ int s_fft_trace_frame;  // which of the workgroup's frames is being stamped
+#define SDR_STAMP(k)                                                                                  \
+    do {                                                                                              \
+        if (blockIdx.x == SDR_FFT_TRACE && (threadIdx.x & 63) == 0)                                   \
+            g_fft_trace[s_fft_trace_frame & 1][threadIdx.x >> 6][k] = wall_clock64();                 \
     } while (0)
 #else
 #define SDR_STAMP(k) \
@@ -216,6 +217,10 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T) void k_fft_project(const floa
     // the 64-entry table of the certified fast dB path (gomath.h) follows the twiddles in HBM and sits
     // behind the exchange area in LDS; the staging barriers publish it long before the epilogue
     gomath::LogTabEntry *ltab = reinterpret_cast<gomath::LogTabEntry *>(smem + PL::LDS_BYTES);
+#if defined(SDR_FFT_TRACE)
+    if ((threadIdx.x & 63) == 0)
+        s_fft_trace_frame = 0;
+#endif
     SDR_STAMP(0);
     if (threadIdx.x < gomath::kLogTabSize)
         ltab[threadIdx.x] = reinterpret_cast<const gomath::LogTabEntry *>(tw + PL::TW_TOTAL)[threadIdx.x];
@@ -250,6 +255,10 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T) void k_fft_project(const floa
         const int frame = frame0 + k;
         if (frame >= n_frames)
             break;
+#if defined(SDR_FFT_TRACE)
+        if ((threadIdx.x & 63) == 0)
+            s_fft_trace_frame = k;  // (every wave writes the same value; its own lane 0 reads it back)
+#endif
         // (with more than one frame per workgroup everything derived from the thread id is loop-invariant and the
         // compiler would hoist - and spill - it: make the thread id opaque per frame)
         int t = threadIdx.x;

@@ -9,7 +9,7 @@
 #if !defined(SDR_ABLATE)
 #define SDR_FFT_TRACE 1000
 #endif
-__device__ unsigned long long g_fft_trace[16][16];
+__device__ unsigned long long g_fft_trace[2][16][16];
 #include "../sdrainer_amd/csrc/k_fft_project.hip"
 #include "../sdrainer_amd/csrc/twiddles.h"
 
@@ -51,28 +51,31 @@ int main()
 #if defined(SDR_ABLATE)
     return 0;
 #endif
-    unsigned long long tr[16][16];
-    hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_fft_trace), sizeof tr);
+    unsigned long long tr2[2][16][16];
+    hipMemcpyFromSymbol(tr2, HIP_SYMBOL(g_fft_trace), sizeof tr2);
     unsigned long long t0 = ~0ull;
     for (int w = 0; w < 16; w++)
-        if (tr[w][0] < t0)
-            t0 = tr[w][0];
-    const char *names[12] = {"start", "loaded", "pass0", "ex0", "pass1", "ex1", "pass2", "ex2", "pass3", "-", "stored", "drained"};
-    printf("input staging: own rows landed / all rows landed / samples in registers, per wave (us):\n");
-    for (int w = 0; w < 16; w++)
-        printf("  wave %2d: %6.2f %6.2f %6.2f\n", w, (double)(tr[w][12] - t0) / 100.0, (double)(tr[w][13] - t0) / 100.0,
-               (double)(tr[w][1] - t0) / 100.0);
-    printf("wave ");
-    for (int k = 0; k < 12; k++)
-        if (k != 9)
+        if (tr2[0][w][0] && tr2[0][w][0] < t0)
+            t0 = tr2[0][w][0];
+    const char *names[14] = {"start", "loaded", "pass0", "ex0", "pass1", "ex1", "pass2", "ex2", "pass3", "-", "stored", "drained", "landed", "all"};
+    const int order[] = {0, 12, 13, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11};
+    const int frames_per_wg = getenv("SDR_FFT_FPW") && atoi(getenv("SDR_FFT_FPW")) == 2 ? 2 : 1;
+    for (int f = 0; f < frames_per_wg; f++) {
+        printf("frame %d of the workgroup (us since its first wave started; 100 MHz clock)\nwave ", f);
+        for (int k : order)
             printf("%8s", names[k]);
-    printf("   (us since the workgroup's first wave started; 100 MHz clock)\n");
-    for (int w = 0; w < 16; w++) {
-        printf("%4d ", w);
-        for (int k = 0; k < 12; k++)
-            if (k != 9)
-                printf("%8.2f", (double)(tr[w][k] - t0) / 100.0);
         printf("\n");
+        for (int w = 0; w < 16; w++) {
+            printf("%4d ", w);
+            for (int k : order) {
+                const unsigned long long v = tr2[f][w][k];
+                if (v >= t0)
+                    printf("%8.2f", (double)(v - t0) / 100.0);
+                else
+                    printf("%8s", "-");
+            }
+            printf("\n");
+        }
     }
     return 0;
 }
