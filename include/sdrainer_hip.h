@@ -141,7 +141,8 @@ int sdr_process_staged(sdr_bank *bank, int *n_frames_out);
  * reference attaches a new listener: rx/receiver.go:409-426). */
 int sdr_process_staged_limit(sdr_bank *bank, int max_frames, int *n_frames_out);
 /* Processes n_frames per band of IQ already in device memory, layout [band][frame][block_size][2]
- * float32 (band stride = n_frames*2*block_size floats).  Asynchronous on the bank's stream. */
+ * float32 (band stride = n_frames*2*block_size floats), 16-byte aligned (SDR_ERR_BAD_ARG otherwise).
+ * Asynchronous on the bank's stream. */
 int sdr_process_device(sdr_bank *bank, const float *iq_dev, int n_frames);
 /* Blocks until everything queued on the bank's stream has finished. */
 int sdr_sync(sdr_bank *bank);

@@ -729,6 +729,8 @@ int sdr_process_device(sdr_bank *b, const float *iq_dev, int n_frames)
 {
     if (!b || !iq_dev)
         return fail(SDR_ERR_BAD_ARG, "null argument");
+    if (reinterpret_cast<uintptr_t>(iq_dev) & 15)
+        return fail(SDR_ERR_BAD_ARG, "iq_dev must be 16-byte aligned (frames are copied to LDS 16 bytes per lane)");
     return process_device_impl(b, iq_dev, n_frames, n_frames);
 }
 

@@ -269,6 +269,10 @@ def test_device_resident_input_and_profile(capi):
     ref = orc.Receiver(rate, n, synth.default_edge_width(n))
     out = ref.process(iq)
     _assert_records_equal(bank.read_frame_records(0), out["frames"])
+    # the device pointer must be 16-byte aligned (frames are staged into LDS 16 bytes per lane)
+    with pytest.raises(capi.SdrError) as e:
+        bank.process_device(t.data_ptr() + 8, 1)
+    assert e.value.code == capi.ERR_BAD_ARG
     bank.close()
 
 
