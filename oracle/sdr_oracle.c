@@ -1535,7 +1535,8 @@ ORC_API int orc_receiver_process(void *h, const float *iq, int n_frames, orc_fra
  * (FFT+projection, noise floor, thresholds, listeners, cumulation, peak scan). */
 ORC_API int orc_receiver_run_baseline(void *h, const float *iq, int n_frames)
 {
-    static orc_peak scratch[4096];
+    /* per call, not static: bench.py runs one receiver per host thread through this entry */
+    orc_peak *scratch = (orc_peak *)malloc(sizeof(orc_peak) * 4096);
     int counts[64], frames_[64];
     int total = 0;
     int done = 0;
@@ -1547,5 +1548,6 @@ ORC_API int orc_receiver_run_baseline(void *h, const float *iq, int n_frames)
                                       NULL, NULL, NULL, scratch, counts, frames_, 64, 64, NULL);
         done += n;
     }
+    free(scratch);
     return total;
 }

@@ -30,12 +30,28 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found: libsdrainer_hip.so cannot be built (no CPU fallback exists)")
 
 
+STAMP = LIB + ".srchash"
+
+
+def source_hash() -> str:
+    """sha256 over every source, header, flag and this script: a library is reused only if it was built
+    from exactly these bytes (mtimes do not survive a copy to another box)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for d in [os.path.join(HERE, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(HERE, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    with open(STAMP) as f:
+        return f.read().strip() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -57,6 +73,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(source_hash() + "\n")
     return LIB
 
 

@@ -2,7 +2,9 @@
 // Compiled with -ffp-contract=off (see gomath.h).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
+#include <mutex>
 
 #include "../../include/sdrainer_hip.h"
 #include "cw_decoder.h"
@@ -22,13 +24,23 @@
 
 namespace sdr {
 
-// Development aid (tools/fft_trace.hip): per-wave time stamps of one workgroup's phases.
+// Development aids (tools/fft_trace.hip).  SDR_FFT_TRACE: per-wave time stamps of one workgroup's phases (the
+// stamps cost a third of the kernel's speed: every one waits for the scalar-memory counter LDS shares).
+// SDR_FFT_STOP: every wave ends at phase `g_fft_stop_at` (a uniform value read at run time), so the launch time
+// of "everything up to phase k" can be measured on otherwise identical code.
 #if defined(SDR_FFT_TRACE)
 __shared__ int s_fft_trace_frame;  // which of the workgroup's frames is being stamped
 #define SDR_STAMP(k)                                                                                  \
     do {                                                                                              \
         if (blockIdx.x == SDR_FFT_TRACE && (threadIdx.x & 63) == 0)                                   \
             g_fft_trace[s_fft_trace_frame & 1][threadIdx.x >> 6][k] = wall_clock64();                 \
+    } while (0)
+#elif defined(SDR_FFT_STOP)
+__device__ int g_fft_stop_at;
+#define SDR_STAMP(k)                                                 \
+    do {                                                             \
+        if (__builtin_amdgcn_readfirstlane(g_fft_stop_at) == (k))    \
+            __builtin_amdgcn_endpgm();                               \
     } while (0)
 #else
 #define SDR_STAMP(k) \
@@ -75,9 +87,12 @@ constexpr bool later_lds_exchange(int e)
     return false;
 }
 
-template <int LOGN, int P, bool FRAME_FOLLOWS = false>
+// `lds_free()` is called once, when the frame's last exchange through LDS is over (a following frame's
+// input may be staged into the exchange area from then on).
+template <int LOGN, int P, bool FRAME_FOLLOWS, class LdsFree>
 __device__ __forceinline__ void run_passes(double (&xr)[fft64::Plan<LOGN>::R], double (&xi)[fft64::Plan<LOGN>::R],
-                                           int t, rsrc_t tw, const fft64::cplx *__restrict__ tw_ptr, double *lds)
+                                           int t, rsrc_t tw, const fft64::cplx *__restrict__ tw_ptr, double *lds,
+                                           LdsFree lds_free)
 {
     using PL = fft64::Plan<LOGN>;
 #if !(defined(SDR_ABLATE) && (SDR_ABLATE == 5))
@@ -95,46 +110,72 @@ __device__ __forceinline__ void run_passes(double (&xr)[fft64::Plan<LOGN>::R], d
     if constexpr (P < PL::NPASS - 1) {
         if constexpr (fft64::make_swap_plan<LOGN>(P).ok) {
             // slot bits <-> lane bits 4/5 only: done in registers (fft_f64.h exchange_swap), no LDS
+#if !(defined(SDR_ABLATE) && (SDR_ABLATE == 14))
             fft64::exchange_swap<LOGN, P>(xr);
             fft64::exchange_swap<LOGN, P>(xi);
+#endif
         } else {
             // A wave-local exchange (fft_f64.h make_layout) only touches LDS words of the wave's own
             // elements: no workgroup barrier, the waves drift apart and one wave's exchange overlaps the
             // others' butterflies.  The single cross-wave exchange is fenced by barriers on both sides.
             constexpr bool CROSS = PL::cross_wave(P);
+            // timing-only builds: 10 = cross-wave exchange without its LDS traffic, 11 = without its barriers,
+            // 12 = without either, 13 = no wave-local LDS exchange
+#if defined(SDR_ABLATE) && (SDR_ABLATE == 11 || SDR_ABLATE == 12)
+            constexpr bool BARRIERS = false;
+#else
+            constexpr bool BARRIERS = CROSS;
+#endif
+#if defined(SDR_ABLATE) && (SDR_ABLATE == 10 || SDR_ABLATE == 12)
+            constexpr bool TRAFFIC = !CROSS;
+#elif defined(SDR_ABLATE) && (SDR_ABLATE == 13)
+            constexpr bool TRAFFIC = CROSS;
+#else
+            constexpr bool TRAFFIC = true;
+#endif
             auto sync = [] {
-                if constexpr (CROSS)
+                if constexpr (BARRIERS)
                     __syncthreads();
                 else
                     wave_sync();
             };
-            if constexpr (CROSS)
+            auto wr = [&](double (&x)[PL::R], double *area) {
+                if constexpr (TRAFFIC)
+                    fft64::exchange_write<LOGN, P>(x, t, area);
+            };
+            auto rd = [&](double (&x)[PL::R], double *area) {
+                if constexpr (TRAFFIC)
+                    fft64::exchange_read<LOGN, P>(x, t, area);
+            };
+            if constexpr (BARRIERS)
                 __syncthreads();  // every wave is done with the words of its previous wave-local exchange
 #if defined(SDR_ABLATE) && (SDR_ABLATE == 2)
             if (t < 0)  // timing-only build: no exchanges
 #endif
             if constexpr (PL::SPLIT) {
-                fft64::exchange_write<LOGN, P>(xr, t, lds);
+                wr(xr, lds);
                 sync();
-                fft64::exchange_read<LOGN, P>(xr, t, lds);
+                rd(xr, lds);
                 sync();
-                fft64::exchange_write<LOGN, P>(xi, t, lds);
+                wr(xi, lds);
                 sync();
-                fft64::exchange_read<LOGN, P>(xi, t, lds);
+                rd(xi, lds);
             } else {
-                fft64::exchange_write<LOGN, P>(xr, t, lds);
-                fft64::exchange_write<LOGN, P>(xi, t, lds + PL::N);
+                wr(xr, lds);
+                wr(xi, lds + PL::N);
                 sync();
-                fft64::exchange_read<LOGN, P>(xr, t, lds);
-                fft64::exchange_read<LOGN, P>(xi, t, lds + PL::N);
+                rd(xr, lds);
+                rd(xi, lds + PL::N);
             }
             // reads done before a later exchange writes LDS again (other waves' words if CROSS)
             // ... or the next frame's staging does
             if constexpr (later_lds_exchange<LOGN>(P) || FRAME_FOLLOWS)
                 sync();
+            if constexpr (!later_lds_exchange<LOGN>(P))
+                lds_free();
         }
         SDR_STAMP(3 + 2 * P);
-        run_passes<LOGN, P + 1, FRAME_FOLLOWS>(xr, xi, t, tw, tw_ptr, lds);
+        run_passes<LOGN, P + 1, FRAME_FOLLOWS>(xr, xi, t, tw, tw_ptr, lds, lds_free);
     }
 }
 
@@ -162,7 +203,9 @@ __device__ __forceinline__ void project_and_store(const double (&xr)[fft64::Plan
     for (int s = 0; s < PL::R; s++) {
         const int sk = fft64::slot_part<LOGN, PL::NPASS - 1>(s) ^ (H & SLOT_MASK);
         const float p = (float)(xr[s] * xr[s] + xi[s] * xi[s]);
-#if defined(SDR_ABLATE) && (SDR_ABLATE == 6 || SDR_ABLATE == 7)
+#if defined(SDR_ABLATE) && (SDR_ABLATE == 15)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(p), pdr, tk * 4u, sk * 4, SDR_FFT_PSD_AUX);  // timing-only: psd only
+#elif defined(SDR_ABLATE) && (SDR_ABLATE == 6 || SDR_ABLATE == 7)
         float db = 0.0f;  // timing-only build: (almost) no stores
         if (!gomath::psd_value_in_db_fast(p, inv_n2, ltab, &db))
             redo |= 1u << s;
@@ -194,22 +237,27 @@ __device__ __forceinline__ void project_and_store(const double (&xr)[fft64::Plan
 }
 
 // (A persistent variant - the grid sized to the chip, each workgroup walking over frames, the next frame's
-// samples prefetched into the registers the projection frees, workgroups started staggered or not - measured
-// 5 % slower at N = 16384: 0.223 against 0.212 ms for 2048 frames, and it keeps the other pipeline stages off
-// the CUs: 0.46 against 0.36 ms per pipelined step.)
+// samples prefetched into the REGISTERS the projection frees, workgroups started staggered or not - measured
+// 5 % slower at N = 16384: 0.223 against 0.212 ms for 2048 frames.)
 //
-// FPW frames per workgroup, one after the other; the default is 1.  With FPW = 2 (SDR_FFT_FPW=2) the second
-// frame's LDS-DMA is issued when the first frame's last butterfly pass is done (LDS is idle from the cross-wave
-// exchange on, the DMA needs no registers, and the projection that follows has no loads the DMA could hold
-// up), so its HBM latency is covered by the first frame's projection, and there is one dispatch gap per two
-// frames.  Measured at N = 16384: 0.189 against 0.192 ms standalone, but 0.282 against 0.275 ms per pipelined
-// step (the tail stages get a CU only every other frame) - hence the default.
-template <int LOGN, int FPW>
+// MULTI: a workgroup takes `fpw` consecutive frames.  The next frame's LDS-DMA is issued as soon as the current
+// frame's last exchange through LDS is over (SDR_FFT_DMA_AT 0; LDS is idle from then on and the DMA needs no
+// registers) or just before the projection (SDR_FFT_DMA_AT 1), so its HBM latency is covered by the current
+// frame's remaining passes and projection, and there is one dispatch gap per `fpw` frames.
+// `stagger_ticks` (100 MHz ticks): the first generation of workgroups (one per CU) starts in four phases a
+// quarter of this apart.  Workgroups of one launch all do the same work, so without it every CU reads its
+// frame at the same moment and stores its spectrum at the same moment: HBM sees 33 MB bursts with idle time
+// between them, and a prefetch issued by all CUs at once lands in the middle of everybody's store burst.
+#if !defined(SDR_FFT_DMA_AT)
+#define SDR_FFT_DMA_AT 0
+#endif
+template <int LOGN, bool MULTI>
 __global__ __launch_bounds__(fft64::Plan<LOGN>::T) void k_fft_project(const float *__restrict__ iq,
                                                                       const fft64::cplx *__restrict__ tw,
                                                                       float *__restrict__ spectrum,
                                                                       float *__restrict__ psd, double inv_n2,
-                                                                      int in_stride, int out_stride, int n_frames)
+                                                                      int in_stride, int out_stride, int n_frames,
+                                                                      int fpw, int stagger_ticks)
 {
     using PL = fft64::Plan<LOGN>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -221,10 +269,25 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T) void k_fft_project(const floa
     if ((threadIdx.x & 63) == 0)
         s_fft_trace_frame = 0;
 #endif
+    if constexpr (MULTI) {
+        if (stagger_ticks > 0 && blockIdx.x < 256u) {
+            const unsigned phase = (blockIdx.x >> 3) & 3u;  // blocks b and b + 8 share an XCD: spread within each
+            const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(phase * (unsigned)stagger_ticks / 4u);
+            while (__builtin_amdgcn_s_memrealtime() < until)
+                __builtin_amdgcn_s_sleep(8);
+        }
+    }
+#if defined(SDR_FFT_CLOCK)
+    unsigned long long ck0 = 0, rt0 = 0;
+    if (blockIdx.x == 100)
+        ck0 = __builtin_amdgcn_s_memtime();
+    rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     SDR_STAMP(0);
     if (threadIdx.x < gomath::kLogTabSize)
         ltab[threadIdx.x] = reinterpret_cast<const gomath::LogTabEntry *>(tw + PL::TW_TOTAL)[threadIdx.x];
-    const int frame0 = blockIdx.x * FPW;
+    const int frame0 = MULTI ? blockIdx.x * fpw : blockIdx.x;
+    const int frame_end = MULTI ? min(frame0 + fpw, n_frames) : frame0 + 1;
     const size_t in_band = (size_t)blockIdx.y * in_stride, out_band = (size_t)blockIdx.y * out_stride;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
 
@@ -251,22 +314,25 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T) void k_fft_project(const floa
     stage_frame(frame0, threadIdx.x);
 
 #pragma nounroll
-    for (int k = 0; k < FPW; k++) {
-        const int frame = frame0 + k;
-        if (frame >= n_frames)
-            break;
+    for (int frame = frame0; frame < frame_end; frame++) {
 #if defined(SDR_FFT_TRACE)
         if ((threadIdx.x & 63) == 0)
-            s_fft_trace_frame = k;  // (every wave writes the same value; its own lane 0 reads it back)
+            s_fft_trace_frame = frame - frame0;  // (every wave writes the same value; its own lane 0 reads it back)
 #endif
         // (with more than one frame per workgroup everything derived from the thread id is loop-invariant and the
         // compiler would hoist - and spill - it: make the thread id opaque per frame)
         int t = threadIdx.x;
-        if constexpr (FPW > 1)
+        if constexpr (MULTI)
             asm volatile("" : "+v"(t));
-        // loads and stores share one counter and may complete out of order with respect to each other, so the
-        // wait for the DMA is a full drain (for the second frame that includes the first frame's last stores)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Vector-memory operations retire in issue order for the counter (MI355X_MICROARCH.md: loads, stores and
+        // LDS-DMA count together, in issue order).  The first frame's DMA is the wave's only traffic: full drain.
+        // A later frame's DMA was issued BEFORE the previous frame's projection stores (2 per slot, plus whatever
+        // the rare redo loop added), so "all but the 2R youngest" covers it without also waiting for those stores
+        // to reach memory; with redo traffic on top it merely waits for a few of the stores as well.
+        if (!MULTI || frame == frame0)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PL::R) : "memory");
         SDR_STAMP(12);  // this wave's rows have landed
         __syncthreads();
         SDR_STAMP(13);  // everybody's have
@@ -289,16 +355,17 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T) void k_fft_project(const floa
         }
         __syncthreads();  // everyone has its samples: the exchange area may be written again
         SDR_STAMP(1);
-        run_passes<LOGN, 0, (FPW > 1)>(xr, xi, t, make_rsrc(tw, (unsigned)(PL::TW_TOTAL * sizeof(fft64::cplx))), tw, lds);
-
-        if constexpr (FPW > 1) {
-            // the butterflies are done (their twiddle loads with them); nobody touches the exchange area any more
-            // (run_passes ends its last LDS exchange with a barrier when a frame follows)
-            // (no scheduling pin here: the compiler keeps the DMA behind the exchanges' LDS accesses and behind the
-            // twiddle loads already issued, which it waits for with counted vmcnt; a "memory" pin cost 46 spills)
-            if (k + 1 < FPW && frame + 1 < n_frames)
+        const bool more = MULTI && frame + 1 < frame_end;
+        // (no scheduling pin around the DMA: the compiler keeps it behind the exchanges' LDS accesses and behind the
+        // twiddle loads already issued, which it waits for with counted vmcnt; a "memory" pin cost 46 spills)
+        run_passes<LOGN, 0, MULTI>(xr, xi, t, make_rsrc(tw, (unsigned)(PL::TW_TOTAL * sizeof(fft64::cplx))), tw, lds, [&] {
+            if constexpr (MULTI && SDR_FFT_DMA_AT == 0)
+                if (more)
+                    stage_frame(frame + 1, t);
+        });
+        if constexpr (MULTI && SDR_FFT_DMA_AT == 1)
+            if (more)
                 stage_frame(frame + 1, t);
-        }
         float *sp = spectrum + (out_band + frame) * PL::N;
         float *pd = psd + (out_band + frame) * PL::N;
 #if defined(SDR_ABLATE) && (SDR_ABLATE == 4)
@@ -317,37 +384,84 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T) void k_fft_project(const floa
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     SDR_STAMP(11);
+#if defined(SDR_FFT_CLOCK)
+    if (blockIdx.x == 100 && threadIdx.x == 0) {
+        g_fft_clock[0] = __builtin_amdgcn_s_memtime() - ck0;
+        g_fft_clock[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
+    // every workgroup: first wave's start, each wave's end (the host takes the latest), where it ran
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) {
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0) {
+            g_fft_wg[blockIdx.x][0] = rt0;
+            g_fft_wg[blockIdx.x][1] = now;
+            // HW_REG_HW_ID: cu_id bits 11:8, sh_id 12, se_id 15:13 (gfx9); XCC_ID is a register of its own
+            g_fft_wg[blockIdx.x][3] = __builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11)) |
+                                      ((unsigned long long)__builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (3 << 11)) << 32);
+        }
+        atomicMax(&g_fft_wg[blockIdx.x][2], now);
+    }
+#endif
 }
 
 constexpr int kLogTabBytes = gomath::kLogTabSize * (int)sizeof(gomath::LogTabEntry);
+
+// Tuning knobs, read once per process: SDR_FFT_FPW = frames per workgroup (default kDefaultFpw),
+// SDR_FFT_STAGGER_US = spread of the first workgroups' start times in microseconds.
+constexpr int kDefaultFpw = 1;
+constexpr int kMaxDevices = 64;
+struct FftKnobs {
+    int fpw = kDefaultFpw;
+    int stagger_ticks = 0;
+};
+static const FftKnobs &fft_knobs()
+{
+    static const FftKnobs k = [] {
+        FftKnobs v;
+        if (const char *e = getenv("SDR_FFT_FPW"))
+            v.fpw = std::max(1, std::min(atoi(e), 64));
+        if (const char *e = getenv("SDR_FFT_STAGGER_US"))
+            v.stagger_ticks = std::max(0, std::min((int)(atof(e) * 100.0), 100000));
+        return v;
+    }();
+    return k;
+}
 
 template <int LOGN>
 static hipError_t launch_fft_t(const float *iq, const fft64::cplx *tw, float *spectrum, float *psd, int n_frames,
                                int n_bands, int in_stride, int out_stride, hipStream_t stream)
 {
     using PL = fft64::Plan<LOGN>;
-    static bool attr_set = false;
-    static int fpw = 1;
-    if (!attr_set) {
-        for (const void *k : {reinterpret_cast<const void *>(&k_fft_project<LOGN, 1>),
-                              reinterpret_cast<const void *>(&k_fft_project<LOGN, 2>)}) {
-            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, PL::LDS_BYTES + kLogTabBytes);
-            if (e != hipSuccess)
-                return e;
+    // the > 64 KB dynamic LDS attribute is per device: set it once on each device a bank launches on
+    static std::once_flag attr_once[kMaxDevices];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess)
+        return e;
+    if (dev < 0 || dev >= kMaxDevices)
+        return hipErrorInvalidDevice;
+    hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once[dev], [&] {
+        for (const void *k : {reinterpret_cast<const void *>(&k_fft_project<LOGN, false>),
+                              reinterpret_cast<const void *>(&k_fft_project<LOGN, true>)}) {
+            const hipError_t ae = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, PL::LDS_BYTES + kLogTabBytes);
+            if (ae != hipSuccess)
+                attr_err = ae;
         }
-        if (const char *e = getenv("SDR_FFT_FPW"))  // frames per workgroup: 1 (default) or 2
-            fpw = atoi(e) == 2 ? 2 : 1;
-        attr_set = true;
-    }
+    });
+    if (attr_err != hipSuccess)
+        return attr_err;
+    const FftKnobs &kn = fft_knobs();
     const double inv_n2 = 1.0 / ((double)PL::N * (double)PL::N);
     if (n_frames <= 0 || n_bands <= 0)
         return hipSuccess;
-    if (fpw == 2)
-        hipLaunchKernelGGL((k_fft_project<LOGN, 2>), dim3((n_frames + 1) / 2, n_bands), dim3(PL::T), PL::LDS_BYTES + kLogTabBytes,
-                           stream, iq, tw, spectrum, psd, inv_n2, in_stride, out_stride, n_frames);
+    if (kn.fpw > 1)
+        hipLaunchKernelGGL((k_fft_project<LOGN, true>), dim3((n_frames + kn.fpw - 1) / kn.fpw, n_bands), dim3(PL::T),
+                           PL::LDS_BYTES + kLogTabBytes, stream, iq, tw, spectrum, psd, inv_n2, in_stride, out_stride, n_frames,
+                           kn.fpw, kn.stagger_ticks);
     else
-        hipLaunchKernelGGL((k_fft_project<LOGN, 1>), dim3(n_frames, n_bands), dim3(PL::T), PL::LDS_BYTES + kLogTabBytes, stream, iq,
-                           tw, spectrum, psd, inv_n2, in_stride, out_stride, n_frames);
+        hipLaunchKernelGGL((k_fft_project<LOGN, false>), dim3(n_frames, n_bands), dim3(PL::T), PL::LDS_BYTES + kLogTabBytes, stream,
+                           iq, tw, spectrum, psd, inv_n2, in_stride, out_stride, n_frames, 1, 0);
     return hipGetLastError();
 }
 

@@ -63,6 +63,15 @@ __device__ __forceinline__ ChainShared<SLOTS> &ring()
 // data" (consumer) only need the COMPILER to keep the program order.  A real workgroup-scope fence compiles
 // to s_waitcnt vmcnt(0) lgkmcnt(0): it would drain the producer's global loads of the unit after next and
 // the consumer's reads of the next chunks, which is exactly the latency both sides run ahead to hide.
+//
+// HARDWARE DEPENDENCY (gfx950 / GCN-CDNA DS pipeline): this protocol is only correct because (a) one wave's
+// LDS (DS) instructions are issued to and executed by the CU's single LDS unit in program order, and (b) all
+// waves of a workgroup share that one LDS, so a flag write that executes after the data writes is also
+// observed after them by every other wave.  The C++ memory model does not promise either (relaxed atomics +
+// a compiler barrier order nothing formally); a target whose DS operations can complete out of order, or
+// whose workgroup can span more than one LDS, needs release/acquire fences here instead.  The chains are
+// checked bit for bit against the oracle on every GPU test run (tests/test_gpu_parity.py), which is what
+// would catch a violation.
 __device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
 
 __device__ __forceinline__ int lds_flag_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }

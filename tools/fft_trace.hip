@@ -3,19 +3,25 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <algorithm>
+#include <cstring>
+#include <map>
 #include <vector>
 
 // -DSDR_ABLATE=n builds time the kernel with one ingredient removed (no stamps then)
-#if !defined(SDR_ABLATE)
-#define SDR_FFT_TRACE 1000
+#if !defined(SDR_ABLATE) && !defined(SDR_FFT_STOP)
+#define SDR_FFT_TRACE 100
 #endif
 __device__ unsigned long long g_fft_trace[2][16][16];
+#if defined(SDR_FFT_CLOCK)
+namespace sdr { __device__ unsigned long long g_fft_clock[2]; __device__ unsigned long long g_fft_wg[2048][4]; }
+#endif
 #include "../sdrainer_amd/csrc/k_fft_project.hip"
 #include "../sdrainer_amd/csrc/twiddles.h"
 
-int main()
+int main(int argc, char **argv)
 {
-    const int logn = 14, N = 1 << logn, frames = 2048;
+    const int logn = 14, N = 1 << logn, frames = argc > 1 ? atoi(argv[1]) : 2048;
     std::vector<double> wre, wim;
     fft64::radix2_factors(N, wre, wim);
     const size_t ntw = (size_t)sdr::twiddle_count(logn);
@@ -39,14 +45,132 @@ int main()
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int rep = 0; rep < 6; rep++) {
+#if defined(SDR_FFT_STOP)
+    {
+        // phase ids as stamped in k_fft_project.hip; 99 = run to the end
+        const int ids[] = {13, 1, 2, 3, 4, 5, 6, 7, 8, 10, 99};
+        const char *what[] = {"staged(all)", "in regs", "pass0", "ex0", "pass1", "ex1", "pass2", "ex2", "pass3", "stored", "full"};
+        float prev = 0.f;
+        for (int i = 0; i < 11; i++) {
+            hipMemcpyToSymbol(HIP_SYMBOL(sdr::g_fft_stop_at), &ids[i], sizeof(int));
+            float b = 1e9f;
+            for (int rep = 0; rep < 7; rep++) {
+                hipEventRecord(e0, 0);
+                sdr::launch_fft(logn, iq, tw, sp, pd, frames, 1, frames, frames, 0);
+                hipEventRecord(e1, 0);
+                hipEventSynchronize(e1);
+                float ms;
+                hipEventElapsedTime(&ms, e0, e1);
+                if (rep >= 2 && ms < b)
+                    b = ms;
+            }
+            printf("stop after %-12s %.4f ms  (+%.4f)  = %.2f us per frame-generation\n", what[i], b, b - prev, 1e3 * b / ((frames + 255) / 256));
+            prev = b;
+        }
+        return 0;
+    }
+#endif
+    float best = 1e9f;
+    for (int rep = 0; rep < 8; rep++) {
         hipEventRecord(e0, 0);
         sdr::launch_fft(logn, iq, tw, sp, pd, frames, 1, frames, frames, 0);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
-        printf("launch %d: %.3f ms\n", rep, ms);
+        if (rep >= 2 && ms < best)
+            best = ms;
+    }
+    printf("single launch (best of 6): %.4f ms\n", best);
+#if defined(SDR_FFT_CLOCK)
+    {
+        // 2 s of back-to-back launches, then the shader clock over one workgroup's lifetime
+        for (int rep = 0; rep < 8000; rep++)
+            sdr::launch_fft(logn, iq, tw, sp, pd, frames, 1, frames, frames, 0);
+        hipDeviceSynchronize();
+        unsigned long long ck[2];
+        hipMemcpyFromSymbol(ck, HIP_SYMBOL(sdr::g_fft_clock), sizeof ck);
+        printf("in-kernel clock: %llu shader cycles in %llu ticks of 10 ns = %.3f GHz (workgroup lifetime %.2f us)\n", ck[0], ck[1],
+               (double)ck[0] / (double)ck[1] / 10.0, (double)ck[1] / 100.0);
+        // one more launch from an idle chip, then every workgroup's span
+        static unsigned long long wg[2048][4];
+        memset(wg, 0, sizeof wg);
+        hipMemcpyToSymbol(HIP_SYMBOL(sdr::g_fft_wg), wg, sizeof wg);
+        sdr::launch_fft(logn, iq, tw, sp, pd, frames, 1, frames, frames, 0);
+        hipDeviceSynchronize();
+        hipMemcpyFromSymbol(wg, HIP_SYMBOL(sdr::g_fft_wg), sizeof wg);
+        const int fpw = getenv("SDR_FFT_FPW") ? atoi(getenv("SDR_FFT_FPW")) : 1;
+        const int nwg = (frames + fpw - 1) / fpw;
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int i = 0; i < nwg; i++) {
+            if (wg[i][0] < t0) t0 = wg[i][0];
+            if (wg[i][2] > t1) t1 = wg[i][2];
+        }
+        printf("launch span (first start -> last end): %.2f us, %d workgroups\n", (double)(t1 - t0) / 100.0, nwg);
+        std::vector<double> life, skew;
+        for (int i = 0; i < nwg; i++) {
+            life.push_back((double)(wg[i][2] - wg[i][0]) / 100.0);
+            skew.push_back((double)(wg[i][2] - wg[i][1]) / 100.0);
+        }
+        std::vector<double> l2 = life, s2 = skew;
+        std::sort(l2.begin(), l2.end());
+        std::sort(s2.begin(), s2.end());
+        printf("workgroup lifetime us: min %.2f p10 %.2f median %.2f p90 %.2f max %.2f ; last wave ends after wave 0 by median %.2f max %.2f us\n",
+               l2[0], l2[nwg / 10], l2[nwg / 2], l2[nwg * 9 / 10], l2[nwg - 1], s2[nwg / 2], s2[nwg - 1]);
+        // per (xcc, se, sh, cu): chain of workgroups -> gaps between one's end and the next one's start
+        std::map<unsigned long long, std::vector<int>> by_cu;
+        for (int i = 0; i < nwg; i++)
+            by_cu[((wg[i][3] >> 32) << 16) | (wg[i][3] & 0xff00)].push_back(i);
+        std::vector<double> gaps, per_xcc_end(8, 0.0);
+        for (auto &kv : by_cu) {
+            auto &v = kv.second;
+            std::sort(v.begin(), v.end(), [&](int a, int b) { return wg[a][0] < wg[b][0]; });
+            for (size_t k = 1; k < v.size(); k++)
+                gaps.push_back(((double)wg[v[k]][0] - (double)wg[v[k - 1]][2]) / 100.0);
+            const int xcc = (int)(kv.first >> 16) & 7;
+            per_xcc_end[xcc] = std::max(per_xcc_end[xcc], (double)(wg[v.back()][2] - t0) / 100.0);
+        }
+        std::sort(gaps.begin(), gaps.end());
+        if (!gaps.empty())
+            printf("%zu distinct CUs; gap between a workgroup's last wave ending and the next one starting on the same CU: min %.2f median %.2f p90 %.2f max %.2f us\n",
+                   by_cu.size(), gaps[0], gaps[gaps.size() / 2], gaps[gaps.size() * 9 / 10], gaps.back());
+        else
+            printf("%zu distinct CUs\n", by_cu.size());
+        printf("last end per XCC (us):");
+        for (double e : per_xcc_end)
+            printf(" %.1f", e);
+        printf("\nfirst-generation starts (us): ");
+        std::vector<double> st;
+        for (int i = 0; i < nwg; i++)
+            st.push_back((double)(wg[i][0] - t0) / 100.0);
+        std::sort(st.begin(), st.end());
+        printf("p0 %.2f p50(first 256) %.2f p100(first 256) %.2f\n", st[0], st[std::min(nwg, 256) / 2], st[std::min(nwg, 256) - 1]);
+    }
+#endif
+    // launches back to back: on one stream (a barrier between kernels) and alternating between two streams
+    // (the next launch's workgroups fill the CUs the previous one's tail leaves idle)
+    hipStream_t st[2];
+    hipStreamCreateWithFlags(&st[0], hipStreamNonBlocking);
+    hipStreamCreateWithFlags(&st[1], hipStreamNonBlocking);
+    for (int ns = 1; ns <= 2; ns++) {
+        const int reps = 40;
+        hipDeviceSynchronize();
+        hipEventRecord(e0, st[0]);
+        if (ns == 2)
+            hipStreamWaitEvent(st[1], e0, 0);
+        for (int rep = 0; rep < reps; rep++)
+            sdr::launch_fft(logn, iq, tw, sp, pd, frames, 1, frames, frames, st[rep % ns]);
+        hipEvent_t ej;
+        hipEventCreate(&ej);
+        if (ns == 2) {
+            hipEventRecord(ej, st[1]);
+            hipStreamWaitEvent(st[0], ej, 0);
+        }
+        hipEventRecord(e1, st[0]);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("%d launches on %d stream(s): %.4f ms per launch\n", reps, ns, ms / reps);
     }
 #if defined(SDR_ABLATE)
     return 0;
@@ -59,7 +183,9 @@ int main()
             t0 = tr2[0][w][0];
     const char *names[14] = {"start", "loaded", "pass0", "ex0", "pass1", "ex1", "pass2", "ex2", "pass3", "-", "stored", "drained", "landed", "all"};
     const int order[] = {0, 12, 13, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11};
-    const int frames_per_wg = getenv("SDR_FFT_FPW") && atoi(getenv("SDR_FFT_FPW")) == 2 ? 2 : 1;
+    const int frames_per_wg = getenv("SDR_FFT_FPW") && atoi(getenv("SDR_FFT_FPW")) >= 2 ? 2 : 1;
+    if (getenv("SDR_TRACE_QUIET"))
+        return 0;
     for (int f = 0; f < frames_per_wg; f++) {
         printf("frame %d of the workgroup (us since its first wave started; 100 MHz clock)\nwave ", f);
         for (int k : order)
