@@ -13,7 +13,7 @@ scaling); the only collective is the RCCL broadcast of the shared configuration 
 from rank 0 before the timed region.
 
 Rank 0 prints ONE JSON line (contract in the task statement) carrying, besides the throughput:
-  roofline      dominant kernel (k_fft_project) algorithmic bytes (8 B per IQ sample) per launch over
+  roofline      dominant kernel (k_fft_psd) algorithmic bytes (8 B per IQ sample) per launch over
                 its average launch duration measured with HIP events on the launch stream, vs 8 TB/s
   cpu_baseline  the CPU oracle (port of the Go path) timed on this box's host cores on a bounded
                 sample of the same workload
@@ -248,7 +248,7 @@ def main():
     bank.sync()
     prof = bank.profile_read()
     bank.profile_enable(False)
-    fft_ms, fft_n = prof["k_fft_project"]
+    fft_ms, fft_n = prof["k_fft_psd"]
     fft_avg_ms = fft_ms / max(fft_n, 1)
     achieved = BYTES_PER_SAMPLE * samples_per_step_rank / (fft_avg_ms * 1e-3) / 1e9
     traffic = None
@@ -258,7 +258,7 @@ def main():
             tj = json.load(open(tpath))
             key = f"{args.workload}_f{frames}"
             if key in tj:
-                traffic = tj[key]["k_fft_project_hbm_bytes_per_launch"]
+                traffic = tj[key]["k_fft_psd_hbm_bytes_per_launch"]
         except Exception:
             traffic = None
     if args.kernel_breakdown and rank == 0:
@@ -295,7 +295,7 @@ def main():
             "sanity": {"runes_decoded_first_listeners": decoded, "cumulations_per_step": chunks},
         },
         "roofline": {
-            "bound": "hbm", "kernel": "k_fft_project", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "bound": "hbm", "kernel": "k_fft_psd", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "avg_launch_ms": round(fft_avg_ms, 4), "launches_timed": fft_n,
             "whole_path_frac": round(value * 1e6 / world * BYTES_PER_SAMPLE / (HBM_PEAK_GBS * 1e9), 4),

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("SDR_HIP_LIB") or os.path.join(_HERE, "csrc", "libsdra
 
 OK, ERR_BAD_ARG, ERR_BAD_RATE, ERR_BAD_SIZE, ERR_WOULD_DROP, ERR_HIP, ERR_NO_SLOT, ERR_STATE = range(8)
 CUMULATION_SIZE = 100
-KERNELS = ("k_fft_project", "k_window_means", "k_noise_stats", "k_thresholds", "k_listen_gather", "k_cumulate",
+KERNELS = ("k_fft_psd", "k_window_means", "k_noise_stats", "k_thresholds", "k_listen_gather", "k_cumulate",
            "k_find_peaks", "k_listen_decode")
 
 

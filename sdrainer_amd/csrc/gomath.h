@@ -86,84 +86,86 @@ SDR_HD inline float psd_value_in_db(float psd, double inv_n2)
 // Certified fast path for psd_value_in_db.
 //
 // The result is a float32, but the reference computes it through a ~60-instruction float64 log.  The
-// fast path evaluates y ~= 10*log10(v) to an absolute error far below a float32 ulp (table of 64
-// mantissa intervals + degree-6 log1p polynomial, FMA allowed: only the error bound matters here),
-// and ACCEPTS float32(y) only if no float32 rounding boundary lies within kDbGuard of y (y - guard and
-// y + guard round to the same float32).  Both y and the reference's value lie within ~2e-13 of the true
-// logarithm (tests/emu/emu_log.cpp measures it), kDbGuard is 1e-10, so an accepted result is the
-// float32 the reference would have produced; anything else (about one value in 10^5, zeros, NaNs,
-// exact powers of two) reports `false` and the caller runs the literal Go algorithm.
+// argument of that log, v = 20 * float64(psd) / N^2, is EXACT in float64 (24-bit psd times the 3-bit 20
+// times a power of two), so the mathematical value the reference approximates is
+//     y = 10 log10(m) + E * 10 log10(2) + [10 log10(20) - 2 log2(N) * 10 log10(2)],   psd = m * 2^E, 1 <= m < 2.
+// The fast path evaluates that straight from the float32 bits: a 1024-entry table over the top ten mantissa
+// bits gives c_i ~ m with |m / c_i - 1| <= 2^-11, a degree-4 log1p finishes 10 log10(m) (truncation 6e-18),
+// and a 512-entry table indexed by sign+exponent supplies the E term, with NaN in the entries of zero /
+// subnormal / infinite / NaN / negative inputs.  FMA is allowed: only the error bound matters here.  The
+// float32 of y is ACCEPTED only if no float32 rounding boundary lies within kDbGuard of y (y - guard and
+// y + guard round to the same float32; a NaN y never does).  Both y and the reference's value lie within
+// ~1e-13 of the true logarithm (tests/emu/emu_log.cpp measures it), kDbGuard is 1e-10, so an accepted
+// result is the float32 the reference would have produced; anything else (about three values in 10^5,
+// plus every special input) reports `false` and the caller runs the literal Go algorithm.
 // ---------------------------------------------------------------------------------------------
 struct LogTabEntry {
-    double inv_c;  // 1 / c_i,  c_i = 1 + (i + 0.5) / 64
-    double ln_c;   // ln(c_i)
+    double inv_c;    // 1 / c_i,  c_i = 1 + (i + 0.5) / 1024
+    double db_of_c;  // 10 log10(c_i)
 };
-constexpr int kLogTabSize = 64;
+constexpr int kLogTabSize = 1024;  // LogTabEntry[kLogTabSize], 16 KB
+constexpr int kExpTabSize = 512;   // double[kExpTabSize], 4 KB: index = float32 bits >> 23 (sign and exponent)
+constexpr int kDbTabBytes = kLogTabSize * 16 + kExpTabSize * 8;
 constexpr double kDbGuard = 1e-10;
 
-// On the device the 64-bit polynomial constants are re-made in SGPRs at every use: left to itself the
-// compiler hoists them out of the caller's loops into VGPR pairs that stay alive through the whole FFT
-// (which needs every register it can get) and end up spilled.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define SDR_SGPR_CONST(name, value) \
-    double name = (value);          \
-    asm volatile("" : "+s"(name))
-#else
-#define SDR_SGPR_CONST(name, value) const double name = (value)
-#endif
-
-// y ~= 10*log10(v) for a normal, positive, finite v
-SDR_HD inline double db_fast_y(double v, const LogTabEntry *tab)
+// Both tables as one blob: [LogTabEntry x 1024][double x 512]
+struct DbTables {
+    const LogTabEntry *log_tab;
+    const double *exp_tab;
+};
+SDR_HD inline DbTables db_tables(const void *blob)
 {
-    uint64_t bits;
-    __builtin_memcpy(&bits, &v, sizeof bits);
-    const int be = (int)((bits >> 52) & 0x7ff);
-    const int idx = (int)((bits >> 46) & 63);
-    const uint64_t mbits = (bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
-    double m;
-    __builtin_memcpy(&m, &mbits, sizeof m);
-    const double r = __builtin_fma(m, tab[idx].inv_c, -1.0);  // |r| <= 1/128
-    // log1p(r) = r - r^2/2 + r^3/3 - r^4/4 + r^5/5 - r^6/6 (+ O(r^7) < 3e-16)
-    // (first step as a separate multiply and add: one 64-bit constant per instruction, so both can sit in
-    // SGPRs instead of a VGPR pair that would stay alive across the whole kernel)
-    SDR_SGPR_CONST(c6, -1.0 / 6.0);
-    SDR_SGPR_CONST(c5, 1.0 / 5.0);
-    SDR_SGPR_CONST(c3, 1.0 / 3.0);
-    double p = r * c6 + c5;
-    p = __builtin_fma(p, r, -1.0 / 4.0);
-    p = __builtin_fma(p, r, c3);
-    p = __builtin_fma(p, r, -1.0 / 2.0);
-    p = __builtin_fma(p, r, 1.0);
-    const double ln_m = __builtin_fma(p, r, tab[idx].ln_c);
-    SDR_SGPR_CONST(TenLog10Of2, 3.01029995663981195213738894724493027);  // 10 * log10(2)
-    SDR_SGPR_CONST(TenOverLn10, 4.34294481903251827651128918916605082);  // 10 / ln(10)
-    const double scaled = TenOverLn10 * ln_m;
-    return __builtin_fma((double)(be - 1023), TenLog10Of2, scaled);
+    const LogTabEntry *lt = static_cast<const LogTabEntry *>(blob);
+    return DbTables{lt, reinterpret_cast<const double *>(lt + kLogTabSize)};
 }
 
-SDR_HD inline bool psd_value_in_db_fast(float psd, double inv_n2, const LogTabEntry *tab, float *out)
+// y ~= 10*log10(20 * psd / N^2) from the float32 bits of psd (NaN for inputs the tables mark as special)
+SDR_HD inline double db_fast_y(float psd, DbTables t)
 {
-    const double v = 20.0 * (double)psd * inv_n2;  // the same float64 the reference feeds to Log10
-    if (!(v >= 2.2250738585072014e-308) || !(v < INFINITY))
-        return false;  // zero, negative, NaN, subnormal, infinite
-    const double y = db_fast_y(v, tab);
+    uint32_t bits;
+    __builtin_memcpy(&bits, &psd, sizeof bits);
+    const uint32_t mant_one = (bits & 0x007fffffu) | 0x3f800000u;
+    float mf;
+    __builtin_memcpy(&mf, &mant_one, sizeof mf);
+    const double m = (double)mf;  // exact
+    const LogTabEntry e = t.log_tab[(bits >> 13) & 1023u];
+    const double eb = t.exp_tab[bits >> 23];
+    const double r = __builtin_fma(m, e.inv_c, -1.0);  // |r| <= 2^-11
+    // (10 / ln 10) * log1p(r) = r * K * (1 - r/2 + r^2/3 - r^3/4)  (+ O(r^5))
+    const double K = 4.34294481903251827651128918916605082;  // 10 / ln(10)
+    double q = __builtin_fma(-K / 4.0, r, K / 3.0);
+    q = __builtin_fma(q, r, -K / 2.0);
+    q = __builtin_fma(q, r, K);
+    return __builtin_fma(q, r, e.db_of_c) + eb;
+}
+
+SDR_HD inline bool psd_value_in_db_fast(float psd, DbTables t, float *out)
+{
+    const double y = db_fast_y(psd, t);
     // Rounding to float32 is monotone: if y - guard and y + guard round to the same float32, so does every
     // value between them, the reference's among them.  (Covers asymmetric intervals at powers of two and
-    // values straddling zero without any bit tests.)
+    // values straddling zero without any bit tests; false for NaN.)
     const float lo = (float)(y - kDbGuard), hi = (float)(y + kDbGuard);
-    if (!(lo == hi))
-        return false;
     *out = lo;
-    return true;
+    return lo == hi;
 }
 
-// host: the table above
-inline void build_log_table(LogTabEntry *tab)
+// host: the tables above for block size 2^logn
+inline void build_db_tables(int logn, void *blob)
 {
+    LogTabEntry *lt = static_cast<LogTabEntry *>(blob);
+    double *et = reinterpret_cast<double *>(lt + kLogTabSize);
     for (int i = 0; i < kLogTabSize; i++) {
-        const double c = 1.0 + ((double)i + 0.5) / 64.0;
-        tab[i].inv_c = 1.0 / c;
-        tab[i].ln_c = ::log(c);
+        const long double c = 1.0L + ((long double)i + 0.5L) / (long double)kLogTabSize;
+        lt[i].inv_c = (double)(1.0L / c);
+        lt[i].db_of_c = (double)(10.0L * ::log10l(c));
+    }
+    const long double A = 10.0L * ::log10l(2.0L);
+    const long double B = 10.0L * ::log10l(20.0L) - 2.0L * (long double)logn * A;
+    for (int i = 0; i < kExpTabSize; i++) {
+        const int e = i & 255;
+        const bool special = (i >> 8) != 0 || e == 0 || e == 255;  // negative; zero / subnormal; inf / NaN
+        et[i] = special ? (double)NAN : (double)((long double)(e - 127) * A + B);
     }
 }
 

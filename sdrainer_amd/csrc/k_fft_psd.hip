@@ -1,5 +1,8 @@
-// k_fft_project.hip — the dominant kernel: IQ frame -> float64 radix-2 DIT FFT -> fftshift -> PSD / dB projection.
-// Compiled with -ffp-contract=off (see gomath.h).
+// k_fft_psd.hip — the dominant kernel: IQ frame -> float64 radix-2 DIT FFT -> fftshift -> PSD (float32), plus the
+// "tap": the PSD values of the bins the band's listeners sit on, gathered into a compact [frame][listener] array.
+// The dB projection of dsp/fft.go:79-81 is a pure function of the float32 PSD value, so it is evaluated where it
+// is consumed (k_peaks.hip cumulation, k_listen.hip envelope), not here: this kernel stores 4 bytes per sample
+// instead of 8 and carries no logarithm.  Compiled with -ffp-contract=off (see gomath.h).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -13,10 +16,7 @@
 #include "sdr_device.h"
 
 #if !defined(SDR_FFT_PSD_AUX)
-#define SDR_FFT_PSD_AUX 0  // cache policy bits of the psd / spectrum stores (2 = nt)
-#endif
-#if !defined(SDR_FFT_SPEC_AUX)
-#define SDR_FFT_SPEC_AUX 0
+#define SDR_FFT_PSD_AUX 0  // cache policy bits of the psd stores (2 = nt)
 #endif
 #if !defined(SDR_FFT_DMA_AUX)
 #define SDR_FFT_DMA_AUX 2  // cache policy bits of the input LDS-DMA: nt - a frame is read once, by one CU (0.198 vs 0.202 ms)
@@ -24,23 +24,16 @@
 
 namespace sdr {
 
-// Development aids (tools/fft_trace.hip).  SDR_FFT_TRACE: per-wave time stamps of one workgroup's phases (the
-// stamps cost a third of the kernel's speed: every one waits for the scalar-memory counter LDS shares).
-// SDR_FFT_STOP: every wave ends at phase `g_fft_stop_at` (a uniform value read at run time), so the launch time
-// of "everything up to phase k" can be measured on otherwise identical code.
+// Development aid (tools/fft_trace.hip).  SDR_FFT_TRACE: per-wave time stamps of one workgroup's phases.  The
+// stamps cost a third of the kernel's speed (every one waits for the scalar-memory counter LDS shares), so they
+// show the order of things, not their durations; durations come from SDR_FFT_CLOCK (per-workgroup spans, two
+// scalar loads per workgroup) and the SDR_ABLATE timing-only builds.
 #if defined(SDR_FFT_TRACE)
 __shared__ int s_fft_trace_frame;  // which of the workgroup's frames is being stamped
 #define SDR_STAMP(k)                                                                                  \
     do {                                                                                              \
         if (blockIdx.x == SDR_FFT_TRACE && (threadIdx.x & 63) == 0)                                   \
             g_fft_trace[s_fft_trace_frame & 1][threadIdx.x >> 6][k] = wall_clock64();                 \
-    } while (0)
-#elif defined(SDR_FFT_STOP)
-__device__ int g_fft_stop_at;
-#define SDR_STAMP(k)                                                 \
-    do {                                                             \
-        if (__builtin_amdgcn_readfirstlane(g_fft_stop_at) == (k))    \
-            __builtin_amdgcn_endpgm();                               \
     } while (0)
 #else
 #define SDR_STAMP(k) \
@@ -49,7 +42,7 @@ __device__ int g_fft_stop_at;
 #endif
 
 // ---------------------------------------------------------------------------------------------
-// k_fft_project  (dsp/fft.go:23-37 IQToSpectrumAndPSD + rx/receiver.go:376-378 projection closure)
+// k_fft_psd  (dsp/fft.go:23-37 IQToSpectrumAndPSD, the psd half; :59-69 setSamplesFromIQ; :54-57 fftshift)
 // ---------------------------------------------------------------------------------------------
 // Buffer addressing: address = descriptor base + per-thread 32-bit byte offset (a VGPR) + a scalar byte
 // offset.  Everything that is the same for all threads - which register slot, which twiddle row - goes into
@@ -179,104 +172,74 @@ __device__ __forceinline__ void run_passes(double (&xr)[fft64::Plan<LOGN>::R], d
     }
 }
 
-// Epilogue (dsp/fft.go:54-57 fftshift, :71-73 PSD[float32], :79-81 MagnitudeIndB, rx/receiver.go:377
-// +dBmShift).  The certified shortcut (gomath.h) settles all but about 2 values in 10^4; the rest are
-// redone with the literal Go algorithm in a rolled loop that re-reads the PSD value just stored, so the
-// long literal path exists once and holds no registers while the slots stream through.
-// `after_slot(s)` lets the persistent kernel slip its prefetch between slots.
-template <int LOGN, typename F>
-__device__ __forceinline__ void project_and_store(const double (&xr)[fft64::Plan<LOGN>::R],
-                                                  const double (&xi)[fft64::Plan<LOGN>::R], int t, float *__restrict__ sp,
-                                                  float *__restrict__ pd, double inv_n2,
-                                                  const gomath::LogTabEntry *ltab, F after_slot)
+// Epilogue (dsp/fft.go:54-57 fftshift, :71-73 PSD[float32]): psd[k] = float32(re^2 + im^2), two multiplies and an
+// add in float64, no FMA, rounded once.
+template <int LOGN>
+__device__ __forceinline__ void store_psd(const double (&xr)[fft64::Plan<LOGN>::R], const double (&xi)[fft64::Plan<LOGN>::R],
+                                          int t, float *__restrict__ pd)
 {
     using PL = fft64::Plan<LOGN>;
-    unsigned redo = 0;
     const int tp = fft64::thread_part<LOGN, PL::NPASS - 1>(t);
     // fft-shift = flip the top index bit: in the slot part it is a compile-time constant, in the thread part
-    // it is applied once; spectrum index k = tk | sk(s), and sk(s) goes into the scalar base pointer
+    // it is applied once; spectrum index k = tk | sk(s), and sk(s) goes into the scalar offset
     constexpr int SLOT_MASK = fft64::slot_part<LOGN, PL::NPASS - 1>(PL::R - 1);
     constexpr int H = PL::N / 2;
     const unsigned tk = (unsigned)(tp ^ (H & ~SLOT_MASK));
-    const rsrc_t pdr = make_rsrc(pd, PL::N * 4u), spr = make_rsrc(sp, PL::N * 4u);
+    const rsrc_t pdr = make_rsrc(pd, PL::N * 4u);
 #pragma unroll
     for (int s = 0; s < PL::R; s++) {
         const int sk = fft64::slot_part<LOGN, PL::NPASS - 1>(s) ^ (H & SLOT_MASK);
         const float p = (float)(xr[s] * xr[s] + xi[s] * xi[s]);
-#if defined(SDR_ABLATE) && (SDR_ABLATE == 15)
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(p), pdr, tk * 4u, sk * 4, SDR_FFT_PSD_AUX);  // timing-only: psd only
-#elif defined(SDR_ABLATE) && (SDR_ABLATE == 6 || SDR_ABLATE == 7)
-        float db = 0.0f;  // timing-only build: (almost) no stores
-        if (!gomath::psd_value_in_db_fast(p, inv_n2, ltab, &db))
-            redo |= 1u << s;
-        if (db == 1234.5f) {
+#if defined(SDR_ABLATE) && (SDR_ABLATE == 6 || SDR_ABLATE == 7)
+        if (p == 1234.5f)  // timing-only build: (almost) no stores
             pd[tk | sk] = p;
-            sp[tk | sk] = db;
-        }
 #else
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(p), pdr, tk * 4u, sk * 4, SDR_FFT_PSD_AUX);
-        float db = 0.0f;
-        if (!gomath::psd_value_in_db_fast(p, inv_n2, ltab, &db))
-            redo |= 1u << s;
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(db + 120.0f), spr, tk * 4u, sk * 4, SDR_FFT_SPEC_AUX);
 #endif
-        after_slot(s);
-    }
-    while (redo) {
-        const int s = __builtin_ctz(redo);
-        redo &= redo - 1;
-        int sl = 0;
-        constexpr fft64::Layout L = fft64::make_layout<LOGN>(PL::NPASS - 1);
-#pragma unroll
-        for (int j = 0; j < PL::LOGR; j++)
-            sl |= ((s >> j) & 1) << L.sbit[j];
-        const int k = ((tp | sl) + PL::N / 2) & (PL::N - 1);
-        const float p = __builtin_nontemporal_load(pd + k);  // this thread's own store, re-read
-        sp[k] = gomath::psd_value_in_db(p, inv_n2) + 120.0f;
     }
 }
 
-// (A persistent variant - the grid sized to the chip, each workgroup walking over frames, the next frame's
-// samples prefetched into the REGISTERS the projection frees, workgroups started staggered or not - measured
-// 5 % slower at N = 16384: 0.223 against 0.212 ms for 2048 frames.)
+// Where the time of a frame goes (N = 16384, tools/fft_trace.hip with -DSDR_FFT_CLOCK and the -DSDR_ABLATE
+// builds, MI355X at 2.3 GHz in-kernel): the phases of a frame run one after the other on its CU - all 16 waves
+// wait for the input, then all compute, then all exchange, ... - and each phase is bound by a different unit, so
+// their times ADD: nothing of another frame can run beside them, a frame's float64 state is half the CU's
+// register file.  Hence:
+//  * MULTI: a workgroup takes `fpw` consecutive frames and has the next frame's LDS-DMA in flight while it
+//    finishes the current one (SDR_FFT_DMA_AT: 0 = issued when the last exchange through LDS is over, 1 = just
+//    before the epilogue).  The wait at the top of the next frame is a COUNTED vmcnt: the DMA is older than the
+//    R psd stores that followed it, and vector-memory operations retire in order, so "all but the R youngest"
+//    covers the DMA without draining the stores.
+//  * no logarithm here (see the file header) - it was a fifth of the kernel.
+// Tried and measured no better: starting the first generation of workgroups staggered over a frame time (the
+// theory was that 256 CUs reading at the same moment and storing at the same moment make HBM bursts; spreading
+// them changed nothing), a persistent variant prefetching into the registers the epilogue frees (5 % slower).
 //
-// MULTI: a workgroup takes `fpw` consecutive frames.  The next frame's LDS-DMA is issued as soon as the current
-// frame's last exchange through LDS is over (SDR_FFT_DMA_AT 0; LDS is idle from then on and the DMA needs no
-// registers) or just before the projection (SDR_FFT_DMA_AT 1), so its HBM latency is covered by the current
-// frame's remaining passes and projection, and there is one dispatch gap per `fpw` frames.
-// `stagger_ticks` (100 MHz ticks): the first generation of workgroups (one per CU) starts in four phases a
-// quarter of this apart.  Workgroups of one launch all do the same work, so without it every CU reads its
-// frame at the same moment and stores its spectrum at the same moment: HBM sees 33 MB bursts with idle time
-// between them, and a prefetch issued by all CUs at once lands in the middle of everybody's store burst.
+// The tap.  `tap_bins[band][tap_stride]` lists the spectrum bins the band's listeners sit on (-1: free slot);
+// for each of them the frame's psd value goes to tap_out[band][frame][slot].  The value is re-read from the psd
+// row the workgroup has stored (thread l takes slot l), once those stores have certainly reached L2.  A MULTI
+// workgroup taps frame f-1 near the end of frame f: by then every wave has waited for twiddles it loaded during
+// frame f - younger than its stores of frame f-1, and vector-memory operations retire in order - and has passed
+// the barriers of the cross-wave exchange since, so all of frame f-1's stores are complete; the tap then costs
+// two instructions per listener and no drain.  The workgroup's last frame is tapped after a final drain.
 #if !defined(SDR_FFT_DMA_AT)
-#define SDR_FFT_DMA_AT 0
+#define SDR_FFT_DMA_AT 1
 #endif
+// (second launch bound = waves per SIMD the register allocation must leave room for: four, i.e. one 1024-thread
+// workgroup or two 512-thread ones per CU)
 template <int LOGN, bool MULTI>
-__global__ __launch_bounds__(fft64::Plan<LOGN>::T) void k_fft_project(const float *__restrict__ iq,
-                                                                      const fft64::cplx *__restrict__ tw,
-                                                                      float *__restrict__ spectrum,
-                                                                      float *__restrict__ psd, double inv_n2,
-                                                                      int in_stride, int out_stride, int n_frames,
-                                                                      int fpw, int stagger_ticks)
+__global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 ? 4 : 1)) void k_fft_psd(const float *__restrict__ iq,
+                                                                  const fft64::cplx *__restrict__ tw,
+                                                                  float *__restrict__ psd, int in_stride, int out_stride,
+                                                                  int n_frames, int fpw, const int *__restrict__ tap_bins,
+                                                                  float *__restrict__ tap_out, int n_tap, int tap_stride)
 {
     using PL = fft64::Plan<LOGN>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *lds = reinterpret_cast<double *>(smem);
-    // the 64-entry table of the certified fast dB path (gomath.h) follows the twiddles in HBM and sits
-    // behind the exchange area in LDS; the staging barriers publish it long before the epilogue
-    gomath::LogTabEntry *ltab = reinterpret_cast<gomath::LogTabEntry *>(smem + PL::LDS_BYTES);
 #if defined(SDR_FFT_TRACE)
     if ((threadIdx.x & 63) == 0)
         s_fft_trace_frame = 0;
 #endif
-    if constexpr (MULTI) {
-        if (stagger_ticks > 0 && blockIdx.x < 256u) {
-            const unsigned phase = (blockIdx.x >> 3) & 3u;  // blocks b and b + 8 share an XCD: spread within each
-            const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(phase * (unsigned)stagger_ticks / 4u);
-            while (__builtin_amdgcn_s_memrealtime() < until)
-                __builtin_amdgcn_s_sleep(8);
-        }
-    }
 #if defined(SDR_FFT_CLOCK)
     unsigned long long ck0 = 0, rt0 = 0;
     if (blockIdx.x == 100)
@@ -284,8 +247,6 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T) void k_fft_project(const floa
     rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     SDR_STAMP(0);
-    if (threadIdx.x < gomath::kLogTabSize)
-        ltab[threadIdx.x] = reinterpret_cast<const gomath::LogTabEntry *>(tw + PL::TW_TOTAL)[threadIdx.x];
     const int frame0 = MULTI ? blockIdx.x * fpw : blockIdx.x;
     const int frame_end = MULTI ? min(frame0 + fpw, n_frames) : frame0 + 1;
     const size_t in_band = (size_t)blockIdx.y * in_stride, out_band = (size_t)blockIdx.y * out_stride;
@@ -311,6 +272,16 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T) void k_fft_project(const floa
                                                      (unsigned)g * 16u, r * 1024, 0, SDR_FFT_DMA_AUX);
         }
     };
+    // tap of one finished frame (its psd stores are known to be complete, see above)
+    auto tap_frame = [&](int frame) {
+        const float *row = psd + (out_band + frame) * PL::N;
+        float *out = tap_out + (out_band + frame) * (size_t)tap_stride;
+        const int *bins = tap_bins + (size_t)blockIdx.y * tap_stride;
+        for (int l = threadIdx.x; l < n_tap; l += PL::T) {
+            const int bin = bins[l];
+            out[l] = bin >= 0 ? row[bin] : 0.0f;
+        }
+    };
     stage_frame(frame0, threadIdx.x);
 
 #pragma nounroll
@@ -324,15 +295,14 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T) void k_fft_project(const floa
         int t = threadIdx.x;
         if constexpr (MULTI)
             asm volatile("" : "+v"(t));
-        // Vector-memory operations retire in issue order for the counter (MI355X_MICROARCH.md: loads, stores and
-        // LDS-DMA count together, in issue order).  The first frame's DMA is the wave's only traffic: full drain.
-        // A later frame's DMA was issued BEFORE the previous frame's projection stores (2 per slot, plus whatever
-        // the rare redo loop added), so "all but the 2R youngest" covers it without also waiting for those stores
-        // to reach memory; with redo traffic on top it merely waits for a few of the stores as well.
+        // The first frame's DMA is the wave's only traffic: full drain.  A later frame's DMA is older than the
+        // previous frame's R psd stores (MI355X_MICROARCH.md: loads, stores and LDS-DMA count together, in issue
+        // order), so "all but the R youngest" covers it (tap traffic behind the stores only makes the wait cover
+        // some of the stores too).
         if (!MULTI || frame == frame0)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PL::R) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PL::R) : "memory");
         SDR_STAMP(12);  // this wave's rows have landed
         __syncthreads();
         SDR_STAMP(13);  // everybody's have
@@ -366,19 +336,20 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T) void k_fft_project(const floa
         if constexpr (MULTI && SDR_FFT_DMA_AT == 1)
             if (more)
                 stage_frame(frame + 1, t);
-        float *sp = spectrum + (out_band + frame) * PL::N;
-        float *pd = psd + (out_band + frame) * PL::N;
-#if defined(SDR_ABLATE) && (SDR_ABLATE == 4)
-#pragma unroll
-        for (int s = 0; s < PL::R; s++) {  // timing-only build: no projection
-            const int kk = fft64::output_bin<LOGN>(t, s);
-            pd[kk] = (float)xr[s];
-            sp[kk] = (float)xi[s];
+        store_psd<LOGN>(xr, xi, t, psd + (out_band + frame) * PL::N);
+        // (behind the DMA and the stores, so that its two dependent loads delay neither: the oldest waves - the
+        // ones that tap - reach the end of a frame microseconds before the youngest)
+        if constexpr (MULTI) {
+            static_assert(PL::NPASS >= 2, "the tap relies on pass-1 twiddle loads");
+            if (n_tap > 0 && frame > frame0)
+                tap_frame(frame - 1);
         }
-#else
-        project_and_store<LOGN>(xr, xi, t, sp, pd, inv_n2, ltab, [](int) {});
-#endif
         SDR_STAMP(10);
+    }
+    if (n_tap > 0 && frame_end > frame0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        tap_frame(frame_end - 1);
     }
 #if defined(SDR_FFT_TRACE)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -404,32 +375,22 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T) void k_fft_project(const floa
 #endif
 }
 
-constexpr int kLogTabBytes = gomath::kLogTabSize * (int)sizeof(gomath::LogTabEntry);
-
-// Tuning knobs, read once per process: SDR_FFT_FPW = frames per workgroup (default kDefaultFpw),
-// SDR_FFT_STAGGER_US = spread of the first workgroups' start times in microseconds.
-constexpr int kDefaultFpw = 1;
+// Tuning knob, read once per process: SDR_FFT_FPW = frames per workgroup.
+constexpr int kDefaultFpw = 1;  // in the pipeline short-lived workgroups win: 0.250 (1) / 0.253 (2) / 0.291 (4) / 0.294 ms (8) per step, standalone the other way round (0.174 / 0.166 / 0.165 / 0.164 ms)
 constexpr int kMaxDevices = 64;
-struct FftKnobs {
-    int fpw = kDefaultFpw;
-    int stagger_ticks = 0;
-};
-static const FftKnobs &fft_knobs()
+static int fft_fpw()
 {
-    static const FftKnobs k = [] {
-        FftKnobs v;
+    static const int v = [] {
         if (const char *e = getenv("SDR_FFT_FPW"))
-            v.fpw = std::max(1, std::min(atoi(e), 64));
-        if (const char *e = getenv("SDR_FFT_STAGGER_US"))
-            v.stagger_ticks = std::max(0, std::min((int)(atof(e) * 100.0), 100000));
-        return v;
+            return std::max(1, std::min(atoi(e), 64));
+        return kDefaultFpw;
     }();
-    return k;
+    return v;
 }
 
 template <int LOGN>
-static hipError_t launch_fft_t(const float *iq, const fft64::cplx *tw, float *spectrum, float *psd, int n_frames,
-                               int n_bands, int in_stride, int out_stride, hipStream_t stream)
+static hipError_t launch_fft_t(const float *iq, const fft64::cplx *tw, float *psd, int n_frames, int n_bands, int in_stride,
+                               int out_stride, FftTap tap, hipStream_t stream)
 {
     using PL = fft64::Plan<LOGN>;
     // the > 64 KB dynamic LDS attribute is per device: set it once on each device a bank launches on
@@ -442,39 +403,41 @@ static hipError_t launch_fft_t(const float *iq, const fft64::cplx *tw, float *sp
         return hipErrorInvalidDevice;
     hipError_t attr_err = hipSuccess;
     std::call_once(attr_once[dev], [&] {
-        for (const void *k : {reinterpret_cast<const void *>(&k_fft_project<LOGN, false>),
-                              reinterpret_cast<const void *>(&k_fft_project<LOGN, true>)}) {
-            const hipError_t ae = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, PL::LDS_BYTES + kLogTabBytes);
+        for (const void *k : {reinterpret_cast<const void *>(&k_fft_psd<LOGN, false>),
+                              reinterpret_cast<const void *>(&k_fft_psd<LOGN, true>)}) {
+            const hipError_t ae = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, PL::LDS_BYTES);
             if (ae != hipSuccess)
                 attr_err = ae;
         }
     });
     if (attr_err != hipSuccess)
         return attr_err;
-    const FftKnobs &kn = fft_knobs();
-    const double inv_n2 = 1.0 / ((double)PL::N * (double)PL::N);
     if (n_frames <= 0 || n_bands <= 0)
         return hipSuccess;
-    if (kn.fpw > 1)
-        hipLaunchKernelGGL((k_fft_project<LOGN, true>), dim3((n_frames + kn.fpw - 1) / kn.fpw, n_bands), dim3(PL::T),
-                           PL::LDS_BYTES + kLogTabBytes, stream, iq, tw, spectrum, psd, inv_n2, in_stride, out_stride, n_frames,
-                           kn.fpw, kn.stagger_ticks);
+    // a workgroup's frames are consecutive; never fewer workgroups than CUs can take (a short batch keeps one
+    // frame per workgroup)
+    int fpw = fft_fpw();
+    while (fpw > 1 && (long)((n_frames + fpw - 1) / fpw) * n_bands < 256)
+        fpw /= 2;
+    if (fpw > 1)
+        hipLaunchKernelGGL((k_fft_psd<LOGN, true>), dim3((n_frames + fpw - 1) / fpw, n_bands), dim3(PL::T), PL::LDS_BYTES, stream,
+                           iq, tw, psd, in_stride, out_stride, n_frames, fpw, tap.bins, tap.out, tap.n, tap.stride);
     else
-        hipLaunchKernelGGL((k_fft_project<LOGN, false>), dim3(n_frames, n_bands), dim3(PL::T), PL::LDS_BYTES + kLogTabBytes, stream,
-                           iq, tw, spectrum, psd, inv_n2, in_stride, out_stride, n_frames, 1, 0);
+        hipLaunchKernelGGL((k_fft_psd<LOGN, false>), dim3(n_frames, n_bands), dim3(PL::T), PL::LDS_BYTES, stream, iq, tw, psd,
+                           in_stride, out_stride, n_frames, 1, tap.bins, tap.out, tap.n, tap.stride);
     return hipGetLastError();
 }
 
-hipError_t launch_fft(int logn, const float *iq, const fft64::cplx *tw, float *spectrum, float *psd, int n_frames,
-                      int n_bands, int in_stride, int out_stride, hipStream_t stream)
+hipError_t launch_fft(int logn, const float *iq, const fft64::cplx *tw, float *psd, int n_frames, int n_bands, int in_stride,
+                      int out_stride, FftTap tap, hipStream_t stream)
 {
     switch (logn) {
-    case 9: return launch_fft_t<9>(iq, tw, spectrum, psd, n_frames, n_bands, in_stride, out_stride, stream);
-    case 10: return launch_fft_t<10>(iq, tw, spectrum, psd, n_frames, n_bands, in_stride, out_stride, stream);
-    case 11: return launch_fft_t<11>(iq, tw, spectrum, psd, n_frames, n_bands, in_stride, out_stride, stream);
-    case 12: return launch_fft_t<12>(iq, tw, spectrum, psd, n_frames, n_bands, in_stride, out_stride, stream);
-    case 13: return launch_fft_t<13>(iq, tw, spectrum, psd, n_frames, n_bands, in_stride, out_stride, stream);
-    case 14: return launch_fft_t<14>(iq, tw, spectrum, psd, n_frames, n_bands, in_stride, out_stride, stream);
+    case 9: return launch_fft_t<9>(iq, tw, psd, n_frames, n_bands, in_stride, out_stride, tap, stream);
+    case 10: return launch_fft_t<10>(iq, tw, psd, n_frames, n_bands, in_stride, out_stride, tap, stream);
+    case 11: return launch_fft_t<11>(iq, tw, psd, n_frames, n_bands, in_stride, out_stride, tap, stream);
+    case 12: return launch_fft_t<12>(iq, tw, psd, n_frames, n_bands, in_stride, out_stride, tap, stream);
+    case 13: return launch_fft_t<13>(iq, tw, psd, n_frames, n_bands, in_stride, out_stride, tap, stream);
+    case 14: return launch_fft_t<14>(iq, tw, psd, n_frames, n_bands, in_stride, out_stride, tap, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -3,9 +3,9 @@
 // (Morse timing state machine).  Compiled with -ffp-contract=off.
 //
 // Two kernels:
-//   k_listen_gather  data-parallel over (signal, frame): one wave takes 64 consecutive frames of one
-//                    signal, gathers spectrum[f][bin], compares against that frame's threshold and turns
-//                    the 64 results into one 64-bit word with a single ballot.
+//   k_listen_gather  data-parallel over (signal, frame): one lane takes 64 consecutive frames of one
+//                    signal, reads the psd values the FFT kernel tapped for it, projects them to dB,
+//                    compares against each frame's threshold and packs the 64 results into one word.
 //   k_listen_decode  one LANE per signal (64 signals per wave): the debouncer and the decoder are
 //                    inherently serial per signal, but between keying edges Decoder.Tick only counts, so
 //                    the lane walks RUNS of equal bits (ffs on the XOR-ed word) and handles each run in
@@ -15,36 +15,53 @@
 
 #include "../../include/sdrainer_hip.h"
 #include "cw_decoder.h"
+#include "gomath.h"
 #include "sdr_device.h"
 
 namespace sdr {
 
-__global__ __launch_bounds__(64) void k_listen_gather(const float *__restrict__ spectrum,
-                                                      const sdr_frame_rec *__restrict__ recs,
+// One lane per listener slot, one wave per 64 frames: lane l reads tap[f][l] for the wave's frames (the FFT kernel
+// wrote the psd value of the slot's bin there, k_fft_psd.hip "The tap"; neighbouring lanes read neighbouring
+// words), projects it to dB with the literal Go algorithm (0.5 M values per batch: no shortcut needed) and
+// collects its own 64 comparison results into one word.
+__global__ __launch_bounds__(64) void k_listen_gather(const float *__restrict__ tap, const sdr_frame_rec *__restrict__ recs,
                                                       const ListenerSlot *__restrict__ slots,
                                                       uint64_t *__restrict__ raw_bits, float *__restrict__ tr_values,
-                                                      uint8_t *__restrict__ tr_raw, ListenGeom g, int n_frames)
+                                                      uint8_t *__restrict__ tr_raw, ListenGeom g, int n_frames,
+                                                      int n_slots, double inv_n2)
 {
-    const int word = blockIdx.x, l = blockIdx.y, band = blockIdx.z, lane = threadIdx.x;
-    const size_t lidx = (size_t)band * g.max_listeners + l;
-    const ListenerSlot *slot = &slots[lidx];
-    if (!slot->active)
+    const int word = blockIdx.x, band = blockIdx.z;
+    const int l = blockIdx.y * 64 + threadIdx.x;
+    if (l >= n_slots)
         return;
-    const int f = word * 64 + lane;
-    float v = 0.f;
-    bool raw = false;
-    if (f < n_frames) {
-        v = spectrum[((size_t)band * g.stride + f) * g.n + slot->bin];
-        raw = v > recs[(size_t)band * g.stride + f].listen_thr;  // cw/spectral.go:49
+    const size_t lidx = (size_t)band * g.max_listeners + l;
+    if (!slots[lidx].active)
+        return;
+    const int f0 = word * 64;
+    const int cnt = min(64, n_frames - f0);
+    const size_t frame0 = (size_t)band * g.stride + f0;
+    uint64_t mask = 0;
+    for (int j0 = 0; j0 < cnt; j0 += 8) {
+        float p[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            p[k] = tap[(frame0 + min(j0 + k, cnt - 1)) * g.max_listeners + l];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int j = j0 + k;
+            if (j < cnt) {
+                const float v = gomath::psd_value_in_db(p[k], inv_n2) + (float)SDR_DBM_SHIFT;  // spectrum[SignalBin]
+                const bool raw = v > recs[frame0 + j].listen_thr;                              // cw/spectral.go:49
+                mask |= (uint64_t)raw << j;
+                if (g.trace) {
+                    const size_t ti = (frame0 + j) * g.max_listeners + l;
+                    tr_values[ti] = v;
+                    tr_raw[ti] = raw;
+                }
+            }
+        }
     }
-    const uint64_t mask = __ballot(raw);
-    if (lane == 0)
-        raw_bits[lidx * g.bit_words + word] = mask;
-    if (g.trace && f < n_frames) {
-        const size_t ti = ((size_t)band * g.stride + f) * g.max_listeners + l;
-        tr_values[ti] = v;
-        tr_raw[ti] = raw;
-    }
+    raw_bits[lidx * g.bit_words + word] = mask;
 }
 
 constexpr int DECODE_LANES = 16;
@@ -154,12 +171,13 @@ __global__ void k_set_debounce(ListenerSlot *slots, int n, int threshold)
         slots[i].deb.threshold = threshold;
 }
 
-hipError_t launch_listen_gather(const float *spectrum, const sdr_frame_rec *recs, const ListenerSlot *slots,
-                                uint64_t *raw_bits, float *tr_values, uint8_t *tr_raw, ListenGeom g, int n_frames,
-                                int n_slots, int n_bands, hipStream_t stream)
+hipError_t launch_listen_gather(const float *tap, const sdr_frame_rec *recs, const ListenerSlot *slots, uint64_t *raw_bits,
+                                float *tr_values, uint8_t *tr_raw, ListenGeom g, int n_frames, int n_slots, int n_bands,
+                                hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_listen_gather, dim3((n_frames + 63) / 64, n_slots, n_bands), dim3(64), 0, stream, spectrum,
-                       recs, slots, raw_bits, tr_values, tr_raw, g, n_frames);
+    const double inv_n2 = 1.0 / ((double)g.n * (double)g.n);
+    hipLaunchKernelGGL(k_listen_gather, dim3((n_frames + 63) / 64, (n_slots + 63) / 64, n_bands), dim3(64), 0, stream, tap, recs,
+                       slots, raw_bits, tr_values, tr_raw, g, n_frames, n_slots, inv_n2);
     return hipGetLastError();
 }
 

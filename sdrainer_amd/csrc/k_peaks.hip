@@ -1,4 +1,5 @@
-// k_peaks.hip — ordered float32 cumulation over 100 frames and the run-length peak scan of each completed cumulation.
+// k_peaks.hip — dB projection + ordered float32 cumulation over 100 frames, and the run-length peak scan of each
+// completed cumulation.  Compiled with -ffp-contract=off (see gomath.h).
 #include <hip/hip_runtime.h>
 
 #include "../../include/sdrainer_hip.h"
@@ -10,16 +11,38 @@
 namespace sdr {
 
 // ---------------------------------------------------------------------------------------------
-// k_cumulate — cumulation[i] += spectrum[i] (rx/receiver.go:404-407): a float32 sum in frame order.
+// k_cumulate — cumulation[i] += spectrum[i] (rx/receiver.go:404-407): a float32 sum in frame order, where
+// spectrum[i] = MagnitudeIndB(...) + dBmShift (dsp/fft.go:79-81, rx/receiver.go:377) is evaluated here from the
+// float32 psd the FFT kernel stored: the projection is a pure function of that value, and this is the only
+// place that needs it for every bin.  One thread per bin, lanes on neighbouring bins (coalesced 256-byte rows),
+// ten loads in flight, then ten ORDERED adds.  The certified table shortcut of gomath.h settles all but about
+// three values in 10^5; the rest take the literal Go algorithm in a (rare, divergent) branch.
 // Slot 0 continues the cumulation carried over from the previous batch; a slot that reaches 100
 // frames is written out for the peak scan, an incomplete last slot becomes the next carry.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_cumulate(const float *__restrict__ spectrum, const float *__restrict__ carry_in,
-                                                  float *__restrict__ carry_out, float *__restrict__ cum_out,
-                                                  CumGeom g)
+__device__ __forceinline__ float spectrum_value(float psd, gomath::DbTables t, double inv_n2)
 {
-    const int i4 = blockIdx.x * blockDim.x + threadIdx.x;  // group of 4 bins
-    if (i4 * 4 >= g.n)
+    float db;
+    if (!gomath::psd_value_in_db_fast(psd, t, &db))
+        db = gomath::psd_value_in_db(psd, inv_n2);
+    return db + (float)SDR_DBM_SHIFT;
+}
+
+__global__ __launch_bounds__(1024) void k_cumulate(const float *__restrict__ psd, const void *__restrict__ db_tab,
+                                                   const float *__restrict__ carry_in, float *__restrict__ carry_out,
+                                                   float *__restrict__ cum_out, CumGeom g, double inv_n2)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_tab[gomath::kDbTabBytes];
+    {
+        const uint4 *src = static_cast<const uint4 *>(db_tab);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_tab);
+        for (int i = threadIdx.x; i < gomath::kDbTabBytes / 16; i += blockDim.x)
+            dst[i] = src[i];
+    }
+    __syncthreads();
+    const gomath::DbTables tab = gomath::db_tables(s_tab);
+    const int bin = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bin >= g.n)
         return;
     const int slot = blockIdx.y, band = blockIdx.z;
     // frames of this slot: slot 0 takes (100 - count0) frames, later slots 100 each
@@ -27,39 +50,53 @@ __global__ __launch_bounds__(256) void k_cumulate(const float *__restrict__ spec
     const int begin = slot == 0 ? 0 : first_len + (slot - 1) * SDR_CUMULATION_SIZE;
     const int len = slot == 0 ? first_len : SDR_CUMULATION_SIZE;
     const int end = min(begin + len, g.n_frames);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float acc = 0.f;
     if (slot == 0 && g.count0 > 0)
-        acc = reinterpret_cast<const float4 *>(carry_in + (size_t)band * g.n)[i4];
-    const float4 *sp = reinterpret_cast<const float4 *>(spectrum + (size_t)band * g.stride * g.n) + i4;
-    const size_t fstride = g.n / 4;
+        acc = carry_in[(size_t)band * g.n + bin];
+    const float *col = psd + (size_t)band * g.stride * g.n + bin;
+    constexpr int U = 10;  // loads in flight, and independent dB evaluations between two ordered adds
     int f = begin;
-    for (; f + 10 <= end; f += 10) {  // ten independent 16-byte loads in flight, then ten ORDERED adds
-        float4 v[10];
+    for (; f + U <= end; f += U) {
+        float v[U], db[U];
 #pragma unroll
-        for (int k = 0; k < 10; k++)
-            v[k] = sp[(size_t)(f + k) * fstride];
+        for (int k = 0; k < U; k++)
+            v[k] = __builtin_nontemporal_load(col + (size_t)(f + k) * g.n);
+        // the shortcut for all of them, straight-line (ten independent float64 chains keep the pipe full); the
+        // literal algorithm only where the certificate failed - about one iteration in a hundred has such a lane
+        bool bad = false;
 #pragma unroll
-        for (int k = 0; k < 10; k++) {
-            acc.x += v[k].x;
-            acc.y += v[k].y;
-            acc.z += v[k].z;
-            acc.w += v[k].w;
+        for (int k = 0; k < U; k++)
+            bad |= !gomath::psd_value_in_db_fast(v[k], tab, &db[k]);
+        if (__builtin_amdgcn_ballot_w64(bad)) {
+#pragma unroll 1
+            for (int k = 0; k < U; k++) {
+                float t;
+                if (!gomath::psd_value_in_db_fast(v[k], tab, &t))
+                    db[k] = gomath::psd_value_in_db(v[k], inv_n2);
+            }
         }
+#pragma unroll
+        for (int k = 0; k < U; k++)
+            acc += db[k] + (float)SDR_DBM_SHIFT;  // MagnitudeIndB + dBmShift (float32 add), then the ordered sum
     }
-    for (; f < end; f++) {
-        const float4 v = sp[(size_t)f * fstride];
-        acc.x += v.x;
-        acc.y += v.y;
-        acc.z += v.z;
-        acc.w += v.w;
-    }
+    for (; f < end; f++)
+        acc += spectrum_value(__builtin_nontemporal_load(col + (size_t)f * g.n), tab, inv_n2);
     const bool complete = (begin + len) <= g.n_frames;
     if (complete) {
         // completed chunk index == slot (slot 0 completes first if it completes at all)
-        reinterpret_cast<float4 *>(cum_out + ((size_t)band * g.max_chunks + slot) * g.n)[i4] = acc;
+        cum_out[((size_t)band * g.max_chunks + slot) * g.n + bin] = acc;
     } else {
-        reinterpret_cast<float4 *>(carry_out + (size_t)band * g.n)[i4] = acc;
+        carry_out[(size_t)band * g.n + bin] = acc;
     }
+}
+
+// spectrum row of one frame from its psd row (parity reads and the scope tap: sdr_read_spectrum), literal algorithm
+__global__ __launch_bounds__(256) void k_spectrum_row(const float *__restrict__ psd, float *__restrict__ out, int n,
+                                                      double inv_n2)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        out[i] = gomath::psd_value_in_db(psd[i], inv_n2) + (float)SDR_DBM_SHIFT;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -134,11 +171,20 @@ __global__ __launch_bounds__(256) void k_find_peaks(const float *__restrict__ cu
     }
 }
 
-hipError_t launch_cumulate(const float *spectrum, const float *carry_in, float *carry_out, float *cum_out, CumGeom g,
-                           int n_slots, int n_bands, hipStream_t stream)
+hipError_t launch_cumulate(const float *psd, const void *db_tab, const float *carry_in, float *carry_out, float *cum_out,
+                           CumGeom g, int n_slots, int n_bands, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_cumulate, dim3((g.n / 4 + 255) / 256, n_slots, n_bands), dim3(256), 0, stream, spectrum,
-                       carry_in, carry_out, cum_out, g);
+    const int threads = g.n < 1024 ? g.n : 1024;
+    const double inv_n2 = 1.0 / ((double)g.n * (double)g.n);
+    hipLaunchKernelGGL(k_cumulate, dim3((g.n + threads - 1) / threads, n_slots, n_bands), dim3(threads), 0, stream, psd, db_tab,
+                       carry_in, carry_out, cum_out, g, inv_n2);
+    return hipGetLastError();
+}
+
+hipError_t launch_spectrum_row(const float *psd_row, float *out, int n, hipStream_t stream)
+{
+    const double inv_n2 = 1.0 / ((double)n * (double)n);
+    hipLaunchKernelGGL(k_spectrum_row, dim3((n + 255) / 256), dim3(256), 0, stream, psd_row, out, n, inv_n2);
     return hipGetLastError();
 }
 

@@ -7,17 +7,17 @@
 // leave the chip idle most of the step, so a bank is a software pipeline over four streams (four is
 // also the number of hardware queues HIP maps streams to by default; more streams alias and serialise):
 //
-//   s_fft     k_fft_project(i)                                        (the caller's stream)
-//   s_noise   k_window_means(i) -> k_noise_stats(i) -> k_thresholds(i) -> k_listen_gather(i)
-//   s_listen  k_listen_decode(i)        (the longest serial stage gets a stream of its own)
-//   s_peaks   k_cumulate(i) -> k_find_peaks(i)
+//   fft     k_fft_psd(i)                                          (the caller's stream)
+//   noise   k_window_means(i) -> k_noise_stats(i) -> k_thresholds(i)
+//   listen  k_listen_gather(i) -> k_listen_decode(i)
+//   peaks   k_cumulate(i) -> k_find_peaks(i)
 //
-// Batch i's per-batch buffers (spectrum, psd, frame records, keying bits, peaks ...) live in set
-// i % RING, and events order the stages: noise(i) after fft(i); thresholds(i) after noise(i); listen(i)
-// after thresholds(i); cumulate(i) after fft(i), find_peaks(i) after thresholds(i); fft(i) after every
-// reader of set i % RING from batch i - RING.  State that is carried from frame to frame is only ever
-// touched by one stage, whose stream keeps it in batch order.  Results are read after sdr_sync(), which
-// drains every stream.
+// Batch i's per-batch buffers (psd, tap, frame records, keying bits, peaks ...) live in set i % RING, and one
+// event per kernel orders the stages across streams (kDefaultPlan, process_device_body): window means and
+// cumulate after the FFT; gather after thresholds; find_peaks after cumulate and thresholds; fft(i) after every
+// reader of set i % RING from batch i - RING.  State that is carried from frame to frame is only ever touched
+// by one kernel, whose stream keeps it in batch order.  Results are read after sdr_sync(), which drains every
+// stream.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -80,17 +80,16 @@ int ilog2(int n)
     return s;
 }
 
-const char *kKernelNames[sdr::K_COUNT] = {"k_fft_project",   "k_window_means", "k_noise_stats", "k_thresholds",
+const char *kKernelNames[sdr::K_COUNT] = {"k_fft_psd",       "k_window_means", "k_noise_stats", "k_thresholds",
                                           "k_listen_gather", "k_cumulate",     "k_find_peaks",  "k_listen_decode"};
 
 constexpr int RING = 4;  // per-batch buffer sets in flight
-enum Stage { S_FFT = 0, S_NOISE, S_LISTEN, S_PEAKS, N_STAGES };
-constexpr int S_THR = N_STAGES;          // event slot of k_thresholds
-constexpr int S_NSTATS = N_STAGES + 1;  // event slot of k_noise_stats
+enum Stage { S_FFT = 0, S_NOISE, S_LISTEN, S_PEAKS, N_STAGES };  // the bank's streams
 
 // Everything one batch produces.
 struct BatchSet {
-    DevBuf<float> spectrum, psd;      // [band][max_batch][N]
+    DevBuf<float> psd;                // [band][max_batch][N] float32(re^2 + im^2), fft-shifted
+    DevBuf<float> tap;                // [band][max_batch][L] psd of each listener slot's bin
     DevBuf<double> win_mean;          // [band][max_batch][10]
     DevBuf<sdr_frame_rec> recs;       // [band][max_batch]
     DevBuf<uint64_t> raw_bits, bits;  // [band][L][bit_words] before / after the debouncer
@@ -101,11 +100,11 @@ struct BatchSet {
     DevBuf<float> cum_out;            // [band][max_chunks][N]
     DevBuf<sdr::DevPeak> dev_peaks;   // [band][max_chunks][max_peaks]
     DevBuf<int> peak_counts;          // [band][max_chunks]
-    hipEvent_t done[N_STAGES + 2] = {};  // recorded when the stage has finished with this set
+    hipEvent_t done[sdr::K_COUNT] = {};  // recorded behind each kernel of the batch that used this set
     void release()
     {
-        spectrum.release();
         psd.release();
+        tap.release();
         win_mean.release();
         recs.release();
         raw_bits.release();
@@ -143,6 +142,9 @@ struct sdr_bank {
     int bit_words = 0;
 
     DevBuf<fft64::cplx> tw;
+    DevBuf<unsigned char> db_tab;   // gomath.h tables of the certified dB shortcut (k_cumulate)
+    DevBuf<int32_t> tap_bins;       // [band][L] bin of every listener slot, -1 = free (k_fft_psd tap)
+    DevBuf<float> spectrum_row;     // scratch of sdr_read_spectrum
     DevBuf<float> iq_stage_dev;  // [band][max_batch][2N] for the host-staged path
     BatchSet set[RING];
     DevBuf<sdr::BandState> band_state;
@@ -162,6 +164,7 @@ struct sdr_bank {
     int last_set = 0, last_frames = 0, last_chunks = 0, last_count0 = 0;
     int edge_width = 0;
     int find_peaks = 1;
+    bool failed = false;  // a HIP call failed in the middle of a launch sequence: device state is unknown
 
     float *h_stage = nullptr;  // pinned [band][max_batch][2N]
     std::vector<int> staged;
@@ -272,7 +275,29 @@ size_t utf8_encode(uint32_t r, char *out)
     return 3;
 }
 
+int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_stride);
+
+// A failure after the first launch leaves the pipeline half enqueued (some stages of this batch ran, the
+// carried state of others did not advance): no later batch can be trusted, so the bank refuses further work.
 int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_stride)
+{
+    if (b->failed)
+        return fail(SDR_ERR_STATE, "an earlier process call failed half way; destroy the bank");
+    const int rc = process_device_body(b, iq_dev, n_frames, in_stride);
+    if (rc == SDR_ERR_HIP)
+        b->failed = true;
+    return rc;
+}
+
+// Which of the bank's four streams each kernel runs on (index = sdr::KernelId).  The step is as long as the
+// longest stream, and kernels that carry state from batch to batch (thresholds, decode, cumulate) must keep their
+// stream so that the stream orders the batches.  SDR_DIAG builds read an override from SDR_DIAG_PLAN (eight
+// digits) to try other plans.
+constexpr int kDefaultPlan[sdr::K_COUNT] = {
+    /* fft */ S_FFT, /* window means */ S_NOISE, /* noise stats */ S_NOISE, /* thresholds */ S_PEAKS,
+    /* gather */ S_LISTEN, /* cumulate */ S_PEAKS, /* find peaks */ S_PEAKS, /* decode */ S_LISTEN};
+
+int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_stride)
 {
     const sdr_config &c = b->cfg;
     if (n_frames <= 0)
@@ -284,10 +309,16 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     const sdr::NoiseGeom ng = b->noise_geom();
     const int si = (int)(b->batch_index % RING);
     BatchSet &S = b->set[si];
+    int plan[sdr::K_COUNT];
+    for (int k = 0; k < sdr::K_COUNT; k++)
+        plan[k] = kDefaultPlan[k];
 #if defined(SDR_DIAG)
     // diagnostic builds only (tools/abl): SDR_DIAG_SKIP = bit mask of kernel ids not to launch, to see
-    // which stage holds the pipelined step up.  Results are wrong by construction.
+    // which stage holds the pipelined step up (results are wrong by construction); SDR_DIAG_PLAN = stream plan.
     static const int diag_skip = getenv("SDR_DIAG_SKIP") ? atoi(getenv("SDR_DIAG_SKIP")) : 0;
+    if (const char *e = getenv("SDR_DIAG_PLAN"))
+        for (int k = 0; k < sdr::K_COUNT && e[k] >= '0' && e[k] < '0' + N_STAGES; k++)
+            plan[k] = e[k] - '0';
 #define SDR_LAUNCH(id, call) \
     do {                     \
         if (!(diag_skip >> (id) & 1)) \
@@ -296,64 +327,62 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
 #else
 #define SDR_LAUNCH(id, call) HIP_TRY(call)
 #endif
-    hipStream_t s_fft = b->stream[S_FFT], s_noise = b->stream[S_NOISE], s_listen = b->stream[S_LISTEN],
-                s_peaks = b->stream[S_PEAKS], s_thr = s_peaks, s_gather = s_peaks;
-    // Stream plan (the step is as long as the longest stream; in-situ durations, config 3):
-    //   fft    : k_fft_project                                        0.30 ms
-    //   noise  : window means -> noise stats                           0.22 ms
-    //   peaks  : thresholds -> gather -> cumulate -> find peaks        0.23 ms
-    //   listen : decode                                                0.18 ms
-    // With thresholds and gather behind the noise stats on the noise stream, that stream was as long as the
-    // FFT's and set the step (0.311 ms against 0.300 ms).  The cumulation deliberately stays BEHIND them in
-    // the peaks stream although it only needs the spectrum: enqueued first it runs straight after the FFT,
-    // beside the window means, and the step is back at 0.313 ms.
-#if defined(SDR_DIAG)
-    {
-        static const int thr_on = getenv("SDR_DIAG_THR") ? atoi(getenv("SDR_DIAG_THR")) : S_PEAKS;
-        static const int gat_on = getenv("SDR_DIAG_GATHER") ? atoi(getenv("SDR_DIAG_GATHER")) : S_PEAKS;
-        s_thr = b->stream[thr_on];
-        s_gather = b->stream[gat_on];
-        static const int dec_on = getenv("SDR_DIAG_DECODE") ? atoi(getenv("SDR_DIAG_DECODE")) : S_LISTEN;
-        s_listen = b->stream[dec_on];
-    }
-#endif
+    auto stream_of = [&](int k) { return b->stream[plan[k]]; };
+    // kernel k of this batch may start once kernel `dep` of this batch is done (nothing to do on the same stream)
+    auto after = [&](int k, int dep) -> int {
+        if (stream_of(k) != stream_of(dep))
+            HIP_TRY(hipStreamWaitEvent(stream_of(k), S.done[dep], 0));
+        return SDR_OK;
+    };
+#define SDR_AFTER(k, dep)          \
+    do {                           \
+        int _rc = after((k), (dep)); \
+        if (_rc)                   \
+            return _rc;            \
+    } while (0)
+#define SDR_DONE(k) HIP_TRY(hipEventRecord(S.done[k], stream_of(k)))
 
-    // stage 0: FFT + projection, once every reader of this set (batch i - RING) is done with it
-    // (with RING sets the previous user is four batches back and has almost always finished: ask the
-    // host first, a barrier packet in the FFT queue costs the command processor tens of microseconds)
-    for (int st : {(int)S_NOISE, (int)S_LISTEN, (int)S_PEAKS})
-        if (hipEventQuery(S.done[st]) != hipSuccess)
-            HIP_TRY(hipStreamWaitEvent(s_fft, S.done[st], 0));
-    {
-        ProfScope ps(b, sdr::K_FFT, s_fft);
-        SDR_LAUNCH(sdr::K_FFT, sdr::launch_fft(b->logn, iq_dev, b->tw.p, S.spectrum.p, S.psd.p, n_frames, B, in_stride, stride, s_fft));
-    }
-    HIP_TRY(hipEventRecord(S.done[S_FFT], s_fft));
-
-    // stage 1: noise floor (stateless per batch)
-    HIP_TRY(hipStreamWaitEvent(s_noise, S.done[S_FFT], 0));
-    {
-        ProfScope ps(b, sdr::K_WINDOW_MEANS, s_noise);
-        SDR_LAUNCH(sdr::K_WINDOW_MEANS, sdr::launch_window_means(S.psd.p, S.win_mean.p, ng, n_frames, B, stride, s_noise));
-    }
-    {
-        ProfScope ps(b, sdr::K_NOISE_STATS, s_noise);
-        SDR_LAUNCH(sdr::K_NOISE_STATS, sdr::launch_noise_stats(S.psd.p, S.win_mean.p, S.recs.p, ng, n_frames, B, stride, s_noise));
-    }
-    HIP_TRY(hipEventRecord(S.done[S_NSTATS], s_noise));
-    // rolling means -> thresholds, in batch order (always the same stream)
-    if (s_thr != s_noise)
-        HIP_TRY(hipStreamWaitEvent(s_thr, S.done[S_NSTATS], 0));
-    {
-        ProfScope ps(b, sdr::K_THRESHOLDS, s_thr);
-        SDR_LAUNCH(sdr::K_THRESHOLDS, sdr::launch_thresholds(S.recs.p, b->band_state.p, n_frames, B, stride, s_thr));
-    }
-    HIP_TRY(hipEventRecord(S.done[S_THR], s_thr));
-
-    // stage 2: per-signal envelope + decoder
+    // FFT + PSD + tap, once every reader of this set (batch i - RING) is done with it (with RING sets the
+    // previous user is four batches back and has almost always finished: ask the host first, a barrier packet in
+    // the FFT queue costs the command processor tens of microseconds)
+    for (int k = 1; k < sdr::K_COUNT; k++)
+        if (stream_of(k) != stream_of(sdr::K_FFT) && hipEventQuery(S.done[k]) != hipSuccess)
+            HIP_TRY(hipStreamWaitEvent(stream_of(sdr::K_FFT), S.done[k], 0));
     int max_slots = 0;
     for (int i = 0; i < B; i++)
         max_slots = std::max(max_slots, b->n_slots[i]);
+    {
+        ProfScope ps(b, sdr::K_FFT, stream_of(sdr::K_FFT));
+        const sdr::FftTap tap{b->tap_bins.p, S.tap.p, max_slots, c.max_listeners};
+        SDR_LAUNCH(sdr::K_FFT, sdr::launch_fft(b->logn, iq_dev, b->tw.p, S.psd.p, n_frames, B, in_stride, stride, tap,
+                                               stream_of(sdr::K_FFT)));
+    }
+    SDR_DONE(sdr::K_FFT);
+
+    // noise floor (stateless per batch), then the rolling means -> thresholds, in batch order
+    SDR_AFTER(sdr::K_WINDOW_MEANS, sdr::K_FFT);
+    {
+        ProfScope ps(b, sdr::K_WINDOW_MEANS, stream_of(sdr::K_WINDOW_MEANS));
+        SDR_LAUNCH(sdr::K_WINDOW_MEANS, sdr::launch_window_means(S.psd.p, S.win_mean.p, ng, n_frames, B, stride,
+                                                                 stream_of(sdr::K_WINDOW_MEANS)));
+    }
+    SDR_DONE(sdr::K_WINDOW_MEANS);
+    SDR_AFTER(sdr::K_NOISE_STATS, sdr::K_WINDOW_MEANS);
+    {
+        ProfScope ps(b, sdr::K_NOISE_STATS, stream_of(sdr::K_NOISE_STATS));
+        SDR_LAUNCH(sdr::K_NOISE_STATS, sdr::launch_noise_stats(S.psd.p, S.win_mean.p, S.recs.p, ng, n_frames, B, stride,
+                                                               stream_of(sdr::K_NOISE_STATS)));
+    }
+    SDR_DONE(sdr::K_NOISE_STATS);
+    SDR_AFTER(sdr::K_THRESHOLDS, sdr::K_NOISE_STATS);
+    {
+        ProfScope ps(b, sdr::K_THRESHOLDS, stream_of(sdr::K_THRESHOLDS));
+        SDR_LAUNCH(sdr::K_THRESHOLDS, sdr::launch_thresholds(S.recs.p, b->band_state.p, n_frames, B, stride,
+                                                             stream_of(sdr::K_THRESHOLDS)));
+    }
+    SDR_DONE(sdr::K_THRESHOLDS);
+
+    // per-signal envelope + decoder
     sdr::ListenGeom lg;
     lg.n = N;
     lg.stride = stride;
@@ -363,22 +392,25 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     lg.bit_words = b->bit_words;
     lg.trace = c.trace;
     lg.frame_base = (uint32_t)b->total_frames;
-    HIP_TRY(hipStreamWaitEvent(s_gather, S.done[S_THR], 0));
+    SDR_AFTER(sdr::K_LISTEN_GATHER, sdr::K_THRESHOLDS);
+    SDR_AFTER(sdr::K_LISTEN_GATHER, sdr::K_FFT);
     if (max_slots > 0) {
-        ProfScope ps(b, sdr::K_LISTEN_GATHER, s_gather);
-        SDR_LAUNCH(sdr::K_LISTEN_GATHER, sdr::launch_listen_gather(S.spectrum.p, S.recs.p, b->slots.p, S.raw_bits.p, S.tr_values.p, S.tr_raw.p,
-                                          lg, n_frames, max_slots, B, s_gather));
+        ProfScope ps(b, sdr::K_LISTEN_GATHER, stream_of(sdr::K_LISTEN_GATHER));
+        SDR_LAUNCH(sdr::K_LISTEN_GATHER, sdr::launch_listen_gather(S.tap.p, S.recs.p, b->slots.p, S.raw_bits.p, S.tr_values.p,
+                                                                   S.tr_raw.p, lg, n_frames, max_slots, B,
+                                                                   stream_of(sdr::K_LISTEN_GATHER)));
     }
-    HIP_TRY(hipEventRecord(S.done[S_NOISE], s_gather));  // the noise stream is done with this set
-    HIP_TRY(hipStreamWaitEvent(s_listen, S.done[S_NOISE], 0));
+    SDR_DONE(sdr::K_LISTEN_GATHER);
+    SDR_AFTER(sdr::K_LISTEN_DECODE, sdr::K_LISTEN_GATHER);
     if (max_slots > 0) {
-        ProfScope ps(b, sdr::K_LISTEN_DECODE, s_listen);
-        SDR_LAUNCH(sdr::K_LISTEN_DECODE, sdr::launch_listen_decode(b->slots.p, b->morse.p, S.raw_bits.p, S.bits.p, b->text.p, S.edges.p,
-                                          S.edge_counts.p, S.tr_deb.p, lg, n_frames, B, s_listen));
+        ProfScope ps(b, sdr::K_LISTEN_DECODE, stream_of(sdr::K_LISTEN_DECODE));
+        SDR_LAUNCH(sdr::K_LISTEN_DECODE, sdr::launch_listen_decode(b->slots.p, b->morse.p, S.raw_bits.p, S.bits.p, b->text.p,
+                                                                   S.edges.p, S.edge_counts.p, S.tr_deb.p, lg, n_frames, B,
+                                                                   stream_of(sdr::K_LISTEN_DECODE)));
     }
-    HIP_TRY(hipEventRecord(S.done[S_LISTEN], s_listen));
+    SDR_DONE(sdr::K_LISTEN_DECODE);
 
-    // stage 3: cumulation + peak scan (rx/receiver.go:404-409,459-460)
+    // dB projection + cumulation, peak scan (rx/receiver.go:404-409,459-460)
     const int count0 = b->cum_count;
     const int first_len = SDR_CUMULATION_SIZE - count0;
     int n_slots_c = 1, n_chunks = 0;
@@ -387,26 +419,34 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         const int rem = (n_frames - first_len) % SDR_CUMULATION_SIZE;
         n_slots_c = n_chunks + (rem > 0 ? 1 : 0);
     }
-    HIP_TRY(hipStreamWaitEvent(s_peaks, S.done[S_FFT], 0));
+    SDR_AFTER(sdr::K_CUMULATE, sdr::K_FFT);
     {
-        ProfScope ps(b, sdr::K_CUMULATE, s_peaks);
+        ProfScope ps(b, sdr::K_CUMULATE, stream_of(sdr::K_CUMULATE));
         sdr::CumGeom cg{N, stride, n_frames, count0, b->max_chunks};
-        SDR_LAUNCH(sdr::K_CUMULATE, sdr::launch_cumulate(S.spectrum.p, b->carry[b->carry_cur].p, b->carry[b->carry_cur ^ 1].p, S.cum_out.p,
-                                     cg, n_slots_c, B, s_peaks));
+        SDR_LAUNCH(sdr::K_CUMULATE, sdr::launch_cumulate(S.psd.p, b->db_tab.p, b->carry[b->carry_cur].p,
+                                                         b->carry[b->carry_cur ^ 1].p, S.cum_out.p, cg, n_slots_c, B,
+                                                         stream_of(sdr::K_CUMULATE)));
     }
+    SDR_DONE(sdr::K_CUMULATE);
     const int new_count = (count0 + n_frames) % SDR_CUMULATION_SIZE;
-    // the carry buffer flips only when this batch wrote a new partial cumulation; if the batch ended
+    SDR_AFTER(sdr::K_FIND_PEAKS, sdr::K_CUMULATE);
+    if (b->find_peaks && n_chunks > 0) {
+        SDR_AFTER(sdr::K_FIND_PEAKS, sdr::K_THRESHOLDS);  // needs the completing frame's peak threshold
+        ProfScope ps(b, sdr::K_FIND_PEAKS, stream_of(sdr::K_FIND_PEAKS));
+        sdr::PeakGeom pg{N, stride, count0, b->max_chunks, c.max_peaks};
+        SDR_LAUNCH(sdr::K_FIND_PEAKS, sdr::launch_find_peaks(S.cum_out.p, S.recs.p, S.dev_peaks.p, S.peak_counts.p, pg, n_chunks, B,
+                                                             stream_of(sdr::K_FIND_PEAKS)));
+    }
+    SDR_DONE(sdr::K_FIND_PEAKS);
+#undef SDR_AFTER
+#undef SDR_DONE
+#undef SDR_LAUNCH
+
+    // every launch of the batch is enqueued: commit the host's view of the carried state in one go.
+    // The carry buffer flips only when this batch wrote a new partial cumulation; if the batch ended
     // exactly on a chunk boundary the next batch starts from zero (count0 == 0 ignores the carry)
     if (new_count != 0)
         b->carry_cur ^= 1;
-    if (b->find_peaks && n_chunks > 0) {
-        HIP_TRY(hipStreamWaitEvent(s_peaks, S.done[S_THR], 0));  // needs the completing frame's peak threshold
-        ProfScope ps(b, sdr::K_FIND_PEAKS, s_peaks);
-        sdr::PeakGeom pg{N, stride, count0, b->max_chunks, c.max_peaks};
-        SDR_LAUNCH(sdr::K_FIND_PEAKS, sdr::launch_find_peaks(S.cum_out.p, S.recs.p, S.dev_peaks.p, S.peak_counts.p, pg, n_chunks, B, s_peaks));
-    }
-    HIP_TRY(hipEventRecord(S.done[S_PEAKS], s_peaks));
-
     b->cum_count = new_count;
     b->last_set = si;
     b->last_frames = n_frames;
@@ -480,23 +520,26 @@ int sdr_create(const sdr_config *cfg, sdr_bank **out)
     {
         std::vector<double> wre, wim;
         fft64::radix2_factors(N, wre, wim);
-        // [twiddles][64-entry table of the fast dB path], both 16-byte entries
         const size_t ntw = (size_t)sdr::twiddle_count(b->logn);
-        std::vector<fft64::cplx> h(ntw + gomath::kLogTabSize);
+        std::vector<fft64::cplx> h(ntw);
         sdr::build_twiddles(b->logn, wre.data(), wim.data(), h.data());
-        static_assert(sizeof(gomath::LogTabEntry) == sizeof(fft64::cplx), "table entries share the twiddle buffer");
-        gomath::build_log_table(reinterpret_cast<gomath::LogTabEntry *>(h.data() + ntw));
         ALLOC(b->tw, h.size());
         hipError_t e = hipMemcpy(b->tw.p, h.data(), h.size() * sizeof(fft64::cplx), hipMemcpyHostToDevice);
+        // tables of the certified dB shortcut (they fold log2 N in)
+        std::vector<unsigned char> tab(gomath::kDbTabBytes);
+        gomath::build_db_tables(b->logn, tab.data());
+        ALLOC(b->db_tab, tab.size());
+        if (e == hipSuccess)
+            e = hipMemcpy(b->db_tab.p, tab.data(), tab.size(), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             sdr_destroy(b);
-            return fail(SDR_ERR_HIP, "twiddle upload failed");
+            return fail(SDR_ERR_HIP, "twiddle / table upload failed");
         }
     }
     for (int r = 0; r < RING; r++) {
         BatchSet &S = b->set[r];
-        ALLOC(S.spectrum, B * F * N);
         ALLOC(S.psd, B * F * N);
+        ALLOC(S.tap, B * F * std::max<size_t>(L, 1));
         ALLOC(S.win_mean, B * F * 10);
         ALLOC(S.recs, B * F);
         ALLOC(S.raw_bits, B * L * (size_t)b->bit_words);
@@ -520,6 +563,16 @@ int sdr_create(const sdr_config *cfg, sdr_bank **out)
         }
     }
     ALLOC(b->band_state, B);
+    ALLOC(b->spectrum_row, (size_t)N);
+    ALLOC(b->tap_bins, B * std::max<size_t>(L, 1));
+    {
+        std::vector<int32_t> free_bins(B * std::max<size_t>(L, 1), -1);
+        hipError_t he = hipMemcpy(b->tap_bins.p, free_bins.data(), free_bins.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+        if (he != hipSuccess) {
+            sdr_destroy(b);
+            return fail(SDR_ERR_HIP, "tap table upload failed");
+        }
+    }
     ALLOC(b->slots, B * L);
     ALLOC(b->morse, cw::kMorseTableSize);
     ALLOC(b->text, B * L * (size_t)b->text_cap);
@@ -557,6 +610,9 @@ int sdr_destroy(sdr_bank *b)
         (void)hipStreamSynchronize(b->stream[s]);
     resolve_profile(b);
     b->tw.release();
+    b->db_tab.release();
+    b->tap_bins.release();
+    b->spectrum_row.release();
     b->iq_stage_dev.release();
     for (auto &S : b->set)
         S.release();
@@ -774,6 +830,8 @@ int sdr_attach(sdr_bank *b, int band, int bin, int *listener_id)
     if (rc)
         return rc;
     HIP_TRY(hipMemcpy(b->slots.p + (size_t)band * c.max_listeners + lid, &s, sizeof s, hipMemcpyHostToDevice));
+    const int32_t tap_bin = bin;
+    HIP_TRY(hipMemcpy(b->tap_bins.p + (size_t)band * c.max_listeners + lid, &tap_bin, sizeof tap_bin, hipMemcpyHostToDevice));
     if (listener_id)
         *listener_id = lid;
     return SDR_OK;
@@ -792,6 +850,9 @@ int sdr_detach(sdr_bank *b, int band, int lid)
     if (rc)
         return rc;
     HIP_TRY(hipMemcpy(&b->slots.p[(size_t)band * b->cfg.max_listeners + lid].active, &s.active, sizeof(int32_t),
+                      hipMemcpyHostToDevice));
+    const int32_t free_bin = -1;
+    HIP_TRY(hipMemcpy(b->tap_bins.p + (size_t)band * b->cfg.max_listeners + lid, &free_bin, sizeof free_bin,
                       hipMemcpyHostToDevice));
     return SDR_OK;
 }
@@ -1065,8 +1126,12 @@ int sdr_read_spectrum(sdr_bank *b, int band, int frame, float *spectrum, float *
     const size_t N = (size_t)b->cfg.block_size;
     const size_t off = ((size_t)band * b->cfg.max_batch_frames + frame) * N;
     const BatchSet &S = b->set[b->last_set];
-    if (spectrum)
-        HIP_TRY(hipMemcpy(spectrum, S.spectrum.p + off, sizeof(float) * N, hipMemcpyDeviceToHost));
+    if (spectrum) {
+        // the pipeline keeps psd only; the dB projection of the row is made on demand (dsp/fft.go:79-81)
+        HIP_TRY(sdr::launch_spectrum_row(S.psd.p + off, b->spectrum_row.p, (int)N, b->stream[S_FFT]));
+        HIP_TRY(hipStreamSynchronize(b->stream[S_FFT]));
+        HIP_TRY(hipMemcpy(spectrum, b->spectrum_row.p, sizeof(float) * N, hipMemcpyDeviceToHost));
+    }
     if (psd)
         HIP_TRY(hipMemcpy(psd, S.psd.p + off, sizeof(float) * N, hipMemcpyDeviceToHost));
     return SDR_OK;

@@ -64,8 +64,16 @@ enum KernelId {
     K_COUNT
 };
 
-hipError_t launch_fft(int logn, const float *iq, const fft64::cplx *tw, float *spectrum, float *psd, int n_frames,
-                      int n_bands, int in_stride, int out_stride, hipStream_t stream);
+// The listeners' bins of every band and where their psd values go (k_fft_psd.hip "The tap").
+struct FftTap {
+    const int32_t *bins;  // [band][stride], -1 = free slot
+    float *out;           // [band][out_stride frames][stride]
+    int n;                // slots in use (high-water mark over the bands); 0 = no tap
+    int stride;           // max_listeners
+};
+
+hipError_t launch_fft(int logn, const float *iq, const fft64::cplx *tw, float *psd, int n_frames, int n_bands, int in_stride,
+                      int out_stride, FftTap tap, hipStream_t stream);
 int twiddle_count(int logn);
 void build_twiddles(int logn, const double *wre, const double *wim, fft64::cplx *out);
 hipError_t launch_window_means(const float *psd, double *win_mean, NoiseGeom g, int n_frames, int n_bands, int stride,
@@ -74,17 +82,18 @@ hipError_t launch_noise_stats(const float *psd, const double *win_mean, sdr_fram
                               int n_bands, int stride, hipStream_t stream);
 hipError_t launch_thresholds(sdr_frame_rec *recs, BandState *st, int n_frames, int n_bands, int stride,
                              hipStream_t stream);
-hipError_t launch_listen_gather(const float *spectrum, const sdr_frame_rec *recs, const ListenerSlot *slots,
-                                uint64_t *raw_bits, float *tr_values, uint8_t *tr_raw, ListenGeom g, int n_frames,
-                                int n_slots, int n_bands, hipStream_t stream);
+hipError_t launch_listen_gather(const float *tap, const sdr_frame_rec *recs, const ListenerSlot *slots, uint64_t *raw_bits,
+                                float *tr_values, uint8_t *tr_raw, ListenGeom g, int n_frames, int n_slots, int n_bands,
+                                hipStream_t stream);
 hipError_t launch_listen_decode(ListenerSlot *slots, const uint16_t *morse, const uint64_t *raw_bits,
                                 uint64_t *deb_bits, uint32_t *text, sdr_edge *edges, uint32_t *edge_counts,
                                 uint8_t *tr_deb, ListenGeom g, int n_frames, int n_bands, hipStream_t stream);
 hipError_t launch_listener_stop(ListenerSlot *slot, const uint16_t *morse, uint32_t *text, int text_cap,
                                 hipStream_t stream);
 hipError_t launch_set_debounce(ListenerSlot *slots, int n, int threshold, hipStream_t stream);
-hipError_t launch_cumulate(const float *spectrum, const float *carry_in, float *carry_out, float *cum_out, CumGeom g,
-                           int n_slots, int n_bands, hipStream_t stream);
+hipError_t launch_cumulate(const float *psd, const void *db_tab, const float *carry_in, float *carry_out, float *cum_out,
+                           CumGeom g, int n_slots, int n_bands, hipStream_t stream);
+hipError_t launch_spectrum_row(const float *psd_row, float *out, int n, hipStream_t stream);
 hipError_t launch_unpack_be16(const uint8_t *raw, float *out, size_t n_values, hipStream_t stream);
 hipError_t launch_find_peaks(const float *cum, const sdr_frame_rec *recs, DevPeak *peaks, int *counts, PeakGeom g,
                              int n_chunks, int n_bands, hipStream_t stream);

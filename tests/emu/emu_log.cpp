@@ -14,8 +14,10 @@
 int main(int argc, char **argv)
 {
     const long n_random = argc > 1 ? atol(argv[1]) : 20000000L;
-    gomath::LogTabEntry tab[gomath::kLogTabSize];
-    gomath::build_log_table(tab);
+    // one table blob per block size (the exponent table folds log2 N in)
+    static unsigned char blobs[15][gomath::kDbTabBytes] __attribute__((aligned(16)));
+    for (int logn = 9; logn <= 14; logn++)
+        gomath::build_db_tables(logn, blobs[logn]);
     std::mt19937_64 rng(12345);
     long tested = 0, accepted = 0, mismatches = 0;
     double max_dy = 0;
@@ -23,7 +25,8 @@ int main(int argc, char **argv)
         const double inv_n2 = std::ldexp(1.0, -2 * logn);
         const float exact = gomath::psd_value_in_db(psd, inv_n2);
         float fast = 0;
-        const bool ok = gomath::psd_value_in_db_fast(psd, inv_n2, tab, &fast);
+        const gomath::DbTables tab = gomath::db_tables(blobs[logn]);
+        const bool ok = gomath::psd_value_in_db_fast(psd, tab, &fast);
         tested++;
         if (ok) {
             accepted++;
@@ -34,24 +37,24 @@ int main(int argc, char **argv)
             }
         }
         const double v = 20.0 * (double)psd * inv_n2;
-        if (v >= 2.2250738585072014e-308 && v < INFINITY) {
-            const double dy = std::fabs(gomath::db_fast_y(v, tab) - 10.0 * gomath::log10(v));
+        if (v >= 2.2250738585072014e-308 && v < INFINITY && std::fabs(psd) >= 1.17549435e-38f) {
+            const double dy = std::fabs(gomath::db_fast_y(psd, tab) - 10.0 * gomath::log10(v));
             if (dy > max_dy)
                 max_dy = dy;
         }
     };
-    // every float32 exponent, a sweep of mantissas around interval edges of the 64-entry table
+    // every float32 exponent, a sweep of mantissas around interval edges of the 1024-entry table
     for (int e = 1; e < 255; e++)
-        for (int k = 0; k < 64; k++)
-            for (int d = -3; d <= 3; d++) {
-                uint32_t b = ((uint32_t)e << 23) | (((uint32_t)k << 17) + (uint32_t)d) % (1u << 23);
+        for (int k = 0; k < 1024; k += (e % 8 == 0 ? 1 : 16))
+            for (int d = -2; d <= 2; d++) {
+                uint32_t b = ((uint32_t)e << 23) | (((uint32_t)k << 13) + (uint32_t)d) % (1u << 23);
                 float f;
                 std::memcpy(&f, &b, sizeof f);
                 for (int logn = 9; logn <= 14; logn++)
                     one(f, logn);
             }
     // special values
-    const float specials[] = {0.f, -0.f, -1.f, INFINITY, NAN, 1e-45f, 1.17549435e-38f, 3.4e38f, 1.f, 2.f, 0.5f};
+    const float specials[] = {0.f, -0.f, -1.f, -1e-40f, INFINITY, -INFINITY, NAN, -NAN, 1e-45f, 1.1e-38f, 1.17549435e-38f, 3.4e38f, 1.f, 2.f, 0.5f};
     for (float f : specials)
         for (int logn = 9; logn <= 14; logn++)
             one(f, logn);

@@ -265,7 +265,7 @@ def test_device_resident_input_and_profile(capi):
     bank.process_device(t.data_ptr(), frames)
     bank.sync()
     prof = bank.profile_read()
-    assert prof["k_fft_project"][1] == 1 and prof["k_fft_project"][0] > 0
+    assert prof["k_fft_psd"][1] == 1 and prof["k_fft_psd"][0] > 0
     ref = orc.Receiver(rate, n, synth.default_edge_width(n))
     out = ref.process(iq)
     _assert_records_equal(bank.read_frame_records(0), out["frames"])

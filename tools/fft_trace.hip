@@ -1,4 +1,4 @@
-// Development aid (not part of the product): per-wave phase timeline of one k_fft_project workgroup.
+// Development aid (not part of the product): per-wave phase timeline of one k_fft_psd workgroup.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -o tools/fft_trace tools/fft_trace.hip
 #include <hip/hip_runtime.h>
 
@@ -9,14 +9,14 @@
 #include <vector>
 
 // -DSDR_ABLATE=n builds time the kernel with one ingredient removed (no stamps then)
-#if !defined(SDR_ABLATE) && !defined(SDR_FFT_STOP)
+#if !defined(SDR_ABLATE)
 #define SDR_FFT_TRACE 100
 #endif
 __device__ unsigned long long g_fft_trace[2][16][16];
 #if defined(SDR_FFT_CLOCK)
 namespace sdr { __device__ unsigned long long g_fft_clock[2]; __device__ unsigned long long g_fft_wg[2048][4]; }
 #endif
-#include "../sdrainer_amd/csrc/k_fft_project.hip"
+#include "../sdrainer_amd/csrc/k_fft_psd.hip"
 #include "../sdrainer_amd/csrc/twiddles.h"
 
 int main(int argc, char **argv)
@@ -25,16 +25,29 @@ int main(int argc, char **argv)
     std::vector<double> wre, wim;
     fft64::radix2_factors(N, wre, wim);
     const size_t ntw = (size_t)sdr::twiddle_count(logn);
-    std::vector<fft64::cplx> h(ntw + gomath::kLogTabSize * sizeof(gomath::LogTabEntry) / sizeof(fft64::cplx) + 1);
+    std::vector<fft64::cplx> h(ntw);
     sdr::build_twiddles(logn, wre.data(), wim.data(), h.data());
-    gomath::build_log_table(reinterpret_cast<gomath::LogTabEntry *>(h.data() + ntw));
     fft64::cplx *tw;
-    float *iq, *sp, *pd;
+    float *iq, *pd;
     hipMalloc(&tw, h.size() * sizeof(fft64::cplx));
     hipMemcpy(tw, h.data(), h.size() * sizeof(fft64::cplx), hipMemcpyHostToDevice);
     hipMalloc(&iq, (size_t)frames * N * 8);
-    hipMalloc(&sp, (size_t)frames * N * 4);
     hipMalloc(&pd, (size_t)frames * N * 4);
+    // the tap: SDR_TAP listeners (default 256) on evenly spread bins
+    const int n_tap = getenv("SDR_TAP") ? atoi(getenv("SDR_TAP")) : 256;
+    sdr::FftTap tap{nullptr, nullptr, n_tap, n_tap > 0 ? n_tap : 1};
+    if (n_tap > 0) {
+        std::vector<int32_t> bins(n_tap);
+        for (int i = 0; i < n_tap; i++)
+            bins[i] = 2300 + i * 40;
+        int32_t *dbins;
+        hipMalloc(&dbins, n_tap * 4);
+        hipMemcpy(dbins, bins.data(), n_tap * 4, hipMemcpyHostToDevice);
+        float *dout;
+        hipMalloc(&dout, (size_t)frames * n_tap * 4);
+        tap.bins = dbins;
+        tap.out = dout;
+    }
     std::vector<float> x((size_t)frames * N * 2);
     unsigned s = 1;
     for (auto &v : x) {
@@ -45,35 +58,10 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-#if defined(SDR_FFT_STOP)
-    {
-        // phase ids as stamped in k_fft_project.hip; 99 = run to the end
-        const int ids[] = {13, 1, 2, 3, 4, 5, 6, 7, 8, 10, 99};
-        const char *what[] = {"staged(all)", "in regs", "pass0", "ex0", "pass1", "ex1", "pass2", "ex2", "pass3", "stored", "full"};
-        float prev = 0.f;
-        for (int i = 0; i < 11; i++) {
-            hipMemcpyToSymbol(HIP_SYMBOL(sdr::g_fft_stop_at), &ids[i], sizeof(int));
-            float b = 1e9f;
-            for (int rep = 0; rep < 7; rep++) {
-                hipEventRecord(e0, 0);
-                sdr::launch_fft(logn, iq, tw, sp, pd, frames, 1, frames, frames, 0);
-                hipEventRecord(e1, 0);
-                hipEventSynchronize(e1);
-                float ms;
-                hipEventElapsedTime(&ms, e0, e1);
-                if (rep >= 2 && ms < b)
-                    b = ms;
-            }
-            printf("stop after %-12s %.4f ms  (+%.4f)  = %.2f us per frame-generation\n", what[i], b, b - prev, 1e3 * b / ((frames + 255) / 256));
-            prev = b;
-        }
-        return 0;
-    }
-#endif
     float best = 1e9f;
     for (int rep = 0; rep < 8; rep++) {
         hipEventRecord(e0, 0);
-        sdr::launch_fft(logn, iq, tw, sp, pd, frames, 1, frames, frames, 0);
+        sdr::launch_fft(logn, iq, tw, pd, frames, 1, frames, frames, tap, 0);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms;
@@ -82,11 +70,13 @@ int main(int argc, char **argv)
             best = ms;
     }
     printf("single launch (best of 6): %.4f ms\n", best);
+    if (getenv("SDR_TOOL_SHORT"))
+        return 0;
 #if defined(SDR_FFT_CLOCK)
     {
         // 2 s of back-to-back launches, then the shader clock over one workgroup's lifetime
         for (int rep = 0; rep < 8000; rep++)
-            sdr::launch_fft(logn, iq, tw, sp, pd, frames, 1, frames, frames, 0);
+            sdr::launch_fft(logn, iq, tw, pd, frames, 1, frames, frames, tap, 0);
         hipDeviceSynchronize();
         unsigned long long ck[2];
         hipMemcpyFromSymbol(ck, HIP_SYMBOL(sdr::g_fft_clock), sizeof ck);
@@ -96,7 +86,7 @@ int main(int argc, char **argv)
         static unsigned long long wg[2048][4];
         memset(wg, 0, sizeof wg);
         hipMemcpyToSymbol(HIP_SYMBOL(sdr::g_fft_wg), wg, sizeof wg);
-        sdr::launch_fft(logn, iq, tw, sp, pd, frames, 1, frames, frames, 0);
+        sdr::launch_fft(logn, iq, tw, pd, frames, 1, frames, frames, tap, 0);
         hipDeviceSynchronize();
         hipMemcpyFromSymbol(wg, HIP_SYMBOL(sdr::g_fft_wg), sizeof wg);
         const int fpw = getenv("SDR_FFT_FPW") ? atoi(getenv("SDR_FFT_FPW")) : 1;
@@ -159,7 +149,7 @@ int main(int argc, char **argv)
         if (ns == 2)
             hipStreamWaitEvent(st[1], e0, 0);
         for (int rep = 0; rep < reps; rep++)
-            sdr::launch_fft(logn, iq, tw, sp, pd, frames, 1, frames, frames, st[rep % ns]);
+            sdr::launch_fft(logn, iq, tw, pd, frames, 1, frames, frames, tap, st[rep % ns]);
         hipEvent_t ej;
         hipEventCreate(&ej);
         if (ns == 2) {

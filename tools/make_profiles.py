@@ -43,7 +43,7 @@ for k in f:
     tab[k] = {"FETCH_SIZE_KB_raw": round(f[k], 1), "WRITE_SIZE_KB_raw": round(w.get(k, 0), 1),
               "hbm_read_bytes_corrected": int(f[k] * 1024 * 2), "hbm_write_bytes": int(w.get(k, 0) * 1024),
               "hbm_bytes_per_launch": int(f[k] * 1024 * 2 + w.get(k, 0) * 1024)}
-fft = [k for k in tab if k.startswith("k_fft_project")][0]
+fft = [k for k in tab if k.startswith("k_fft_psd")][0]
 tpath = os.path.join(P, "traffic.json")
 doc = json.load(open(tpath)) if os.path.exists(tpath) else {}
 doc["_how"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes (no trace domains) over "
@@ -51,7 +51,7 @@ doc["_how"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate 
                "correction per MI355X_MICROARCH.md §HBM: FETCH_SIZE reports 1/2 of the bytes of a coalesced streaming read "
                "-> read bytes = FETCH_SIZE*1024*2 (checked here on k_cumulate, which streams exactly the 134.2 MB spectrum "
                "once); WRITE_SIZE is exact.")
-doc[key] = {"k_fft_project_hbm_bytes_per_launch": tab[fft]["hbm_bytes_per_launch"],
+doc[key] = {"k_fft_psd_hbm_bytes_per_launch": tab[fft]["hbm_bytes_per_launch"],
             "algorithmic_bytes_per_launch": 8 * 2048 * 16384, "kernels": tab}
 json.dump(doc, open(tpath, "w"), indent=1)
 shutil.copy(os.path.join(G, "bench_full.log"), os.path.join(P, f"{tag}_bench_{key}.json"))

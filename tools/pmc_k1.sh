@@ -1,5 +1,5 @@
 #!/bin/bash
-# Development aid: SQ counters of k_fft_project over a short serial bench run, one rocprofv3 pass per
+# Development aid: SQ counters of k_fft_psd over a short serial bench run, one rocprofv3 pass per
 # counter group (no trace domains).  Output: gpurun_out/pmc_k1/<group>_counter_collection.csv
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -18,7 +18,7 @@ import csv, collections, glob
 for f in sorted(glob.glob("gpurun_out/pmc_k1/**/g*_counter_collection.csv", recursive=True)):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "k_fft_project" in r["Kernel_Name"]:
+        if "k_fft_psd" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         print(f"{k:28s} {sum(v)/len(v):16.0f}  (n={len(v)})")

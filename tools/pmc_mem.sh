@@ -1,5 +1,5 @@
 #!/bin/bash
-# Development aid: memory-side counters of k_fft_project (one rocprofv3 pass per group, no trace domains).
+# Development aid: memory-side counters of k_fft_psd (one rocprofv3 pass per group, no trace domains).
 # (A group of TA_* counters made rocprofv3 abort and the run hang on this pool: left out.)
 cd /tmp && export TMPDIR=/tmp
 cd ${GRAFT_REPO_ROOT:-/root/repo}
@@ -17,7 +17,7 @@ import csv, collections, glob
 for f in sorted(glob.glob("gpurun_out/pmc_mem/**/m*_counter_collection.csv", recursive=True)):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "k_fft_project" in r["Kernel_Name"]:
+        if "k_fft_psd" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         print(f"{k:40s} {sum(v)/len(v):16.0f}  (n={len(v)})")

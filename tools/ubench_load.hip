@@ -1,4 +1,4 @@
-// Development aid: how long does a 1024-thread workgroup (one per CU, as k_fft_project at N=16384) take
+// Development aid: how long does a 1024-thread workgroup (one per CU, as k_fft_psd at N=16384) take
 // to pull its 128 KB frame into registers, by load pattern?  Grid 2048, 129 KB LDS to force 1 WG/CU.
 #include <hip/hip_runtime.h>
 #include <cstdio>
