@@ -271,6 +271,11 @@ def main():
     # sanity: the timed path really decoded something (guards against measuring an empty pipeline)
     decoded = sum(len(bank.read_text(0, lid)) for lid in range(min(tones, 4)))
     chunks = bank.last_batch_chunks
+    # rehearsal / test hook: what THIS rank worked on (tests/test_bench_ranks.py)
+    if os.environ.get("SDR_BENCH_RANK_REPORT"):
+        with open(os.environ["SDR_BENCH_RANK_REPORT"], "w") as fh:
+            json.dump({"rank": rank, "bands": my_bands, "shared_config": sharding.describe(shared),
+                       "decoded_runes": decoded}, fh)
 
     result = {
         "metric": "IQ MSamples/s through FFT+peak+envelope",

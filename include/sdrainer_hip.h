@@ -27,6 +27,11 @@
  *   sdr_read_frame_records          locals of Receiver.run (noise floor, thresholds)  rx/receiver.go:381-385
  *   sdr_push_kiwi_snd               decodeIQMessage + kiwi.Process.IQData       kiwi/client.go:284-308, kiwi/kiwi.go:94-105
  *   sdr_audio_*                     cw.AudioDemodulator (Goertzel audio path)   cw/audio.go:37-211
+ *   sdr_enable_results / sdr_poll   the consumer side in bulk: what Receiver.run hands to its listeners'
+ *                                   io.Writer (rx/receiver.go:123, ChannelWriter :508-539) and to the
+ *                                   Reporter (rx/rx.go:11-17), one call per processed batch
+ *   sdr_scope_*                     scope.Scope.ShowSpectralFrame / ShowTimeFrame  scope/scope.go:14-37,
+ *                                   call sites rx/receiver.go:428-457, cw/spectral.go:56-81
  *
  * Semantics kept from the reference: setters take effect between frames, never mid-frame (here: at
  * the next process call, rx/receiver.go:166-172); wrong sample rate / block size / a full queue do
@@ -47,7 +52,7 @@
 extern "C" {
 #endif
 
-#define SDR_ABI_VERSION 1
+#define SDR_ABI_VERSION 2
 
 /* status codes */
 #define SDR_OK 0
@@ -58,6 +63,7 @@ extern "C" {
 #define SDR_ERR_HIP 5        /* a HIP runtime call failed; sdr_last_error() has the text          */
 #define SDR_ERR_NO_SLOT 6    /* listener pool exhausted (rx/listener.go:214-217)                  */
 #define SDR_ERR_STATE 7      /* call not valid in the current state                               */
+#define SDR_ERR_WOULD_BLOCK 8 /* sdr_poll: no finished batch is waiting to be delivered                */
 
 /* rx/receiver.go:15-27 */
 #define SDR_CUMULATION_SIZE 100
@@ -187,6 +193,58 @@ int sdr_read_trace(sdr_bank *bank, int band, int listener_id, float *values, uin
 int sdr_read_spectrum(sdr_bank *bank, int band, int frame, float *spectrum, float *psd);
 /* cw.Decoder state of a listener: ticks, onStart, offStart, wpm, on{low,high,last,thr}, off{...}. */
 int sdr_read_decoder_state(sdr_bank *bank, int band, int listener_id, double *out12);
+
+/* bulk delivery ----------------------------------------------------------------------------- */
+/* With results enabled every process call ends with two small kernels that copy what the batch produced - peaks
+ * of each completed cumulation, each listener's keying edges and newly decoded runes - into pinned host memory;
+ * sdr_poll hands the oldest finished batch to the caller WITHOUT draining the pipeline (it looks at two events)
+ * and never loses one: a batch whose buffers are about to be reused is parked on the host first.  Text is then
+ * delivered here only (sdr_read_text finds nothing left).  Decoded runes the device could not store and edges
+ * beyond a batch's edge buffer are counted, never silently lost: runes_dropped / edges_dropped (both stay 0
+ * while every batch is polled; the reference's io.Writer never drops). */
+typedef struct sdr_chunk_result {
+    int32_t band;
+    int32_t n_peaks;    /* peaks[first_peak .. first_peak + n_peaks) */
+    int64_t frame;      /* frame (counted from bank start) that completed this 100-frame cumulation */
+    int32_t first_peak;
+    int32_t peaks_found; /* runs FindPeaks found; > n_peaks only if max_peaks was too small */
+} sdr_chunk_result;
+
+typedef struct sdr_listener_result {
+    int32_t band, listener;
+    int32_t first_edge, n_edges; /* edges[first_edge ..): frame counted from bank start, state 1 = key down */
+    int32_t first_rune, n_runes; /* runes[first_rune ..): Unicode code points in decode order */
+} sdr_listener_result;
+
+typedef struct sdr_results {
+    int32_t struct_size;   /* = sizeof(sdr_results), ABI guard (in) */
+    int32_t n_frames;      /* frames per band in this batch (out) */
+    int64_t batch_index;   /* 0-based count of process calls (out) */
+    int64_t first_frame;   /* bank frame index of the batch's first frame (out) */
+    /* caller-owned buffers with their capacities in records (in); counts written (out).  If a buffer is too
+     * small the call returns SDR_ERR_BAD_SIZE with the n_* fields set to what is needed and delivers nothing. */
+    sdr_chunk_result *chunks;
+    int32_t chunks_cap, n_chunks;
+    sdr_peak *peaks;
+    int32_t peaks_cap, n_peaks;
+    sdr_listener_result *listeners; /* listeners with at least one edge or rune in this batch */
+    int32_t listeners_cap, n_listeners;
+    sdr_edge *edges;
+    int32_t edges_cap, n_edges;
+    uint32_t *runes;
+    int32_t runes_cap, n_runes;
+    uint64_t runes_dropped, edges_dropped; /* since bank creation (out) */
+} sdr_results;
+
+int sdr_enable_results(sdr_bank *bank, int on);
+/* Oldest finished, undelivered batch -> *r.  SDR_ERR_WOULD_BLOCK if there is none (yet); with wait != 0 the
+ * call blocks until the oldest undelivered batch has finished (WOULD_BLOCK only if nothing was processed). */
+int sdr_poll(sdr_bank *bank, sdr_results *r, int wait);
+/* Batches processed but not yet delivered. */
+int sdr_results_pending(sdr_bank *bank);
+/* Overflow counters without bulk delivery (synchronises): runes the decoders could not store because a text
+ * buffer was full, and keying edges beyond the edge buffer of the batches so far. */
+int sdr_read_drop_counters(sdr_bank *bank, uint64_t *runes_dropped, uint64_t *edges_dropped);
 
 /* measurement ------------------------------------------------------------------------------- */
 /* When enabled every kernel launch is bracketed by HIP events on the bank's stream. */

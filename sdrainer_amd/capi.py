@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SDR_HIP_LIB") or os.path.join(_HERE, "csrc", "libsdrainer_hip.so")  # env: diagnostic builds
 
-OK, ERR_BAD_ARG, ERR_BAD_RATE, ERR_BAD_SIZE, ERR_WOULD_DROP, ERR_HIP, ERR_NO_SLOT, ERR_STATE = range(8)
+OK, ERR_BAD_ARG, ERR_BAD_RATE, ERR_BAD_SIZE, ERR_WOULD_DROP, ERR_HIP, ERR_NO_SLOT, ERR_STATE, ERR_WOULD_BLOCK = range(9)
 CUMULATION_SIZE = 100
 KERNELS = ("k_fft_psd", "k_window_means", "k_noise_stats", "k_thresholds", "k_listen_gather", "k_cumulate",
            "k_find_peaks", "k_listen_decode")
@@ -50,6 +50,25 @@ FRAME_REC_DTYPE = np.dtype([("min_mean", "<f4"), ("dev_in", "<f4"), ("variance",
                             ("noise_dev", "<f4"), ("noise_floor", "<f4"), ("peak_thr", "<f4"), ("listen_thr", "<f4"),
                             ("pad", "<f4")])
 EDGE_DTYPE = np.dtype([("frame", "<u4"), ("state", "<u4")])
+PEAK_DTYPE = np.dtype([("from", "<i4"), ("to", "<i4"), ("from_frequency", "<i8"), ("to_frequency", "<i8"),
+                       ("signal_frequency", "<i8"), ("signal_value", "<f4"), ("signal_bin", "<i4")])
+CHUNK_RESULT_DTYPE = np.dtype([("band", "<i4"), ("n_peaks", "<i4"), ("frame", "<i8"), ("first_peak", "<i4"),
+                               ("peaks_found", "<i4")])
+LISTENER_RESULT_DTYPE = np.dtype([("band", "<i4"), ("listener", "<i4"), ("first_edge", "<i4"), ("n_edges", "<i4"),
+                                  ("first_rune", "<i4"), ("n_runes", "<i4")])
+
+
+class Results(C.Structure):
+    """sdr_results (include/sdrainer_hip.h)."""
+    _fields_ = [
+        ("struct_size", C.c_int32), ("n_frames", C.c_int32), ("batch_index", C.c_int64), ("first_frame", C.c_int64),
+        ("chunks", C.c_void_p), ("chunks_cap", C.c_int32), ("n_chunks", C.c_int32),
+        ("peaks", C.c_void_p), ("peaks_cap", C.c_int32), ("n_peaks", C.c_int32),
+        ("listeners", C.c_void_p), ("listeners_cap", C.c_int32), ("n_listeners", C.c_int32),
+        ("edges", C.c_void_p), ("edges_cap", C.c_int32), ("n_edges", C.c_int32),
+        ("runes", C.c_void_p), ("runes_cap", C.c_int32), ("n_runes", C.c_int32),
+        ("runes_dropped", C.c_uint64), ("edges_dropped", C.c_uint64),
+    ]
 
 _lib = None
 
@@ -60,7 +79,7 @@ SYMBOLS = (
     "sdr_set_peak_threshold sdr_set_edge_width sdr_set_signal_debounce sdr_set_center_frequency sdr_set_find_peaks "
     "sdr_last_batch_frames sdr_total_frames sdr_last_batch_chunks sdr_read_peaks sdr_read_cumulation sdr_read_text "
     "sdr_read_edges sdr_read_keying_bits sdr_read_frame_records sdr_read_trace sdr_read_spectrum "
-    "sdr_read_decoder_state sdr_profile_enable sdr_profile_read sdr_profile_reset sdr_kernel_name sdr_audio_create "
+    "sdr_read_decoder_state sdr_enable_results sdr_poll sdr_results_pending sdr_read_drop_counters sdr_profile_enable sdr_profile_read sdr_profile_reset sdr_kernel_name sdr_audio_create "
     "sdr_audio_destroy sdr_audio_blocksize sdr_audio_set_scale sdr_audio_set_debounce "
     "sdr_audio_set_magnitude_threshold sdr_audio_write sdr_audio_close sdr_audio_read_text sdr_audio_read_trace"
 ).split()
@@ -125,6 +144,10 @@ def load():
     sig("sdr_read_trace", C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int)
     sig("sdr_read_spectrum", C.c_int, vp, C.c_int, C.c_int, vp, vp)
     sig("sdr_read_decoder_state", C.c_int, vp, C.c_int, C.c_int, C.POINTER(C.c_double))
+    sig("sdr_enable_results", C.c_int, vp, C.c_int)
+    sig("sdr_poll", C.c_int, vp, C.POINTER(Results), C.c_int)
+    sig("sdr_results_pending", C.c_int, vp)
+    sig("sdr_read_drop_counters", C.c_int, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
     sig("sdr_profile_enable", C.c_int, vp, C.c_int)
     sig("sdr_profile_read", C.c_int, vp, C.c_int, C.POINTER(C.c_double), ip)
     sig("sdr_profile_reset", C.c_int, vp)
@@ -329,6 +352,63 @@ class Bank:
         out = np.empty(12)
         _check(self._L.sdr_read_decoder_state(self._h, band, lid, out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
+
+    # bulk delivery ----------------------------------------------------------------------------
+    def enable_results(self, on: bool = True):
+        _check(self._L.sdr_enable_results(self._h, int(on)))
+        if on and not hasattr(self, "_res"):
+            c = self.cfg
+            chunks = (c.max_batch_frames // CUMULATION_SIZE + 2) * c.n_bands
+            listeners = max(c.max_listeners * c.n_bands, 1)
+            self._res_bufs = {
+                "chunks": np.zeros(chunks, CHUNK_RESULT_DTYPE),
+                "peaks": np.zeros(chunks * c.max_peaks, PEAK_DTYPE),
+                "listeners": np.zeros(listeners, LISTENER_RESULT_DTYPE),
+                "edges": np.zeros(listeners * min(c.max_batch_frames, 8192), EDGE_DTYPE),
+                "runes": np.zeros(listeners * 2048, np.uint32),
+            }
+            r = Results()
+            r.struct_size = C.sizeof(Results)
+            for k, a in self._res_bufs.items():
+                setattr(r, k, a.ctypes.data)
+                setattr(r, k + "_cap", len(a))
+            self._res = r
+
+    def poll(self, wait: bool = False, copy: bool = True):
+        """Oldest finished batch as a dict of record arrays (views into reused buffers unless `copy`), or None."""
+        r = self._res
+        rc = self._L.sdr_poll(self._h, C.byref(r), int(wait))
+        if rc == ERR_WOULD_BLOCK:
+            return None
+        _check(rc)
+        out = {"batch_index": r.batch_index, "first_frame": r.first_frame, "n_frames": r.n_frames,
+               "runes_dropped": r.runes_dropped, "edges_dropped": r.edges_dropped}
+        for k, a in self._res_bufs.items():
+            v = a[:getattr(r, "n_" + k)]
+            out[k] = v.copy() if copy else v
+        return out
+
+    def poll_counts(self, wait: bool = False):
+        """Like poll() but returns only the record counts (the bench's timed loop: no Python-side copies)."""
+        r = self._res
+        rc = self._L.sdr_poll(self._h, C.byref(r), int(wait))
+        if rc == ERR_WOULD_BLOCK:
+            return None
+        _check(rc)
+        return (r.batch_index, r.n_chunks, r.n_peaks, r.n_listeners, r.n_edges, r.n_runes, r.runes_dropped, r.edges_dropped)
+
+    @property
+    def results_pending(self) -> int:
+        return self._L.sdr_results_pending(self._h)
+
+    def read_drop_counters(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        _check(self._L.sdr_read_drop_counters(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    @staticmethod
+    def runes_to_text(runes) -> str:
+        return "".join(chr(int(x)) for x in runes)
 
     # measurement ------------------------------------------------------------------------------
     def profile_enable(self, on: bool):

@@ -12,7 +12,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libsdrainer_hip.so")
-SOURCES = ["k_fft_psd.hip", "k_noise.hip", "k_listen.hip", "k_peaks.hip", "k_unpack.hip", "sdr_capi.hip", "sdr_audio.hip"]
+SOURCES = ["k_fft_psd.hip", "k_noise.hip", "k_listen.hip", "k_peaks.hip", "k_unpack.hip", "k_results.hip", "sdr_capi.hip", "sdr_audio.hip"]
 HEADERS = ["sdr_device.h", "fft_f64.h", "gomath.h", "cw_decoder.h", "twiddles.h", "host/frequency_mapping.h",
            "../../include/sdrainer_hip.h"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

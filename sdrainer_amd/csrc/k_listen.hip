@@ -83,7 +83,8 @@ __global__ __launch_bounds__(64) void k_listen_decode(ListenerSlot *__restrict__
                                                       uint64_t *__restrict__ deb_bits, uint32_t *__restrict__ text,
                                                       sdr_edge *__restrict__ edges,
                                                       uint32_t *__restrict__ edge_counts, uint8_t *__restrict__ tr_deb,
-                                                      ListenGeom g, int n_frames, int n_total)
+                                                      DropCounters *__restrict__ drops, ListenGeom g, int n_frames,
+                                                      int n_total)
 {
     // the 512-entry code table is hit on every decoded character, on the serial path: keep it in LDS
     __shared__ uint16_t s_morse[cw::kMorseTableSize];
@@ -146,12 +147,17 @@ __global__ __launch_bounds__(64) void k_listen_decode(ListenerSlot *__restrict__
     slot->deb = deb;
     slot->dec = dec;
     slot->text_count = sink.count;
+    // nothing is lost silently: what did not fit is counted bank-wide (rare; the host reads or polls the totals)
+    if (sink.dropped != slot->text_dropped)
+        atomicAdd(&drops->runes, (unsigned long long)(sink.dropped - slot->text_dropped));
+    if (n_edges > (uint32_t)g.edge_cap)
+        atomicAdd(&drops->edges, (unsigned long long)(n_edges - (uint32_t)g.edge_cap));
     slot->text_dropped = sink.dropped;
     edge_counts[idx] = n_edges;
 }
 
 // cw.Decoder.stop for one listener (cw/decode.go:352-354)
-__global__ void k_listener_stop(ListenerSlot *slot, const uint16_t *morse, uint32_t *text, int text_cap)
+__global__ void k_listener_stop(ListenerSlot *slot, const uint16_t *morse, uint32_t *text, int text_cap, DropCounters *drops)
 {
     if (threadIdx.x != 0 || !slot->active)
         return;
@@ -160,6 +166,8 @@ __global__ void k_listener_stop(ListenerSlot *slot, const uint16_t *morse, uint3
     cw::decoder_stop(dec, morse, sink);
     slot->dec = dec;
     slot->text_count = sink.count;
+    if (sink.dropped != slot->text_dropped)
+        atomicAdd(&drops->runes, (unsigned long long)(sink.dropped - slot->text_dropped));
     slot->text_dropped = sink.dropped;
 }
 
@@ -183,18 +191,19 @@ hipError_t launch_listen_gather(const float *tap, const sdr_frame_rec *recs, con
 
 hipError_t launch_listen_decode(ListenerSlot *slots, const uint16_t *morse, const uint64_t *raw_bits,
                                 uint64_t *deb_bits, uint32_t *text, sdr_edge *edges, uint32_t *edge_counts,
-                                uint8_t *tr_deb, ListenGeom g, int n_frames, int n_bands, hipStream_t stream)
+                                uint8_t *tr_deb, DropCounters *drops, ListenGeom g, int n_frames, int n_bands,
+                                hipStream_t stream)
 {
     const int n_total = n_bands * g.max_listeners;
     hipLaunchKernelGGL(k_listen_decode, dim3((n_total + DECODE_LANES - 1) / DECODE_LANES), dim3(64), 0, stream, slots, morse, raw_bits,
-                       deb_bits, text, edges, edge_counts, tr_deb, g, n_frames, n_total);
+                       deb_bits, text, edges, edge_counts, tr_deb, drops, g, n_frames, n_total);
     return hipGetLastError();
 }
 
-hipError_t launch_listener_stop(ListenerSlot *slot, const uint16_t *morse, uint32_t *text, int text_cap,
+hipError_t launch_listener_stop(ListenerSlot *slot, const uint16_t *morse, uint32_t *text, int text_cap, DropCounters *drops,
                                 hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_listener_stop, dim3(1), dim3(64), 0, stream, slot, morse, text, text_cap);
+    hipLaunchKernelGGL(k_listener_stop, dim3(1), dim3(64), 0, stream, slot, morse, text, text_cap, drops);
     return hipGetLastError();
 }
 

@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -101,8 +102,20 @@ struct BatchSet {
     DevBuf<sdr::DevPeak> dev_peaks;   // [band][max_chunks][max_peaks]
     DevBuf<int> peak_counts;          // [band][max_chunks]
     hipEvent_t done[sdr::K_COUNT] = {};  // recorded behind each kernel of the batch that used this set
+    // bulk delivery (k_results.hip): this set's block of pinned host memory and what the host knows about the batch in it
+    unsigned char *res_host = nullptr;
+    hipEvent_t res_listen = nullptr, res_peaks = nullptr;
+    int64_t res_batch = -1;  // batch whose results sit in res_host, not delivered yet (-1: none)
+    int64_t res_first_frame = 0;
+    int res_frames = 0, res_chunks = 0, res_count0 = 0, res_slots = 0;
     void release()
     {
+        if (res_host)
+            (void)hipHostFree(res_host);
+        if (res_listen)
+            (void)hipEventDestroy(res_listen);
+        if (res_peaks)
+            (void)hipEventDestroy(res_peaks);
         psd.release();
         tap.release();
         win_mean.release();
@@ -165,6 +178,17 @@ struct sdr_bank {
     int edge_width = 0;
     int find_peaks = 1;
     bool failed = false;  // a HIP call failed in the middle of a launch sequence: device state is unknown
+    DevBuf<sdr::DropCounters> drops;
+    // bulk delivery
+    bool results_on = false;
+    sdr::ResultsLayout res_layout{};
+    int64_t deliver_next = 0;  // batch index sdr_poll hands out next
+    struct Parked {            // a finished batch moved off its ring set before delivery
+        int64_t batch, first_frame;
+        int frames, chunks, count0, slots;
+        std::vector<unsigned char> block;
+    };
+    std::deque<Parked> parked;
 
     float *h_stage = nullptr;  // pinned [band][max_batch][2N]
     std::vector<int> staged;
@@ -289,6 +313,56 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     return rc;
 }
 
+// ---- bulk delivery -------------------------------------------------------------------------------------------
+sdr::ResultsLayout make_results_layout(const sdr_bank *b)
+{
+    const sdr_config &c = b->cfg;
+    sdr::ResultsLayout l{};
+    l.max_listeners = c.max_listeners;
+    l.max_chunks = b->max_chunks;
+    l.max_peaks = c.max_peaks;
+    l.edge_cap = b->edge_cap;
+    l.text_cap = b->text_cap;
+    const size_t B = (size_t)c.n_bands, L = (size_t)c.max_listeners, C = (size_t)b->max_chunks;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off += (bytes + 63) & ~(size_t)63;
+        return at;
+    };
+    l.off_drops = take(sizeof(sdr::DropCounters));
+    l.off_peak_counts = take(B * C * 2 * sizeof(int));
+    l.off_peaks = take(B * C * (size_t)c.max_peaks * sizeof(sdr::DevPeak));
+    l.off_edge_counts = take(B * L * sizeof(uint32_t));
+    l.off_edges = take(B * L * (size_t)b->edge_cap * sizeof(sdr_edge));
+    l.off_text_counts = take(B * L * sizeof(uint32_t));
+    l.off_text = take(B * L * (size_t)b->text_cap * sizeof(uint32_t));
+    l.bytes = off;
+    return l;
+}
+
+// The set is about to be reused while its results were never polled: wait for them and keep a compact copy on
+// the host (the reference's io.Writer never drops).  Only the used parts of the block are copied.
+int park_results(sdr_bank *b, BatchSet &S)
+{
+    if (S.res_batch < 0)
+        return SDR_OK;
+    HIP_TRY(hipEventSynchronize(S.res_listen));
+    HIP_TRY(hipEventSynchronize(S.res_peaks));
+    sdr_bank::Parked p;
+    p.batch = S.res_batch;
+    p.first_frame = S.res_first_frame;
+    p.frames = S.res_frames;
+    p.chunks = S.res_chunks;
+    p.count0 = S.res_count0;
+    p.slots = S.res_slots;
+    // (a full copy keeps one decoding routine; batches are parked only when the caller polls too rarely)
+    p.block.assign(S.res_host, S.res_host + b->res_layout.bytes);
+    b->parked.push_back(std::move(p));
+    S.res_batch = -1;
+    return SDR_OK;
+}
+
 // Which of the bank's four streams each kernel runs on (index = sdr::KernelId).  The step is as long as the
 // longest stream, and kernels that carry state from batch to batch (thresholds, decode, cumulate) must keep their
 // stream so that the stream orders the batches.  SDR_DIAG builds read an override from SDR_DIAG_PLAN (eight
@@ -351,6 +425,11 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     int max_slots = 0;
     for (int i = 0; i < B; i++)
         max_slots = std::max(max_slots, b->n_slots[i]);
+    if (b->results_on) {
+        const int prc = park_results(b, S);
+        if (prc)
+            return prc;
+    }
     {
         ProfScope ps(b, sdr::K_FFT, stream_of(sdr::K_FFT));
         const sdr::FftTap tap{b->tap_bins.p, S.tap.p, max_slots, c.max_listeners};
@@ -405,8 +484,15 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     if (max_slots > 0) {
         ProfScope ps(b, sdr::K_LISTEN_DECODE, stream_of(sdr::K_LISTEN_DECODE));
         SDR_LAUNCH(sdr::K_LISTEN_DECODE, sdr::launch_listen_decode(b->slots.p, b->morse.p, S.raw_bits.p, S.bits.p, b->text.p,
-                                                                   S.edges.p, S.edge_counts.p, S.tr_deb.p, lg, n_frames, B,
-                                                                   stream_of(sdr::K_LISTEN_DECODE)));
+                                                                   S.edges.p, S.edge_counts.p, S.tr_deb.p, b->drops.p, lg, n_frames,
+                                                                   B, stream_of(sdr::K_LISTEN_DECODE)));
+    }
+    if (b->results_on) {
+        // delivery of this batch's edges and runes, behind the decoder on its stream; the decoder's event is
+        // recorded behind it so that the set is not reused before the copy to the host has happened
+        HIP_TRY(sdr::launch_pack_listen(b->slots.p, S.edges.p, S.edge_counts.p, b->text.p, b->drops.p, b->res_layout, max_slots, B,
+                                        S.res_host, stream_of(sdr::K_LISTEN_DECODE)));
+        HIP_TRY(hipEventRecord(S.res_listen, stream_of(sdr::K_LISTEN_DECODE)));
     }
     SDR_DONE(sdr::K_LISTEN_DECODE);
 
@@ -436,6 +522,17 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         sdr::PeakGeom pg{N, stride, count0, b->max_chunks, c.max_peaks};
         SDR_LAUNCH(sdr::K_FIND_PEAKS, sdr::launch_find_peaks(S.cum_out.p, S.recs.p, S.dev_peaks.p, S.peak_counts.p, pg, n_chunks, B,
                                                              stream_of(sdr::K_FIND_PEAKS)));
+    }
+    if (b->results_on) {
+        HIP_TRY(sdr::launch_pack_peaks(S.dev_peaks.p, S.peak_counts.p, b->res_layout, b->find_peaks, n_chunks, B, S.res_host,
+                                       stream_of(sdr::K_FIND_PEAKS)));
+        HIP_TRY(hipEventRecord(S.res_peaks, stream_of(sdr::K_FIND_PEAKS)));
+        S.res_batch = b->batch_index;
+        S.res_first_frame = b->total_frames;
+        S.res_frames = n_frames;
+        S.res_chunks = n_chunks;
+        S.res_count0 = count0;
+        S.res_slots = max_slots;
     }
     SDR_DONE(sdr::K_FIND_PEAKS);
 #undef SDR_AFTER
@@ -563,6 +660,7 @@ int sdr_create(const sdr_config *cfg, sdr_bank **out)
         }
     }
     ALLOC(b->band_state, B);
+    ALLOC(b->drops, 1);
     ALLOC(b->spectrum_row, (size_t)N);
     ALLOC(b->tap_bins, B * std::max<size_t>(L, 1));
     {
@@ -610,6 +708,7 @@ int sdr_destroy(sdr_bank *b)
         (void)hipStreamSynchronize(b->stream[s]);
     resolve_profile(b);
     b->tw.release();
+    b->drops.release();
     b->db_tab.release();
     b->tap_bins.release();
     b->spectrum_row.release();
@@ -874,7 +973,7 @@ int sdr_listener_stop(sdr_bank *b, int band, int lid)
         return rc;
     const size_t idx = (size_t)band * b->cfg.max_listeners + lid;
     HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(sdr::launch_listener_stop(b->slots.p + idx, b->morse.p, b->text.p + idx * b->text_cap, b->text_cap,
+    HIP_TRY(sdr::launch_listener_stop(b->slots.p + idx, b->morse.p, b->text.p + idx * b->text_cap, b->text_cap, b->drops.p,
                                       b->stream[S_LISTEN]));
     return SDR_OK;
 }
@@ -1162,6 +1261,200 @@ int sdr_read_decoder_state(sdr_bank *b, int band, int lid, double *out12)
     out12[9] = d.offThreshold.high;
     out12[10] = d.offThreshold.last;
     out12[11] = d.offThreshold.threshold;
+    return SDR_OK;
+}
+
+// ---- bulk delivery -------------------------------------------------------------------------------------------
+int sdr_enable_results(sdr_bank *b, int on)
+{
+    if (!b)
+        return fail(SDR_ERR_BAD_ARG, "null bank");
+    int rc = sync_bank(b);
+    if (rc)
+        return rc;
+    if (on && !b->set[0].res_host) {
+        HIP_TRY(hipSetDevice(b->device));
+        b->res_layout = make_results_layout(b);
+        for (auto &S : b->set) {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&S.res_host), b->res_layout.bytes, hipHostMallocDefault));
+            memset(S.res_host, 0, b->res_layout.bytes);
+            HIP_TRY(hipEventCreateWithFlags(&S.res_listen, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&S.res_peaks, hipEventDisableTiming));
+        }
+    }
+    if (!on) {
+        // undelivered batches are discarded with the mode
+        for (auto &S : b->set)
+            S.res_batch = -1;
+        b->parked.clear();
+    }
+    b->results_on = on != 0;
+    b->deliver_next = b->batch_index;
+    return SDR_OK;
+}
+
+int sdr_results_pending(sdr_bank *b)
+{
+    if (!b || !b->results_on)
+        return 0;
+    return (int)(b->batch_index - b->deliver_next);
+}
+
+namespace {
+struct BatchMeta {
+    int64_t batch, first_frame;
+    int frames, chunks, count0, slots;
+};
+
+// block (pinned set or parked copy) -> the caller's buffers
+static int deliver_block(sdr_bank *b, const unsigned char *blk, const BatchMeta &m, sdr_results *r)
+{
+    const sdr_config &c = b->cfg;
+    const sdr::ResultsLayout &lay = b->res_layout;
+    const int B = c.n_bands, L = c.max_listeners;
+    const int *peak_counts = reinterpret_cast<const int *>(blk + lay.off_peak_counts);
+    const sdr::DevPeak *peaks = reinterpret_cast<const sdr::DevPeak *>(blk + lay.off_peaks);
+    const uint32_t *edge_counts = reinterpret_cast<const uint32_t *>(blk + lay.off_edge_counts);
+    const sdr_edge *edges = reinterpret_cast<const sdr_edge *>(blk + lay.off_edges);
+    const uint32_t *text_counts = reinterpret_cast<const uint32_t *>(blk + lay.off_text_counts);
+    const uint32_t *text = reinterpret_cast<const uint32_t *>(blk + lay.off_text);
+    // what is needed
+    int64_t need_peaks = 0, need_edges = 0, need_runes = 0;
+    int need_listeners = 0;
+    for (int band = 0; band < B; band++) {
+        for (int ch = 0; ch < m.chunks; ch++)
+            need_peaks += peak_counts[2 * ((size_t)band * lay.max_chunks + ch)];
+        for (int l = 0; l < m.slots; l++) {
+            const size_t idx = (size_t)band * L + l;
+            need_edges += edge_counts[idx];
+            need_runes += text_counts[idx];
+            need_listeners += (edge_counts[idx] || text_counts[idx]) ? 1 : 0;
+        }
+    }
+    const int need_chunks = m.chunks * B;
+    const bool fits = need_chunks <= r->chunks_cap && need_peaks <= r->peaks_cap && need_listeners <= r->listeners_cap &&
+                      need_edges <= r->edges_cap && need_runes <= r->runes_cap &&
+                      (need_chunks == 0 || r->chunks) && (need_peaks == 0 || r->peaks) &&
+                      (need_listeners == 0 || r->listeners) && (need_edges == 0 || r->edges) && (need_runes == 0 || r->runes);
+    r->n_chunks = need_chunks;
+    r->n_peaks = (int32_t)need_peaks;
+    r->n_listeners = need_listeners;
+    r->n_edges = (int32_t)need_edges;
+    r->n_runes = (int32_t)need_runes;
+    r->n_frames = m.frames;
+    r->batch_index = m.batch;
+    r->first_frame = m.first_frame;
+    const sdr::DropCounters *dc = reinterpret_cast<const sdr::DropCounters *>(blk + lay.off_drops);
+    r->runes_dropped = dc->runes;
+    r->edges_dropped = dc->edges;
+    if (!fits)
+        return fail(SDR_ERR_BAD_SIZE, "sdr_poll: a result buffer is too small (the n_* fields say what is needed)");
+    int ci = 0, pi = 0, li = 0, ei = 0, ri = 0;
+    for (int band = 0; band < B; band++) {
+        host::FrequencyMapping fm(c.sample_rate, c.block_size, b->center_frequency[band]);
+        for (int ch = 0; ch < m.chunks; ch++) {
+            const size_t cidx = (size_t)band * lay.max_chunks + ch;
+            const int n = peak_counts[2 * cidx];
+            sdr_chunk_result &cr = r->chunks[ci++];
+            cr.band = band;
+            cr.n_peaks = n;
+            cr.frame = m.first_frame + (SDR_CUMULATION_SIZE - m.count0) + (int64_t)ch * SDR_CUMULATION_SIZE - 1;
+            cr.first_peak = pi;
+            cr.peaks_found = peak_counts[2 * cidx + 1];
+            for (int i = 0; i < n; i++) {
+                const sdr::DevPeak &p = peaks[cidx * lay.max_peaks + i];
+                sdr_peak &o = r->peaks[pi++];
+                o.from = p.from;
+                o.to = p.to;
+                o.signal_bin = p.signal_bin;
+                o.signal_value = p.signal_value;
+                o.from_frequency = fm.BinToFrequency(p.from, host::BinFrom);
+                o.to_frequency = fm.BinToFrequency(p.to, host::BinTo);
+                o.signal_frequency = fm.BinToFrequency(p.signal_bin, host::PeakCenterCorrection(p.signal_bin, c.block_size, p.y1, p.y2, p.y3));
+            }
+        }
+    }
+    for (int band = 0; band < B; band++)
+        for (int l = 0; l < m.slots; l++) {
+            const size_t idx = (size_t)band * L + l;
+            const int ne = (int)edge_counts[idx], nr = (int)text_counts[idx];
+            if (!ne && !nr)
+                continue;
+            sdr_listener_result &lr = r->listeners[li++];
+            lr.band = band;
+            lr.listener = l;
+            lr.first_edge = ei;
+            lr.n_edges = ne;
+            lr.first_rune = ri;
+            lr.n_runes = nr;
+            if (ne)
+                memcpy(r->edges + ei, edges + idx * lay.edge_cap, sizeof(sdr_edge) * (size_t)ne);
+            if (nr)
+                memcpy(r->runes + ri, text + idx * lay.text_cap, sizeof(uint32_t) * (size_t)nr);
+            ei += ne;
+            ri += nr;
+        }
+    return SDR_OK;
+}
+}  // namespace
+
+int sdr_poll(sdr_bank *b, sdr_results *r, int wait)
+{
+    if (!b || !r)
+        return fail(SDR_ERR_BAD_ARG, "null argument");
+    if (r->struct_size != (int32_t)sizeof(sdr_results))
+        return fail(SDR_ERR_BAD_ARG, "sdr_results.struct_size mismatch (ABI)");
+    if (!b->results_on)
+        return fail(SDR_ERR_STATE, "bulk delivery is off (sdr_enable_results)");
+    if (b->deliver_next >= b->batch_index)
+        return fail(SDR_ERR_WOULD_BLOCK, "no batch waiting");
+    // oldest first: parked batches are older than anything still in the ring
+    if (!b->parked.empty() && b->parked.front().batch == b->deliver_next) {
+        const sdr_bank::Parked &p = b->parked.front();
+        const BatchMeta m{p.batch, p.first_frame, p.frames, p.chunks, p.count0, p.slots};
+        const int rc = deliver_block(b, p.block.data(), m, r);
+        if (rc == SDR_OK) {
+            b->parked.pop_front();
+            b->deliver_next++;
+        }
+        return rc;
+    }
+    BatchSet &S = b->set[b->deliver_next % RING];
+    if (S.res_batch != b->deliver_next)
+        return fail(SDR_ERR_STATE, "results of the next batch are not where they should be");
+    HIP_TRY(hipSetDevice(b->device));
+    for (hipEvent_t e : {S.res_listen, S.res_peaks}) {
+        if (wait) {
+            HIP_TRY(hipEventSynchronize(e));
+        } else {
+            const hipError_t q = hipEventQuery(e);
+            if (q == hipErrorNotReady)
+                return fail(SDR_ERR_WOULD_BLOCK, "the oldest undelivered batch has not finished");
+            HIP_TRY(q);
+        }
+    }
+    const BatchMeta m{S.res_batch, S.res_first_frame, S.res_frames, S.res_chunks, S.res_count0, S.res_slots};
+    const int rc = deliver_block(b, S.res_host, m, r);
+    if (rc == SDR_OK) {
+        S.res_batch = -1;
+        b->deliver_next++;
+    }
+    return rc;
+}
+
+int sdr_read_drop_counters(sdr_bank *b, uint64_t *runes_dropped, uint64_t *edges_dropped)
+{
+    if (!b)
+        return fail(SDR_ERR_BAD_ARG, "null bank");
+    int rc = sync_bank(b);
+    if (rc)
+        return rc;
+    sdr::DropCounters dc{};
+    HIP_TRY(hipMemcpy(&dc, b->drops.p, sizeof dc, hipMemcpyDeviceToHost));
+    if (runes_dropped)
+        *runes_dropped = dc.runes;
+    if (edges_dropped)
+        *edges_dropped = dc.edges;
     return SDR_OK;
 }
 

@@ -26,9 +26,15 @@ struct ListenerSlot {
     cw::Debouncer deb;
     cw::DecoderState dec;
     uint32_t text_count;    // runes in the text buffer not yet read by the host
-    uint32_t text_dropped;  // runes dropped because the buffer was full
-    uint32_t edge_count;    // edges produced by the last batch
-    int32_t last_debounced;
+    uint32_t text_dropped;  // runes dropped because the buffer was full (since attach)
+    uint32_t reserved0;
+    int32_t reserved1;
+};
+
+// Bank-wide overflow counters (device memory): what the reference's never-dropping io.Writer would have kept.
+struct DropCounters {
+    unsigned long long runes;  // decoded runes that found the listener's text buffer full
+    unsigned long long edges;  // keying edges beyond a batch's per-listener edge buffer
 };
 
 // What k_find_peaks hands to the host, which finishes dsp.Peak (frequencies are float64 -> int).
@@ -59,6 +65,16 @@ struct PeakGeom {
     int n, stride, count0, max_chunks, max_peaks;
 };
 
+// Layout of one batch's block of pinned host memory (k_results.hip): byte offsets of its arrays
+//   peak_counts [band][max_chunks][2] int32 (stored, found)   peaks [band][max_chunks][max_peaks] DevPeak
+//   edge_counts [band][L] uint32                              edges [band][L][edge_cap] sdr_edge
+//   text_counts [band][L] uint32                              text  [band][L][text_cap] uint32 runes
+//   drops       DropCounters of the bank as of this batch
+struct ResultsLayout {
+    int max_listeners, max_chunks, max_peaks, edge_cap, text_cap;
+    size_t off_peak_counts, off_peaks, off_edge_counts, off_edges, off_text_counts, off_text, off_drops, bytes;
+};
+
 enum KernelId {
     K_FFT = 0, K_WINDOW_MEANS, K_NOISE_STATS, K_THRESHOLDS, K_LISTEN_GATHER, K_CUMULATE, K_FIND_PEAKS, K_LISTEN_DECODE,
     K_COUNT
@@ -87,13 +103,19 @@ hipError_t launch_listen_gather(const float *tap, const sdr_frame_rec *recs, con
                                 hipStream_t stream);
 hipError_t launch_listen_decode(ListenerSlot *slots, const uint16_t *morse, const uint64_t *raw_bits,
                                 uint64_t *deb_bits, uint32_t *text, sdr_edge *edges, uint32_t *edge_counts,
-                                uint8_t *tr_deb, ListenGeom g, int n_frames, int n_bands, hipStream_t stream);
-hipError_t launch_listener_stop(ListenerSlot *slot, const uint16_t *morse, uint32_t *text, int text_cap,
+                                uint8_t *tr_deb, DropCounters *drops, ListenGeom g, int n_frames, int n_bands,
+                                hipStream_t stream);
+hipError_t launch_listener_stop(ListenerSlot *slot, const uint16_t *morse, uint32_t *text, int text_cap, DropCounters *drops,
                                 hipStream_t stream);
 hipError_t launch_set_debounce(ListenerSlot *slots, int n, int threshold, hipStream_t stream);
 hipError_t launch_cumulate(const float *psd, const void *db_tab, const float *carry_in, float *carry_out, float *cum_out,
                            CumGeom g, int n_slots, int n_bands, hipStream_t stream);
 hipError_t launch_spectrum_row(const float *psd_row, float *out, int n, hipStream_t stream);
+hipError_t launch_pack_listen(ListenerSlot *slots, const sdr_edge *edges, const uint32_t *edge_counts, const uint32_t *text,
+                              const DropCounters *drops, ResultsLayout lay, int n_slots, int n_bands, unsigned char *host,
+                              hipStream_t stream);
+hipError_t launch_pack_peaks(const DevPeak *peaks, const int *counts, ResultsLayout lay, int find_peaks, int n_chunks,
+                             int n_bands, unsigned char *host, hipStream_t stream);
 hipError_t launch_unpack_be16(const uint8_t *raw, float *out, size_t n_values, hipStream_t stream);
 hipError_t launch_find_peaks(const float *cum, const sdr_frame_rec *recs, DevPeak *peaks, int *counts, PeakGeom g,
                              int n_chunks, int n_bands, hipStream_t stream);

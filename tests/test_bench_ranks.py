@@ -1,0 +1,48 @@
+"""bench.py's N > 1 branch, rehearsed on ONE GPU: two fresh child processes (ranks 0 and 1 of a
+world of 2) share the card, the collectives run over gloo on the CPU (a one-GPU box cannot host two
+RCCL ranks).  Checks what the multi-GPU contract needs: one JSON line from rank 0 with n_gpus 2, whole-job
+throughput over both ranks, each rank working on its own band, the broadcast configuration equal on both."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_rank_bench_on_one_gpu(tmp_path):
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), SDR_DIST_BACKEND="gloo", SDR_FORCE_DEVICE="0",
+                   SDR_BENCH_RANK_REPORT=str(tmp_path / f"rank{rank}.json"))
+        # children are started before this process touches the GPU (it never does)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5",
+                                       "--warmup", "2", "--frames", "256", "--settle-ms", "0", "--no-cpu-baseline"],
+                                      env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for rank, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {rank} failed:\n{se[-2000:]}"
+    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, outs[0][0]
+    assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")], "only rank 0 prints the line"
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["steps"] == 5
+    per_rank = res["config"]["samples_per_step_per_gpu"]
+    assert res["value"] == pytest.approx(2 * per_rank * 5 / (res["ms_per_step"] * 5 * 1e-3) / 1e6, rel=1e-3)
+    reports = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    assert reports[0]["bands"] != reports[1]["bands"] and sorted(reports[0]["bands"] + reports[1]["bands"]) == [0, 1]
+    assert reports[0]["shared_config"] == reports[1]["shared_config"]
+    assert all(r["decoded_runes"] > 0 for r in reports)

@@ -41,10 +41,13 @@ def test_library_exports_every_declared_symbol(lib_path):
 def test_library_loads_and_reports_abi(lib_path):
     from sdrainer_amd import capi
     L = capi.load()
-    assert L.sdr_abi_version() == 1
+    assert L.sdr_abi_version() == 2
     assert [L.sdr_kernel_name(i).decode() for i in range(8)] == list(capi.KERNELS)
     assert ctypes.sizeof(capi.Config) == 56 and ctypes.sizeof(capi.Peak) == 40
     assert capi.FRAME_REC_DTYPE.itemsize == 40 and capi.EDGE_DTYPE.itemsize == 8
+    # bulk delivery records (sdr_results and what it points to)
+    assert ctypes.sizeof(capi.Results) == 120 and capi.PEAK_DTYPE.itemsize == 40
+    assert capi.CHUNK_RESULT_DTYPE.itemsize == 24 and capi.LISTENER_RESULT_DTYPE.itemsize == 24
 
 
 def test_code_object_is_gfx950_only(lib_path):

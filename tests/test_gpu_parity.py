@@ -476,3 +476,165 @@ def test_kiwi_snd_payload_unpacked_on_device(capi):
     # afterwards the band accepts float frames again
     assert bank.push_iq(0, rate, np.zeros(2 * n, np.float32) + 1e-3) == capi.OK
     bank.close()
+
+
+def test_config5_geometry(capi):
+    """BASELINE config 5's per-GPU share: one bank of 8 channels x 8192-point FFT x 16 listeners each.  Every
+    channel is an independent receiver (rx/receiver.go:64-91) and is checked against its own oracle receiver:
+    frame records, keying bits, edges, text, cumulation and peaks, over two batches (state carried across)."""
+    import torch
+
+    n, rate, tones, B, frames = 8192, 2000000, 16, 8, 136
+    edge = synth.default_edge_width(n)
+    bands = [synth.make_band(frames, rate, n, tones, seed=5000 + 17 * b) for b in range(B)]
+    bank = capi.Bank(rate, n, n_bands=B, edge_width=edge, max_batch_frames=96, max_listeners=tones, max_peaks=256)
+    bank.set_stream(torch.cuda.current_stream().cuda_stream)
+    refs = []
+    for b, (iq, bins, _) in enumerate(bands):
+        r = orc.Receiver(rate, n, edge, 15.0, 1, center_frequency=14000000 + 100000 * b)
+        bank.set_center_frequency(b, 14000000 + 100000 * b)
+        for bn in bins:
+            assert bank.attach(b, int(bn)) == r.attach(int(bn))
+        refs.append(r)
+    outs = [refs[b].process(bands[b][0]) for b in range(B)]
+    text = [["" for _ in range(tones)] for _ in range(B)]
+    n_peaks = 0
+    for a, e in ((0, 96), (96, frames)):
+        dev = torch.from_numpy(np.stack([iq[a:e] for iq, _, _ in bands])).cuda()  # [band][frame][2N]
+        bank.process_device(dev.data_ptr(), e - a)
+        bank.sync()
+        for b in range(B):
+            out = outs[b]
+            recs = bank.read_frame_records(b)
+            for f in REC_FIELDS:
+                assert _bits_equal(recs[f], out["frames"][f][a:e].copy()), f"band {b} frames {a}:{e} field {f}"
+            for lid in range(tones):
+                assert np.array_equal(bank.read_keying_bits(b, lid), out["deb"][a:e, lid]), f"band {b} listener {lid}"
+                deb = out["deb"][:, lid].astype(np.int8)
+                trans = np.flatnonzero(np.diff(np.concatenate([[0], deb])) != 0)
+                trans = trans[(trans >= a) & (trans < e)]
+                ed = bank.read_edges(b, lid)
+                assert np.array_equal(ed["frame"], trans) and np.array_equal(ed["state"], deb[trans])
+                text[b][lid] += bank.read_text(b, lid)
+            for c in range(bank.last_batch_chunks):
+                peaks, count, fr = bank.read_peaks(b, c)
+                gc = list(out["peak_frames"]).index(a + fr)
+                assert _bits_equal(bank.read_cumulation(b, c), out["cumulation"][gc])
+                assert peaks == out["peaks"][gc] and count == len(peaks)
+                n_peaks += len(peaks)
+    for b in range(B):
+        for lid in range(tones):
+            assert text[b][lid] == refs[b].text(lid), f"band {b} listener {lid}"
+            assert np.array_equal(bank.read_decoder_state(b, lid), refs[b].decoder_state(lid))
+    assert n_peaks >= B * tones // 2
+    bank.close()
+
+
+def _check_delivery(res, out, a, e, tones, text, ref_frames_base=0):
+    """One polled batch covering frames [a, e) against the oracle's whole-run output."""
+    assert res["first_frame"] == a and res["n_frames"] == e - a
+    by_listener = {int(r["listener"]): r for r in res["listeners"] if r["band"] == 0}
+    for lid in range(tones):
+        deb = out["deb"][:, lid].astype(np.int8)
+        trans = np.flatnonzero(np.diff(np.concatenate([[0], deb])) != 0)
+        trans = trans[(trans >= a) & (trans < e)]
+        r = by_listener.get(lid)
+        if r is None:
+            assert len(trans) == 0
+            continue
+        ed = res["edges"][r["first_edge"]:r["first_edge"] + r["n_edges"]]
+        assert np.array_equal(ed["frame"], trans) and np.array_equal(ed["state"], deb[trans])
+        text[lid] += "".join(chr(int(x)) for x in res["runes"][r["first_rune"]:r["first_rune"] + r["n_runes"]])
+    for ch in res["chunks"]:
+        gc = list(out["peak_frames"]).index(int(ch["frame"]))
+        got = [tuple(int(p[k]) if k != "signal_value" else float(p[k]) for k in
+                     ("from", "to", "from_frequency", "to_frequency", "signal_frequency", "signal_value", "signal_bin"))
+               for p in res["peaks"][ch["first_peak"]:ch["first_peak"] + ch["n_peaks"]]]
+        assert got == out["peaks"][gc] and ch["peaks_found"] == len(got)
+
+
+def test_bulk_delivery_poll(capi):
+    """sdr_enable_results / sdr_poll: every batch's peaks, edges and runes arrive once, in order, identical to the
+    oracle - polled promptly, polled late (more batches in flight than ring sets: the parked path) and with
+    buffers that are too small first (nothing is consumed then)."""
+    import ctypes as C
+
+    n, rate, tones, frames = 1024, 96000, 6, 1500
+    iq, bins, _ = synth.make_band(frames, rate, n, tones, seed=77)
+    edge = synth.default_edge_width(n)
+    ref = orc.Receiver(rate, n, edge, 15.0, 1, center_frequency=3500000)
+    bank = capi.Bank(rate, n, edge_width=edge, max_batch_frames=128, max_listeners=tones + 1, max_peaks=128)
+    bank.set_center_frequency(0, 3500000)
+    for b in bins:
+        assert bank.attach(0, int(b)) == ref.attach(int(b))
+    out = ref.process(iq)
+    bank.enable_results(True)
+    assert bank.poll() is None and bank.results_pending == 0
+    text = ["" for _ in range(tones)]
+    cuts = list(range(0, frames, 125)) + [frames]
+    spans = list(zip(cuts[:-1], cuts[1:]))
+    delivered = 0
+    # phase 1: poll (blocking) after every batch
+    for a, e in spans[:3]:
+        assert bank.process_host(iq[a:e]) == e - a
+        res = bank.poll(wait=True)
+        assert res["batch_index"] == delivered
+        _check_delivery(res, out, a, e, tones, text)
+        delivered += 1
+    # phase 2: seven batches without polling (ring holds four): the oldest are parked on the host, none is lost
+    for a, e in spans[3:10]:
+        assert bank.process_host(iq[a:e]) == e - a
+    assert bank.results_pending == 7
+    # a too-small buffer reports what is needed and consumes nothing
+    r = capi.Results()
+    r.struct_size = C.sizeof(capi.Results)
+    rc = bank._L.sdr_poll(bank._h, C.byref(r), 1)
+    assert rc == capi.ERR_BAD_SIZE and r.n_edges > 0 and bank.results_pending == 7
+    for a, e in spans[3:10]:
+        res = bank.poll(wait=True)
+        assert res["batch_index"] == delivered
+        _check_delivery(res, out, a, e, tones, text)
+        delivered += 1
+    # phase 3: non-blocking polls while the rest is enqueued
+    for a, e in spans[10:]:
+        assert bank.process_host(iq[a:e]) == e - a
+    pending = [s for s in spans[10:]]
+    while pending:
+        res = bank.poll(wait=False)
+        if res is None:
+            res = bank.poll(wait=True)
+        a, e = pending.pop(0)
+        assert res["batch_index"] == delivered
+        _check_delivery(res, out, a, e, tones, text)
+        delivered += 1
+    assert bank.poll() is None and delivered == len(spans)
+    assert res["runes_dropped"] == 0 and res["edges_dropped"] == 0 and bank.read_drop_counters() == (0, 0)
+    for lid in range(tones):
+        assert text[lid] == ref.text(lid) and len(text[lid]) > 0
+        assert bank.read_text(0, lid) == ""  # delivered through sdr_poll only
+    bank.close()
+
+
+def test_drop_counters_are_exposed(capi):
+    """Without polling the per-listener text buffer (2048 runes) eventually fills: further runes are counted, not
+    lost silently (the reference's io.Writer never drops; the counters tell the host it polled too rarely)."""
+    n, rate = 512, 48000
+    frames = 4096
+    bank = capi.Bank(rate, n, max_batch_frames=frames, max_listeners=1, find_peaks=False)
+    b = 200
+    fft_bin = (b + n // 2) % n
+    tone = 0.1 * np.exp(2j * np.pi * fft_bin * np.arange(n) / n)
+    rng = np.random.default_rng(1)
+    # fastest legal keying: two frames on, two off = a stream of dits ("e" after "e"); one rune every ~8 frames
+    bits = (np.arange(frames) % 4 < 2).astype(np.float64)
+    x = bits[:, None] * tone[None, :] + 1e-3 * (rng.standard_normal((frames, n)) + 1j * rng.standard_normal((frames, n)))
+    iq = np.empty((frames, 2 * n), np.float32)
+    iq[:, 0::2], iq[:, 1::2] = x.real, x.imag
+    bank.attach(0, b)
+    for _ in range(24):  # about one rune per 32 frames
+        bank.process_host(iq)
+    runes, edges = bank.read_drop_counters()
+    kept = len(bank.read_text(0, 0))
+    assert edges == 0 and kept <= 2048
+    assert runes > 0 and kept == 2048, (runes, kept)
+    bank.close()
