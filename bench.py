@@ -34,6 +34,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_SAMPLE = 8   # one complex64 IQ sample read once
+# float64 vector rate without FMA (the bit-exact contract forbids fusing): MI355X's 78.6 TFLOP/s
+# FP64 vector peak counts an FMA as two, so 39.3 T lane-operations per second = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz
+F64_PEAK_TOPS = 39.3
 
 WORKLOADS = {
     # name: (sample_rate, block_size, tracked signals per band, bands per GPU, free_last_window)
@@ -65,7 +68,35 @@ def parse():
     ap.add_argument("--kernel-breakdown", action="store_true", help="print per-kernel HIP-event times to stderr")
     ap.add_argument("--serial", action="store_true",
                     help="diagnostic: run all stages on one stream (no overlap) so per-kernel times are standalone")
+    ap.add_argument("--no-delivery", action="store_true",
+                    help="diagnostic: leave results in HBM (no sdr_poll in the timed loop), as round 1 measured")
     return ap.parse_args()
+
+
+def f64_ops_per_sample(n):
+    """float64 add / mul instructions per IQ sample in k_fft_psd and in the whole path, counted in the compiled
+    kernels by tools/count_f64_ops.py (profiles/f64_ops.json); None if the count is missing for this block size."""
+    path = os.path.join(ROOT, "profiles", "f64_ops.json")
+    try:
+        d = json.load(open(path))[str(n)]
+        return d["k_fft_psd"], d["whole_path"]
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
+def measured_traffic(workload, frames):
+    """HBM bytes per k_fft_psd launch from the committed rocprofv3 --pmc runs (profiles/traffic.json), but only if
+    they were measured on exactly the kernel sources this run was built from (a plain bench run cannot collect
+    PMC counters itself); otherwise None."""
+    from sdrainer_amd.csrc import build
+
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if tj.get("_source_hash") != build.source_hash():
+            return None
+        return tj[f"{workload}_f{frames}"]["k_fft_psd_hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def available_cores() -> int:
@@ -199,8 +230,28 @@ def main():
             bank.attach(bi, int(b))
     torch.cuda.synchronize()
 
+    # results are DELIVERED inside the timed region: every step ends with a non-blocking sdr_poll loop that takes
+    # whatever batches have finished (peaks, edges, runes into host buffers); nothing may be dropped
+    delivery = not args.no_delivery
+    got = {"batches": 0, "peaks": 0, "edges": 0, "runes": 0, "runes_dropped": 0, "edges_dropped": 0}
+    if delivery:
+        bank.enable_results(True)
+
+    def take(wait=False):
+        while True:
+            r = bank.poll_counts(wait=wait and bank.results_pending > 0)
+            if r is None:
+                return
+            got["batches"] += 1
+            got["peaks"] += r[2]
+            got["edges"] += r[4]
+            got["runes"] += r[5]
+            got["runes_dropped"], got["edges_dropped"] = r[6], r[7]
+
     def step(i):
         bank.process_device(ring[i % len(ring)].data_ptr(), frames)
+        if delivery:
+            take()
 
     # run-in (untimed, not counted as warmup): the clocks ramp up from idle over the first few hundred
     # milliseconds of load; then the W warmup steps of the contract
@@ -214,6 +265,10 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+    if delivery:
+        take(wait=True)
+    for k_ in got:
+        got[k_] = 0
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -221,10 +276,16 @@ def main():
     for i in range(args.steps):
         step(args.warmup + i)
     torch.cuda.synchronize()
+    if delivery:
+        take(wait=True)  # the last batches' results, still inside the timed region
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if delivery:
+        assert got["batches"] == args.steps, f"delivered {got['batches']} of {args.steps} batches"
+        assert got["runes_dropped"] == 0 and got["edges_dropped"] == 0, got
+    delivered = dict(got)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -246,21 +307,15 @@ def main():
     for i in range(prof_steps):
         step(i)
     bank.sync()
+    if delivery:
+        take(wait=True)
     prof = bank.profile_read()
     bank.profile_enable(False)
     fft_ms, fft_n = prof["k_fft_psd"]
     fft_avg_ms = fft_ms / max(fft_n, 1)
     achieved = BYTES_PER_SAMPLE * samples_per_step_rank / (fft_avg_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            key = f"{args.workload}_f{frames}"
-            if key in tj:
-                traffic = tj[key]["k_fft_psd_hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+    traffic = measured_traffic(args.workload, frames)
+    ops_fft, ops_path = f64_ops_per_sample(n)
     if args.kernel_breakdown and rank == 0:
         tot = sum(v[0] for v in prof.values())
         for k, (ms, cnt) in prof.items():
@@ -269,7 +324,11 @@ def main():
               file=sys.stderr)
 
     # sanity: the timed path really decoded something (guards against measuring an empty pipeline)
-    decoded = sum(len(bank.read_text(0, lid)) for lid in range(min(tones, 4)))
+    if delivery:
+        decoded = delivered["runes"]
+        assert decoded > 0 and delivered["edges"] > 0, delivered
+    else:
+        decoded = sum(len(bank.read_text(0, lid)) for lid in range(min(tones, 4)))
     chunks = bank.last_batch_chunks
     # rehearsal / test hook: what THIS rank worked on (tests/test_bench_ranks.py)
     if os.environ.get("SDR_BENCH_RANK_REPORT"):
@@ -297,7 +356,12 @@ def main():
             "samples_per_step_per_gpu": samples_per_step_rank, "input": "complex64 IQ resident in HBM",
             "sharding": f"{bands_per_gpu * world} independent bands, {bands_per_gpu} per GPU, no data-path collective",
             "clock_settle_ms": args.settle_ms,
-            "sanity": {"runes_decoded_first_listeners": decoded, "cumulations_per_step": chunks},
+            "delivery": ("sdr_poll after every step inside the timed region: peaks, keying edges and decoded runes of "
+                         "every batch copied to host buffers, drop counters asserted zero") if delivery
+                        else "none (results left in HBM)",
+            "sanity": ({"batches_delivered": delivered["batches"], "peaks": delivered["peaks"], "edges": delivered["edges"],
+                        "runes": delivered["runes"], "cumulations_per_step": chunks} if delivery
+                       else {"runes_decoded_first_listeners": decoded, "cumulations_per_step": chunks}),
         },
         "roofline": {
             "bound": "hbm", "kernel": "k_fft_psd", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -306,6 +370,19 @@ def main():
             "whole_path_frac": round(value * 1e6 / world * BYTES_PER_SAMPLE / (HBM_PEAK_GBS * 1e9), 4),
         },
     }
+    if ops_fft:
+        # What actually bounds the kernel: float64 vector issue.  The bit-exact contract (same butterfly graph, no
+        # FMA) fixes the float64 operations per sample, so the chip's non-FMA float64 rate caps the sample rate,
+        # and with it the reachable fraction of the HBM roofline (ceiling_hbm_frac), below the 8 B/sample line.
+        tops = ops_fft * samples_per_step_rank / (fft_avg_ms * 1e-3) / 1e12
+        result["roofline"]["compute"] = {
+            "bound": "f64_valu", "ops_per_sample": ops_fft, "achieved_Tops": round(tops, 2), "peak_Tops": F64_PEAK_TOPS,
+            "frac": round(tops / F64_PEAK_TOPS, 4),
+            "ceiling_hbm_frac": round(F64_PEAK_TOPS * 1e12 / ops_fft * BYTES_PER_SAMPLE / (HBM_PEAK_GBS * 1e9), 4),
+            "whole_path_ops_per_sample": ops_path,
+            "whole_path_ceiling_hbm_frac": round(F64_PEAK_TOPS * 1e12 / ops_path * BYTES_PER_SAMPLE / (HBM_PEAK_GBS * 1e9), 4),
+            "whole_path_frac_of_ceiling": round(value * 1e6 / world * ops_path / (F64_PEAK_TOPS * 1e12), 4),
+        }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(rate, n, tones, free_last, args.cpu_seconds)
     bank.close()
