@@ -231,7 +231,8 @@ typedef struct sdr_results {
     int32_t listeners_cap, n_listeners;
     sdr_edge *edges;
     int32_t edges_cap, n_edges;
-    uint32_t *runes;
+    uint32_t *runes;       /* Unicode code points */
+    uint32_t *rune_frames; /* same capacity and count as runes: bank frame index of the Tick that wrote each rune */
     int32_t runes_cap, n_runes;
     uint64_t runes_dropped, edges_dropped; /* since bank creation (out) */
 } sdr_results;
@@ -245,6 +246,36 @@ int sdr_results_pending(sdr_bank *bank);
 /* Overflow counters without bulk delivery (synchronises): runes the decoders could not store because a text
  * buffer was full, and keying edges beyond the edge buffer of the batches so far. */
 int sdr_read_drop_counters(sdr_bank *bank, uint64_t *runes_dropped, uint64_t *edges_dropped);
+
+/* scope tap ---------------------------------------------------------------------------------- */
+/* The reference shows its inner workings through scope.Scope (scope/scope.go:33-37); NullScope is the default
+ * and so is "no tap" here: the two reads below need a bank created with trace = 1 (that is scope.Active()).
+ * A frame's Timestamp is replaced by the frame index, everything else is the reference's payload:
+ *   stream "spectrum" (rx/receiver.go:428-457): once per completed cumulation, Values = cumulation / 100 as
+ *       float64, FrequencyMarkers{"signal_bin"} = bin of the first listener (-1: none),
+ *       MagnitudeMarkers{"threshold"} = peakThreshold, FromFrequency 0, ToFrequency 1;
+ *   stream "demod" (cw/spectral.go:56-81): once per listener per frame, Values{"threshold", "value",
+ *       "state" (-1 / 100), "debounced" (-1 / 80)}. */
+typedef struct sdr_scope_spectral_frame {
+    int64_t frame;          /* bank frame index that completed the cumulation */
+    double from_frequency;  /* 0 */
+    double to_frequency;    /* 1 */
+    double signal_bin;      /* FrequencyMarkers["signal_bin"] */
+    double threshold;       /* MagnitudeMarkers["threshold"] */
+    int32_t n_values;       /* block_size */
+    int32_t reserved;
+} sdr_scope_spectral_frame;
+
+typedef struct sdr_scope_time_frame {
+    double threshold, value, state, debounced;
+} sdr_scope_time_frame;
+
+/* 1 if the bank taps (created with trace = 1), else 0: scope.Scope.Active(). */
+int sdr_scope_active(sdr_bank *bank);
+/* Spectral frame of completed cumulation `chunk` of the last batch; values: float64[block_size]. */
+int sdr_scope_read_spectral(sdr_bank *bank, int band, int chunk, sdr_scope_spectral_frame *frame, double *values, int max_values);
+/* The listener's "demod" time frames of the last batch, one per frame. */
+int sdr_scope_read_demod(sdr_bank *bank, int band, int listener_id, sdr_scope_time_frame *out, int max, int *n_out);
 
 /* measurement ------------------------------------------------------------------------------- */
 /* When enabled every kernel launch is bracketed by HIP events on the bank's stream. */

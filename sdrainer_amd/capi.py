@@ -58,6 +58,15 @@ LISTENER_RESULT_DTYPE = np.dtype([("band", "<i4"), ("listener", "<i4"), ("first_
                                   ("first_rune", "<i4"), ("n_runes", "<i4")])
 
 
+class ScopeSpectralFrame(C.Structure):
+    """sdr_scope_spectral_frame: scope.SpectralFrame without its Values (scope/scope.go:24-31)."""
+    _fields_ = [("frame", C.c_int64), ("from_frequency", C.c_double), ("to_frequency", C.c_double),
+                ("signal_bin", C.c_double), ("threshold", C.c_double), ("n_values", C.c_int32), ("reserved", C.c_int32)]
+
+
+SCOPE_TIME_DTYPE = np.dtype([("threshold", "<f8"), ("value", "<f8"), ("state", "<f8"), ("debounced", "<f8")])
+
+
 class Results(C.Structure):
     """sdr_results (include/sdrainer_hip.h)."""
     _fields_ = [
@@ -66,7 +75,7 @@ class Results(C.Structure):
         ("peaks", C.c_void_p), ("peaks_cap", C.c_int32), ("n_peaks", C.c_int32),
         ("listeners", C.c_void_p), ("listeners_cap", C.c_int32), ("n_listeners", C.c_int32),
         ("edges", C.c_void_p), ("edges_cap", C.c_int32), ("n_edges", C.c_int32),
-        ("runes", C.c_void_p), ("runes_cap", C.c_int32), ("n_runes", C.c_int32),
+        ("runes", C.c_void_p), ("rune_frames", C.c_void_p), ("runes_cap", C.c_int32), ("n_runes", C.c_int32),
         ("runes_dropped", C.c_uint64), ("edges_dropped", C.c_uint64),
     ]
 
@@ -79,7 +88,7 @@ SYMBOLS = (
     "sdr_set_peak_threshold sdr_set_edge_width sdr_set_signal_debounce sdr_set_center_frequency sdr_set_find_peaks "
     "sdr_last_batch_frames sdr_total_frames sdr_last_batch_chunks sdr_read_peaks sdr_read_cumulation sdr_read_text "
     "sdr_read_edges sdr_read_keying_bits sdr_read_frame_records sdr_read_trace sdr_read_spectrum "
-    "sdr_read_decoder_state sdr_enable_results sdr_poll sdr_results_pending sdr_read_drop_counters sdr_profile_enable sdr_profile_read sdr_profile_reset sdr_kernel_name sdr_audio_create "
+    "sdr_read_decoder_state sdr_scope_active sdr_scope_read_spectral sdr_scope_read_demod sdr_enable_results sdr_poll sdr_results_pending sdr_read_drop_counters sdr_profile_enable sdr_profile_read sdr_profile_reset sdr_kernel_name sdr_audio_create "
     "sdr_audio_destroy sdr_audio_blocksize sdr_audio_set_scale sdr_audio_set_debounce "
     "sdr_audio_set_magnitude_threshold sdr_audio_write sdr_audio_close sdr_audio_read_text sdr_audio_read_trace"
 ).split()
@@ -144,6 +153,9 @@ def load():
     sig("sdr_read_trace", C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int)
     sig("sdr_read_spectrum", C.c_int, vp, C.c_int, C.c_int, vp, vp)
     sig("sdr_read_decoder_state", C.c_int, vp, C.c_int, C.c_int, C.POINTER(C.c_double))
+    sig("sdr_scope_active", C.c_int, vp)
+    sig("sdr_scope_read_spectral", C.c_int, vp, C.c_int, C.c_int, C.POINTER(ScopeSpectralFrame), C.POINTER(C.c_double), C.c_int)
+    sig("sdr_scope_read_demod", C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, ip)
     sig("sdr_enable_results", C.c_int, vp, C.c_int)
     sig("sdr_poll", C.c_int, vp, C.POINTER(Results), C.c_int)
     sig("sdr_results_pending", C.c_int, vp)
@@ -353,6 +365,29 @@ class Bank:
         _check(self._L.sdr_read_decoder_state(self._h, band, lid, out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
 
+    # scope tap --------------------------------------------------------------------------------
+    @property
+    def scope_active(self) -> bool:
+        return bool(self._L.sdr_scope_active(self._h))
+
+    def scope_spectral_frame(self, band: int, chunk: int):
+        """(header dict, Values float64[N]) of the "spectrum" scope stream for one completed cumulation."""
+        fr = ScopeSpectralFrame()
+        vals = np.empty(self.n, np.float64)
+        _check(self._L.sdr_scope_read_spectral(self._h, band, chunk, C.byref(fr), vals.ctypes.data_as(C.POINTER(C.c_double)),
+                                               self.n))
+        hdr = {"frame": fr.frame, "from_frequency": fr.from_frequency, "to_frequency": fr.to_frequency,
+               "signal_bin": fr.signal_bin, "threshold": fr.threshold, "n_values": fr.n_values}
+        return hdr, vals
+
+    def scope_demod_frames(self, band: int, lid: int) -> np.ndarray:
+        """The listener's "demod" scope stream of the last batch: threshold, value, state, debounced per frame."""
+        nf = self.last_batch_frames
+        out = np.zeros(max(nf, 1), SCOPE_TIME_DTYPE)
+        n = C.c_int()
+        _check(self._L.sdr_scope_read_demod(self._h, band, lid, _vp(out), nf, C.byref(n)))
+        return out[:min(nf, n.value)]
+
     # bulk delivery ----------------------------------------------------------------------------
     def enable_results(self, on: bool = True):
         _check(self._L.sdr_enable_results(self._h, int(on)))
@@ -367,11 +402,13 @@ class Bank:
                 "edges": np.zeros(listeners * min(c.max_batch_frames, 8192), EDGE_DTYPE),
                 "runes": np.zeros(listeners * 2048, np.uint32),
             }
+            self._rune_frames = np.zeros(listeners * 2048, np.uint32)
             r = Results()
             r.struct_size = C.sizeof(Results)
             for k, a in self._res_bufs.items():
                 setattr(r, k, a.ctypes.data)
                 setattr(r, k + "_cap", len(a))
+            r.rune_frames = self._rune_frames.ctypes.data
             self._res = r
 
     def poll(self, wait: bool = False, copy: bool = True):
@@ -386,6 +423,8 @@ class Bank:
         for k, a in self._res_bufs.items():
             v = a[:getattr(r, "n_" + k)]
             out[k] = v.copy() if copy else v
+        v = self._rune_frames[:r.n_runes]
+        out["rune_frames"] = v.copy() if copy else v
         return out
 
     def poll_counts(self, wait: bool = False):

@@ -302,7 +302,8 @@ SDR_HD inline void decoder_edge(DecoderState &d, bool state, const uint16_t *tab
     d.lastState = state;
 }
 
-// `k` consecutive Tick(state) calls with state == lastState, in closed form.  Between edges Tick only
+// `k` consecutive Tick(state) calls with state == lastState, in closed form.  (The sink is told which tick of
+// the run writes - `at_run_tick` - so that a rune can be stamped with its frame.)  Between edges Tick only
 // counts (`ticks++`) and checks `decoding && currentDuration > upperBound` (:244-249); neither
 // threshold changes, currentDuration = now - start is an exact integer, so the check first fires at
 // the tick where now == floor(upperBound) + 1 + start (if that tick is within the run) and never again
@@ -318,6 +319,7 @@ SDR_HD inline void decoder_advance(DecoderState &d, int k, const uint16_t *table
         const double first_now = ::floor(upperBound) + 1.0 + start;  // smallest integer now with now-start > upperBound
         if (first_now <= d.ticks + (double)k) {  // (first_now <= ticks cannot happen while decoding is still set)
             d.decoding = 0;
+            out.at_run_tick((int)(first_now - d.ticks) - 1);  // which of the run's k ticks writes (0-based)
             decode_current_char(d, table, out);
         }
     }

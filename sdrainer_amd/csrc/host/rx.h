@@ -13,6 +13,7 @@
 // listener is bound to which peak, time-outs.  Everything per frame is on the device.
 #pragma once
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <functional>
@@ -273,8 +274,35 @@ public:
         }
         text_ += utf8;
     }
+    void WriteRune(uint32_t r)  // one Decoder write (cw/decode.go:352: one rune per call)
+    {
+        char b[4];
+        size_t n = 0;
+        if (r < 0x80) {
+            b[n++] = (char)r;
+        } else if (r < 0x800) {
+            b[n++] = (char)(0xC0 | (r >> 6));
+            b[n++] = (char)(0x80 | (r & 0x3F));
+        } else if (r < 0x10000) {
+            b[n++] = (char)(0xE0 | (r >> 12));
+            b[n++] = (char)(0x80 | ((r >> 6) & 0x3F));
+            b[n++] = (char)(0x80 | (r & 0x3F));
+        } else {
+            b[n++] = (char)(0xF0 | (r >> 18));
+            b[n++] = (char)(0x80 | ((r >> 12) & 0x3F));
+            b[n++] = (char)(0x80 | ((r >> 6) & 0x3F));
+            b[n++] = (char)(0x80 | (r & 0x3F));
+        }
+        const std::string s(b, n);
+        textProcessor_.Write(s);
+        text_ += s;
+    }
     const std::string &Text() const { return text_; }
     TextProcessor &Processor() { return textProcessor_; }
+    double LastAttach() const { return lastAttach_; }
+    double LastWrite() const { return textProcessor_.LastWrite(); }
+    double SilenceTimeout() const { return silenceTimeout_; }
+    double AttachmentTimeout() const { return attachmentTimeout_; }
 
 private:
     // :70-83 — the text processor's callbacks, forwarded with the listener's id and signal frequency
@@ -445,7 +473,19 @@ public:
             return rc;
         sampleRate_ = sampleRate;
         blockSize_ = blockSize;
+        maxBatchFrames_ = maxBatchFrames;
         sdr_set_center_frequency(bank_, 0, centerFrequency_);
+        // results arrive in bulk, one sdr_poll per processed segment (no per-listener reads, no pipeline drain)
+        rc = sdr_enable_results(bank_, 1);
+        if (rc != SDR_OK)
+            return rc;
+        const size_t chunks = (size_t)maxBatchFrames / kCumulationSize + 2, pool = (size_t)std::max(listeners_.Size(), 1);
+        resChunks_.resize(chunks);
+        resPeaks_.resize(chunks * (size_t)cfg.max_peaks);
+        resListeners_.resize(pool);
+        resEdges_.resize(pool * (size_t)std::min(maxBatchFrames, 8192));
+        resRunes_.resize(pool * 2048);
+        resRuneFrames_.resize(pool * 2048);
         peaks_.reset(new PeaksTable(blockSize, clock_));
         peaks_->SetRand(rand_);
         peaks_->SetPolicy(policy_);
@@ -497,30 +537,52 @@ public:
         return attach(listener, peak);
     }
 
-    // The frame case of run() (:353-463) for everything staged so far.  In strain mode with a free
-    // listener the batch is cut at every cumulation boundary, because that is where the reference binds
-    // a new listener that must start listening with the very next frame (:409-426).
+    // The frame case of run() (:353-463) for everything staged so far (IQData), or for `n_frames` frames already
+    // in device memory ([frame][2 * blockSize] float32, 16-byte aligned).  The stream is processed in segments;
+    // where a segment ends is what keeps the per-frame semantics of the reference (:388-426) although the
+    // device works on many frames per call:
+    //  * strain mode with a free listener: at every cumulation boundary, where the reference binds a new
+    //    listener that must start listening with the very next frame (:409-426);
+    //  * any listener: at the earliest frame its attachment or silence time-out can fire (:396-400).  With the
+    //    stream clock (frame f happens at (f + 1) * blockSize / sampleRate) that frame is known: the attachment
+    //    expiry exactly, the silence expiry as "no rune from now on" - runes only postpone it, and every rune
+    //    comes back stamped with the frame of its Write (text_processor.go:208-209), so the check after the
+    //    segment is the reference's check at exactly that frame.  With a caller-supplied clock the time of a
+    //    frame is not defined; time-outs are then evaluated once per segment, at the clock's value.
     int Process()
     {
         if (!bank_)
             return SDR_OK;
-        while (sdr_staged_frames(bank_, 0) > 0) {
-            const bool hunting = mode_ == StrainMode && listeners_.Available();
-            const int until_boundary = kCumulationSize - (int)(framesProcessed_ % kCumulationSize);
+        for (;;) {
+            const int staged = sdr_staged_frames(bank_, 0);
+            if (staged <= 0)
+                return SDR_OK;
+            const int limit = segmentLimit(staged);
             int n = 0;
-            sdr_set_find_peaks(bank_, hunting ? 1 : 0);  // :410: FindPeaks only while a listener is free
-            int rc = hunting ? sdr_process_staged_limit(bank_, until_boundary, &n) : sdr_process_staged(bank_, &n);
+            int rc = sdr_process_staged_limit(bank_, limit, &n);
             if (rc != SDR_OK)
                 return rc;
             if (n == 0)
-                break;
-            framesProcessed_ += n;
-            streamClock_.Set((double)framesProcessed_ * (double)blockSize_ / (double)sampleRate_);
-            drainText();
-            housekeeping();
-            checkTimeouts();
-            if (hunting && sdr_last_batch_chunks(bank_) > 0)
-                discover(sdr_last_batch_chunks(bank_) - 1);
+                return SDR_OK;
+            rc = afterSegment(n);
+            if (rc != SDR_OK)
+                return rc;
+        }
+    }
+    int ProcessDevice(const float *iq_dev, int n_frames)
+    {
+        if (!bank_)
+            return SDR_OK;
+        int done = 0;
+        while (done < n_frames) {
+            const int n = segmentLimit(n_frames - done);
+            int rc = sdr_process_device(bank_, iq_dev + (size_t)done * 2 * (size_t)blockSize_, n);
+            if (rc != SDR_OK)
+                return rc;
+            rc = afterSegment(n);
+            if (rc != SDR_OK)
+                return rc;
+            done += n;
         }
         return SDR_OK;
     }
@@ -607,16 +669,93 @@ private:
         listener->Attach(peak, dev);
         return SDR_OK;
     }
-    void drainText()
+    double frameTime(int64_t f) const { return (double)(f + 1) * (double)blockSize_ / (double)sampleRate_; }
+    bool firesAt(const Listener &l, int64_t f) const  // Listener.TimeoutExceeded with the clock at frame f
     {
-        char buf[8192];
-        for (auto &l : listeners_.Listeners()) {
-            if (!l->Attached())
-                continue;
-            int nb = 0;
-            if (sdr_read_text(bank_, 0, l->DeviceID(), buf, (int)sizeof buf, &nb) == SDR_OK && nb > 0)
-                l->Write(std::string(buf, (size_t)nb));
+        const double now = frameTime(f);
+        return (now - l.LastAttach() > l.AttachmentTimeout()) || (now - l.LastWrite() > l.SilenceTimeout());
+    }
+    // first frame >= from at which the listener's time-out fires if it writes nothing more
+    int64_t earliestExpiry(const Listener &l, int64_t from) const
+    {
+        const double T = (double)blockSize_ / (double)sampleRate_;
+        const double due = std::min(l.LastAttach() + l.AttachmentTimeout(), l.LastWrite() + l.SilenceTimeout());
+        if (!(due < 1e18))
+            return INT64_MAX;
+        int64_t f = (int64_t)std::floor(due / T);  // (f + 1) * T > due  <=>  f + 1 > due / T
+        f = std::max(f - 2, from);                 // settle rounding with the predicate itself
+        while (!firesAt(l, f))
+            f++;
+        return f;
+    }
+    // how many of `available` frames the next device call may take
+    int segmentLimit(int available)
+    {
+        int limit = std::min(available, maxBatchFrames_);
+        segExpiryAtEnd_ = false;
+        if (mode_ != StrainMode)
+            return limit;
+        const int until_boundary = kCumulationSize - (int)(framesProcessed_ % kCumulationSize);
+        const bool hunting = listeners_.Available();
+        if (hunting)
+            limit = std::min(limit, until_boundary);
+        if (clock_ == &streamClock_) {
+            int64_t first = INT64_MAX;
+            for (auto &l : listeners_.Listeners())
+                if (l->Attached())
+                    first = std::min(first, earliestExpiry(*l, framesProcessed_));
+            if (first != INT64_MAX && first - framesProcessed_ + 1 <= (int64_t)limit) {
+                limit = (int)(first - framesProcessed_ + 1);
+                segExpiryAtEnd_ = true;
+            }
         }
+        // FindPeaks is only needed where a listener can be bound: at a boundary with a free slot (:410) - free
+        // now, or freed by a time-out on the segment's last frame
+        const bool ends_on_boundary = limit >= until_boundary;
+        sdr_set_find_peaks(bank_, (hunting || (segExpiryAtEnd_ && ends_on_boundary)) ? 1 : 0);
+        return limit;
+    }
+    int afterSegment(int n)
+    {
+        const int64_t first = framesProcessed_;
+        framesProcessed_ += n;
+        sdr_results r{};
+        r.struct_size = sizeof r;
+        r.chunks = resChunks_.data();
+        r.chunks_cap = (int)resChunks_.size();
+        r.peaks = resPeaks_.data();
+        r.peaks_cap = (int)resPeaks_.size();
+        r.listeners = resListeners_.data();
+        r.listeners_cap = (int)resListeners_.size();
+        r.edges = resEdges_.data();
+        r.edges_cap = (int)resEdges_.size();
+        r.runes = resRunes_.data();
+        r.rune_frames = resRuneFrames_.data();
+        r.runes_cap = (int)resRunes_.size();
+        const int rc = sdr_poll(bank_, &r, 1);
+        if (rc != SDR_OK)
+            return rc;
+        (void)first;
+        // runes -> the listeners' text processors, each stamped with the time of its frame
+        for (int i = 0; i < r.n_listeners; i++) {
+            const sdr_listener_result &lr = r.listeners[i];
+            for (auto &l : listeners_.Listeners()) {
+                if (!l->Attached() || l->DeviceID() != lr.listener)
+                    continue;
+                for (int k = 0; k < lr.n_runes; k++) {
+                    if (clock_ == &streamClock_)
+                        streamClock_.Set(frameTime(r.rune_frames[lr.first_rune + k]));
+                    l->WriteRune(r.runes[lr.first_rune + k]);
+                }
+                break;
+            }
+        }
+        streamClock_.Set(frameTime(framesProcessed_ - 1));
+        housekeeping();
+        checkTimeouts();
+        if (mode_ == StrainMode && framesProcessed_ % kCumulationSize == 0 && listeners_.Available() && r.n_chunks > 0)
+            discover(r, r.n_chunks - 1);
+        return SDR_OK;
     }
     void housekeeping()  // the cleanupTicker case, :359-363: once per second of clock time
     {
@@ -629,7 +768,7 @@ private:
         if (peaks_)
             peaks_->Cleanup();
     }
-    void checkTimeouts()  // :396-402 (evaluated per processed segment instead of per frame)
+    void checkTimeouts()  // :396-402, with the clock at the segment's last frame (see Process)
     {
         if (mode_ != StrainMode)
             return;
@@ -644,15 +783,11 @@ private:
         for (auto &l : detached)
             listeners_.Release(l);
     }
-    void discover(int chunk)  // :409-426
+    void discover(const sdr_results &r, int chunk)  // :409-426
     {
-        std::vector<Peak> found((size_t)blockSize_ / 2);
-        int n = 0, frame = 0;
-        if (sdr_read_peaks(bank_, 0, chunk, found.data(), (int)found.size(), &n, &frame) != SDR_OK)
-            return;
-        found.resize((size_t)std::min(n, (int)found.size()));
-        lastPeaks_ = found;
-        for (const Peak &p : found)
+        const sdr_chunk_result &cr = r.chunks[chunk];
+        lastPeaks_.assign(r.peaks + cr.first_peak, r.peaks + cr.first_peak + cr.n_peaks);
+        for (const Peak &p : lastPeaks_)
             peaks_->Put(newPeakCenteredOnSignal(p));
         const Peak *selected = peaks_->FindNext();
         if (!selected)
@@ -682,8 +817,16 @@ private:
     PeaksTable::Policy policy_ = PeaksTable::ReferenceOrder;
     ListenerPool listeners_;
     int64_t framesProcessed_ = 0;
+    int maxBatchFrames_ = 256;
+    bool segExpiryAtEnd_ = false;
     double lastCleanup_ = 0;
     std::vector<Peak> lastPeaks_;
+    // sdr_poll buffers
+    std::vector<sdr_chunk_result> resChunks_;
+    std::vector<sdr_peak> resPeaks_;
+    std::vector<sdr_listener_result> resListeners_;
+    std::vector<sdr_edge> resEdges_;
+    std::vector<uint32_t> resRunes_, resRuneFrames_;
 };
 
 }  // namespace rx

@@ -66,22 +66,32 @@ __global__ __launch_bounds__(64) void k_listen_gather(const float *__restrict__ 
 
 constexpr int DECODE_LANES = 16;
 
+// The io.Writer of a listener's decoder (cw/decode.go:352): runes and, beside each, the bank frame index of the
+// Tick that wrote it (the host stamps TextProcessor.Write with that frame's time: rx/text_processor.go:208-209,
+// which is what the listener's silence time-out is measured from, rx/listener.go:126-136).
 struct TextSink {
     uint32_t *buf;
+    uint32_t *frames;
     uint32_t count, cap, dropped;
+    uint32_t frame;     // frame of the tick being processed
+    uint32_t run_base;  // frame of the first tick of the run decoder_advance is walking
+    __device__ void at_run_tick(int k) { frame = run_base + (uint32_t)k; }
     __device__ void put(uint32_t r)
     {
-        if (count < cap)
-            buf[count++] = r;
-        else
+        if (count < cap) {
+            buf[count] = r;
+            frames[count] = frame;
+            count++;
+        } else {
             dropped++;
+        }
     }
 };
 
 __global__ __launch_bounds__(64) void k_listen_decode(ListenerSlot *__restrict__ slots, const uint16_t *morse,
                                                       const uint64_t *__restrict__ raw_bits,
                                                       uint64_t *__restrict__ deb_bits, uint32_t *__restrict__ text,
-                                                      sdr_edge *__restrict__ edges,
+                                                      uint32_t *__restrict__ text_frames, sdr_edge *__restrict__ edges,
                                                       uint32_t *__restrict__ edge_counts, uint8_t *__restrict__ tr_deb,
                                                       DropCounters *__restrict__ drops, ListenGeom g, int n_frames,
                                                       int n_total)
@@ -104,7 +114,8 @@ __global__ __launch_bounds__(64) void k_listen_decode(ListenerSlot *__restrict__
         return;
     cw::Debouncer deb = slot->deb;
     cw::DecoderState dec = slot->dec;
-    TextSink sink{text + (size_t)idx * g.text_cap, slot->text_count, (uint32_t)g.text_cap, slot->text_dropped};
+    TextSink sink{text + (size_t)idx * g.text_cap, text_frames + (size_t)idx * g.text_cap, slot->text_count,
+                  (uint32_t)g.text_cap, slot->text_dropped, g.frame_base, g.frame_base};
     sdr_edge *my_edges = edges + (size_t)idx * g.edge_cap;
     const uint64_t *rw = raw_bits + (size_t)idx * g.bit_words;
     uint64_t *dw = deb_bits + (size_t)idx * g.bit_words;
@@ -129,6 +140,7 @@ __global__ __launch_bounds__(64) void k_listen_decode(ListenerSlot *__restrict__
             if (cnt - pos < 64)
                 diff &= (1ull << (cnt - pos)) - 1ull;
             const int run = diff ? (__ffsll((long long)diff) - 1) : (cnt - pos);
+            sink.run_base = g.frame_base + (uint32_t)(f0 + pos);
             cw::decoder_advance(dec, run, morse, sink);
             pos += run;
             if (pos < cnt) {  // the edge tick
@@ -136,6 +148,7 @@ __global__ __launch_bounds__(64) void k_listen_decode(ListenerSlot *__restrict__
                 if (n_edges < (uint32_t)g.edge_cap)
                     my_edges[n_edges] = sdr_edge{(uint32_t)(g.frame_base + f0 + pos), st ? 1u : 0u};
                 n_edges++;
+                sink.frame = g.frame_base + (uint32_t)(f0 + pos);
                 cw::decoder_edge(dec, st, morse, sink);
                 pos++;
             }
@@ -157,12 +170,13 @@ __global__ __launch_bounds__(64) void k_listen_decode(ListenerSlot *__restrict__
 }
 
 // cw.Decoder.stop for one listener (cw/decode.go:352-354)
-__global__ void k_listener_stop(ListenerSlot *slot, const uint16_t *morse, uint32_t *text, int text_cap, DropCounters *drops)
+__global__ void k_listener_stop(ListenerSlot *slot, const uint16_t *morse, uint32_t *text, uint32_t *text_frames, int text_cap,
+                                uint32_t frame, DropCounters *drops)
 {
     if (threadIdx.x != 0 || !slot->active)
         return;
     cw::DecoderState dec = slot->dec;
-    TextSink sink{text, slot->text_count, (uint32_t)text_cap, slot->text_dropped};
+    TextSink sink{text, text_frames, slot->text_count, (uint32_t)text_cap, slot->text_dropped, frame, frame};
     cw::decoder_stop(dec, morse, sink);
     slot->dec = dec;
     slot->text_count = sink.count;
@@ -190,20 +204,20 @@ hipError_t launch_listen_gather(const float *tap, const sdr_frame_rec *recs, con
 }
 
 hipError_t launch_listen_decode(ListenerSlot *slots, const uint16_t *morse, const uint64_t *raw_bits,
-                                uint64_t *deb_bits, uint32_t *text, sdr_edge *edges, uint32_t *edge_counts,
-                                uint8_t *tr_deb, DropCounters *drops, ListenGeom g, int n_frames, int n_bands,
-                                hipStream_t stream)
+                                uint64_t *deb_bits, uint32_t *text, uint32_t *text_frames, sdr_edge *edges,
+                                uint32_t *edge_counts, uint8_t *tr_deb, DropCounters *drops, ListenGeom g, int n_frames,
+                                int n_bands, hipStream_t stream)
 {
     const int n_total = n_bands * g.max_listeners;
     hipLaunchKernelGGL(k_listen_decode, dim3((n_total + DECODE_LANES - 1) / DECODE_LANES), dim3(64), 0, stream, slots, morse, raw_bits,
-                       deb_bits, text, edges, edge_counts, tr_deb, drops, g, n_frames, n_total);
+                       deb_bits, text, text_frames, edges, edge_counts, tr_deb, drops, g, n_frames, n_total);
     return hipGetLastError();
 }
 
-hipError_t launch_listener_stop(ListenerSlot *slot, const uint16_t *morse, uint32_t *text, int text_cap, DropCounters *drops,
-                                hipStream_t stream)
+hipError_t launch_listener_stop(ListenerSlot *slot, const uint16_t *morse, uint32_t *text, uint32_t *text_frames, int text_cap,
+                                uint32_t frame, DropCounters *drops, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_listener_stop, dim3(1), dim3(64), 0, stream, slot, morse, text, text_cap, drops);
+    hipLaunchKernelGGL(k_listener_stop, dim3(1), dim3(64), 0, stream, slot, morse, text, text_frames, text_cap, frame, drops);
     return hipGetLastError();
 }
 

@@ -15,6 +15,7 @@ namespace sdr {
 __global__ __launch_bounds__(64) void k_pack_listen(ListenerSlot *__restrict__ slots, const sdr_edge *__restrict__ edges,
                                                     const uint32_t *__restrict__ edge_counts,
                                                     const uint32_t *__restrict__ text,
+                                                    const uint32_t *__restrict__ text_frames,
                                                     const DropCounters *__restrict__ drops, ResultsLayout lay,
                                                     unsigned char *__restrict__ host)
 {
@@ -40,8 +41,12 @@ __global__ __launch_bounds__(64) void k_pack_listen(ListenerSlot *__restrict__ s
         dst_e[i] = src_e[i];
     const uint32_t *src_t = text + idx * lay.text_cap;
     uint32_t *dst_t = reinterpret_cast<uint32_t *>(host + lay.off_text) + idx * lay.text_cap;
-    for (uint32_t i = lane; i < n_runes; i += 64)
+    const uint32_t *src_f = text_frames + idx * lay.text_cap;
+    uint32_t *dst_f = reinterpret_cast<uint32_t *>(host + lay.off_text_frames) + idx * lay.text_cap;
+    for (uint32_t i = lane; i < n_runes; i += 64) {
         dst_t[i] = src_t[i];
+        dst_f[i] = src_f[i];
+    }
     if (lane == 0) {
         h_edge_counts[idx] = n_edges;
         h_text_counts[idx] = n_runes;
@@ -69,12 +74,12 @@ __global__ __launch_bounds__(64) void k_pack_peaks(const DevPeak *__restrict__ p
 }
 
 hipError_t launch_pack_listen(ListenerSlot *slots, const sdr_edge *edges, const uint32_t *edge_counts, const uint32_t *text,
-                              const DropCounters *drops, ResultsLayout lay, int n_slots, int n_bands, unsigned char *host,
+                              const uint32_t *text_frames, const DropCounters *drops, ResultsLayout lay, int n_slots, int n_bands, unsigned char *host,
                               hipStream_t stream)
 {
     // (at least one workgroup: it also delivers the drop counters)
     hipLaunchKernelGGL(k_pack_listen, dim3(n_slots > 0 ? n_slots : 1, n_bands), dim3(64), 0, stream, slots, edges, edge_counts, text,
-                       drops, lay, host);
+                       text_frames, drops, lay, host);
     return hipGetLastError();
 }
 

@@ -163,7 +163,8 @@ struct sdr_bank {
     DevBuf<sdr::BandState> band_state;
     DevBuf<sdr::ListenerSlot> slots;  // [band][max_listeners]
     DevBuf<uint16_t> morse;
-    DevBuf<uint32_t> text;   // [band][L][text_cap]
+    DevBuf<uint32_t> text;         // [band][L][text_cap] decoded runes not yet read / delivered
+    DevBuf<uint32_t> text_frames;  // [band][L][text_cap] bank frame index of the Tick that wrote each rune
     DevBuf<float> carry[2];  // [band][N] cumulation carried between batches (double buffered)
 
     std::vector<sdr::BandState> h_band_state;
@@ -337,6 +338,7 @@ sdr::ResultsLayout make_results_layout(const sdr_bank *b)
     l.off_edges = take(B * L * (size_t)b->edge_cap * sizeof(sdr_edge));
     l.off_text_counts = take(B * L * sizeof(uint32_t));
     l.off_text = take(B * L * (size_t)b->text_cap * sizeof(uint32_t));
+    l.off_text_frames = take(B * L * (size_t)b->text_cap * sizeof(uint32_t));
     l.bytes = off;
     return l;
 }
@@ -484,13 +486,13 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     if (max_slots > 0) {
         ProfScope ps(b, sdr::K_LISTEN_DECODE, stream_of(sdr::K_LISTEN_DECODE));
         SDR_LAUNCH(sdr::K_LISTEN_DECODE, sdr::launch_listen_decode(b->slots.p, b->morse.p, S.raw_bits.p, S.bits.p, b->text.p,
-                                                                   S.edges.p, S.edge_counts.p, S.tr_deb.p, b->drops.p, lg, n_frames,
+                                                                   b->text_frames.p, S.edges.p, S.edge_counts.p, S.tr_deb.p, b->drops.p, lg, n_frames,
                                                                    B, stream_of(sdr::K_LISTEN_DECODE)));
     }
     if (b->results_on) {
         // delivery of this batch's edges and runes, behind the decoder on its stream; the decoder's event is
         // recorded behind it so that the set is not reused before the copy to the host has happened
-        HIP_TRY(sdr::launch_pack_listen(b->slots.p, S.edges.p, S.edge_counts.p, b->text.p, b->drops.p, b->res_layout, max_slots, B,
+        HIP_TRY(sdr::launch_pack_listen(b->slots.p, S.edges.p, S.edge_counts.p, b->text.p, b->text_frames.p, b->drops.p, b->res_layout, max_slots, B,
                                         S.res_host, stream_of(sdr::K_LISTEN_DECODE)));
         HIP_TRY(hipEventRecord(S.res_listen, stream_of(sdr::K_LISTEN_DECODE)));
     }
@@ -674,6 +676,7 @@ int sdr_create(const sdr_config *cfg, sdr_bank **out)
     ALLOC(b->slots, B * L);
     ALLOC(b->morse, cw::kMorseTableSize);
     ALLOC(b->text, B * L * (size_t)b->text_cap);
+    ALLOC(b->text_frames, B * L * (size_t)b->text_cap);
     ALLOC(b->carry[0], B * N);
     ALLOC(b->carry[1], B * N);
 #undef ALLOC
@@ -719,6 +722,7 @@ int sdr_destroy(sdr_bank *b)
     b->slots.release();
     b->morse.release();
     b->text.release();
+    b->text_frames.release();
     b->carry[0].release();
     b->carry[1].release();
     for (int s = 0; s < N_STAGES; s++)
@@ -973,8 +977,9 @@ int sdr_listener_stop(sdr_bank *b, int band, int lid)
         return rc;
     const size_t idx = (size_t)band * b->cfg.max_listeners + lid;
     HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(sdr::launch_listener_stop(b->slots.p + idx, b->morse.p, b->text.p + idx * b->text_cap, b->text_cap, b->drops.p,
-                                      b->stream[S_LISTEN]));
+    HIP_TRY(sdr::launch_listener_stop(b->slots.p + idx, b->morse.p, b->text.p + idx * b->text_cap,
+                                      b->text_frames.p + idx * b->text_cap, b->text_cap,
+                                      (uint32_t)std::max<int64_t>(b->total_frames - 1, 0), b->drops.p, b->stream[S_LISTEN]));
     return SDR_OK;
 }
 
@@ -1264,6 +1269,82 @@ int sdr_read_decoder_state(sdr_bank *b, int band, int lid, double *out12)
     return SDR_OK;
 }
 
+// ---- scope tap (scope/scope.go:14-37) -------------------------------------------------------------------------
+int sdr_scope_active(sdr_bank *b) { return b ? (b->cfg.trace ? 1 : 0) : 0; }
+
+int sdr_scope_read_spectral(sdr_bank *b, int band, int chunk, sdr_scope_spectral_frame *frame, double *values, int max_values)
+{
+    int rc = check_band(b, band);
+    if (rc)
+        return rc;
+    if (!b->cfg.trace)
+        return fail(SDR_ERR_STATE, "scope inactive: the bank was created without trace");
+    if (chunk < 0 || chunk >= b->last_chunks || !frame)
+        return fail(SDR_ERR_BAD_ARG, "chunk out of range");
+    rc = sync_bank(b);
+    if (rc)
+        return rc;
+    const sdr_config &c = b->cfg;
+    const int N = c.block_size;
+    const BatchSet &S = b->set[b->last_set];
+    const int end_frame = (SDR_CUMULATION_SIZE - b->last_count0) + chunk * SDR_CUMULATION_SIZE - 1;
+    sdr_frame_rec rec;
+    HIP_TRY(hipMemcpy(&rec, S.recs.p + (size_t)band * c.max_batch_frames + end_frame, sizeof rec, hipMemcpyDeviceToHost));
+    frame->frame = (b->total_frames - b->last_frames) + end_frame;
+    frame->from_frequency = 0.0;
+    frame->to_frequency = 1.0;
+    frame->threshold = (double)rec.peak_thr;
+    frame->n_values = N;
+    frame->reserved = 0;
+    // DecodeMode: the listener; StrainMode: the pool's first listener (rx/receiver.go:430-441); -1 without one
+    frame->signal_bin = -1.0;
+    for (int i = 0; i < b->n_slots[band]; i++) {
+        const sdr::ListenerSlot &sl = b->h_slots[(size_t)band * c.max_listeners + i];
+        if (sl.active) {
+            frame->signal_bin = (double)sl.bin;
+            break;
+        }
+    }
+    if (values) {
+        std::vector<float> cum((size_t)N);
+        HIP_TRY(hipMemcpy(cum.data(), S.cum_out.p + ((size_t)band * b->max_chunks + chunk) * N, sizeof(float) * (size_t)N,
+                          hipMemcpyDeviceToHost));
+        const double scale = 1.0 / (double)SDR_CUMULATION_SIZE;  // scaledValuesForScope(cumulation, 1.0/float64(cumulationSize))
+        for (int i = 0; i < std::min(N, max_values); i++)
+            values[i] = (double)cum[i] * scale;
+    }
+    return SDR_OK;
+}
+
+int sdr_scope_read_demod(sdr_bank *b, int band, int lid, sdr_scope_time_frame *out, int max, int *n_out)
+{
+    int rc = check_listener(b, band, lid);
+    if (rc)
+        return rc;
+    if (!b->cfg.trace)
+        return fail(SDR_ERR_STATE, "scope inactive: the bank was created without trace");
+    const int n = std::min(b->last_frames, max);
+    if (n_out)
+        *n_out = b->last_frames;
+    if (n <= 0 || !out)
+        return SDR_OK;
+    std::vector<float> v((size_t)n);
+    std::vector<uint8_t> raw((size_t)n), deb((size_t)n);
+    rc = sdr_read_trace(b, band, lid, v.data(), raw.data(), deb.data(), n);  // synchronises
+    if (rc)
+        return rc;
+    std::vector<sdr_frame_rec> recs((size_t)n);
+    HIP_TRY(hipMemcpy(recs.data(), b->set[b->last_set].recs.p + (size_t)band * b->cfg.max_batch_frames,
+                      sizeof(sdr_frame_rec) * (size_t)n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) {
+        out[i].threshold = (double)recs[i].listen_thr;
+        out[i].value = (double)v[i];
+        out[i].state = raw[i] ? 100.0 : -1.0;      // cw/spectral.go:61-64
+        out[i].debounced = deb[i] ? 80.0 : -1.0;   // cw/spectral.go:65-68
+    }
+    return SDR_OK;
+}
+
 // ---- bulk delivery -------------------------------------------------------------------------------------------
 int sdr_enable_results(sdr_bank *b, int on)
 {
@@ -1318,6 +1399,7 @@ static int deliver_block(sdr_bank *b, const unsigned char *blk, const BatchMeta 
     const sdr_edge *edges = reinterpret_cast<const sdr_edge *>(blk + lay.off_edges);
     const uint32_t *text_counts = reinterpret_cast<const uint32_t *>(blk + lay.off_text_counts);
     const uint32_t *text = reinterpret_cast<const uint32_t *>(blk + lay.off_text);
+    const uint32_t *text_frames = reinterpret_cast<const uint32_t *>(blk + lay.off_text_frames);
     // what is needed
     int64_t need_peaks = 0, need_edges = 0, need_runes = 0;
     int need_listeners = 0;
@@ -1335,7 +1417,8 @@ static int deliver_block(sdr_bank *b, const unsigned char *blk, const BatchMeta 
     const bool fits = need_chunks <= r->chunks_cap && need_peaks <= r->peaks_cap && need_listeners <= r->listeners_cap &&
                       need_edges <= r->edges_cap && need_runes <= r->runes_cap &&
                       (need_chunks == 0 || r->chunks) && (need_peaks == 0 || r->peaks) &&
-                      (need_listeners == 0 || r->listeners) && (need_edges == 0 || r->edges) && (need_runes == 0 || r->runes);
+                      (need_listeners == 0 || r->listeners) && (need_edges == 0 || r->edges) &&
+                      (need_runes == 0 || (r->runes && r->rune_frames));
     r->n_chunks = need_chunks;
     r->n_peaks = (int32_t)need_peaks;
     r->n_listeners = need_listeners;
@@ -1389,8 +1472,10 @@ static int deliver_block(sdr_bank *b, const unsigned char *blk, const BatchMeta 
             lr.n_runes = nr;
             if (ne)
                 memcpy(r->edges + ei, edges + idx * lay.edge_cap, sizeof(sdr_edge) * (size_t)ne);
-            if (nr)
+            if (nr) {
                 memcpy(r->runes + ri, text + idx * lay.text_cap, sizeof(uint32_t) * (size_t)nr);
+                memcpy(r->rune_frames + ri, text_frames + idx * lay.text_cap, sizeof(uint32_t) * (size_t)nr);
+            }
             ei += ne;
             ri += nr;
         }

@@ -69,10 +69,11 @@ struct PeakGeom {
 //   peak_counts [band][max_chunks][2] int32 (stored, found)   peaks [band][max_chunks][max_peaks] DevPeak
 //   edge_counts [band][L] uint32                              edges [band][L][edge_cap] sdr_edge
 //   text_counts [band][L] uint32                              text  [band][L][text_cap] uint32 runes
+//                                                             text_frames [band][L][text_cap] uint32
 //   drops       DropCounters of the bank as of this batch
 struct ResultsLayout {
     int max_listeners, max_chunks, max_peaks, edge_cap, text_cap;
-    size_t off_peak_counts, off_peaks, off_edge_counts, off_edges, off_text_counts, off_text, off_drops, bytes;
+    size_t off_peak_counts, off_peaks, off_edge_counts, off_edges, off_text_counts, off_text, off_text_frames, off_drops, bytes;
 };
 
 enum KernelId {
@@ -102,17 +103,17 @@ hipError_t launch_listen_gather(const float *tap, const sdr_frame_rec *recs, con
                                 float *tr_values, uint8_t *tr_raw, ListenGeom g, int n_frames, int n_slots, int n_bands,
                                 hipStream_t stream);
 hipError_t launch_listen_decode(ListenerSlot *slots, const uint16_t *morse, const uint64_t *raw_bits,
-                                uint64_t *deb_bits, uint32_t *text, sdr_edge *edges, uint32_t *edge_counts,
-                                uint8_t *tr_deb, DropCounters *drops, ListenGeom g, int n_frames, int n_bands,
-                                hipStream_t stream);
-hipError_t launch_listener_stop(ListenerSlot *slot, const uint16_t *morse, uint32_t *text, int text_cap, DropCounters *drops,
-                                hipStream_t stream);
+                                uint64_t *deb_bits, uint32_t *text, uint32_t *text_frames, sdr_edge *edges,
+                                uint32_t *edge_counts, uint8_t *tr_deb, DropCounters *drops, ListenGeom g, int n_frames,
+                                int n_bands, hipStream_t stream);
+hipError_t launch_listener_stop(ListenerSlot *slot, const uint16_t *morse, uint32_t *text, uint32_t *text_frames, int text_cap,
+                                uint32_t frame, DropCounters *drops, hipStream_t stream);
 hipError_t launch_set_debounce(ListenerSlot *slots, int n, int threshold, hipStream_t stream);
 hipError_t launch_cumulate(const float *psd, const void *db_tab, const float *carry_in, float *carry_out, float *cum_out,
                            CumGeom g, int n_slots, int n_bands, hipStream_t stream);
 hipError_t launch_spectrum_row(const float *psd_row, float *out, int n, hipStream_t stream);
 hipError_t launch_pack_listen(ListenerSlot *slots, const sdr_edge *edges, const uint32_t *edge_counts, const uint32_t *text,
-                              const DropCounters *drops, ResultsLayout lay, int n_slots, int n_bands, unsigned char *host,
+                              const uint32_t *text_frames, const DropCounters *drops, ResultsLayout lay, int n_slots, int n_bands, unsigned char *host,
                               hipStream_t stream);
 hipError_t launch_pack_peaks(const DevPeak *peaks, const int *counts, ResultsLayout lay, int find_peaks, int n_chunks,
                              int n_bands, unsigned char *host, hipStream_t stream);

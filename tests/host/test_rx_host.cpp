@@ -214,8 +214,19 @@ static void TestPeakCentering()  // rx/receiver.go:474-500 + dsp/fft_test.go:31-
 
 struct PrintReporter : rx::Reporter {
     std::vector<std::string> events;
-    void ListenerActivated(const std::string &l, int64_t f) override { events.push_back("+" + l + "@" + std::to_string(f)); }
-    void ListenerDeactivated(const std::string &l, int64_t f) override { events.push_back("-" + l + "@" + std::to_string(f)); }
+    std::vector<long long> event_frames;  // frames processed when the event was reported
+    rx::Receiver *receiver = nullptr;
+    void stamp() { event_frames.push_back(receiver ? (long long)receiver->FramesProcessed() : -1); }
+    void ListenerActivated(const std::string &l, int64_t f) override
+    {
+        events.push_back("+" + l + "@" + std::to_string(f));
+        stamp();
+    }
+    void ListenerDeactivated(const std::string &l, int64_t f) override
+    {
+        events.push_back("-" + l + "@" + std::to_string(f));
+        stamp();
+    }
     // rx/rx.go:14-16
     std::vector<std::string> callsigns;
     void CallsignDecoded(const std::string &l, const std::string &c, int64_t f, int count, int weight) override
@@ -232,7 +243,8 @@ struct PrintReporter : rx::Reporter {
     }
 };
 
-static int run_strain(const char *path, int rate, int n, int frames, int pool, bool strongest = false)
+static int run_strain(const char *path, int rate, int n, int frames, int pool, bool strongest = false, double silence = 1e9,
+                      double attachment = 1e9, int max_batch = 256)
 {
     FILE *f = fopen(path, "rb");
     if (!f)
@@ -243,14 +255,15 @@ static int run_strain(const char *path, int rate, int n, int frames, int pool, b
     fclose(f);
     PrintReporter rep;  // must outlive the receiver: Stop() reports the final deactivations
     rx::Receiver r("rx", rx::StrainMode, nullptr, pool);
+    rep.receiver = &r;
     r.AddReporter(&rep);
     r.SetCenterFrequency(7020000);
     if (strongest)
         r.SetSelectionPolicy(rx::PeaksTable::StrongestFirst);
-    r.SetSilenceTimeout(1e9);
-    r.SetAttachmentTimeout(1e9);
+    r.SetSilenceTimeout(silence);
+    r.SetAttachmentTimeout(attachment);
     r.SetEdgeWidth(70 * n / 512);
-    if (r.Start(rate, n, 256) != SDR_OK) {
+    if (r.Start(rate, n, max_batch) != SDR_OK) {
         fprintf(stderr, "Start failed: %s\n", sdr_last_error());
         return 3;
     }
@@ -273,6 +286,9 @@ static int run_strain(const char *path, int rate, int n, int frames, int pool, b
     printf("{\"frames\": %lld, \"events\": [", (long long)r.FramesProcessed());
     for (size_t i = 0; i < rep.events.size(); i++)
         printf("%s\"%s\"", i ? ", " : "", rep.events[i].c_str());
+    printf("], \"event_frames\": [");
+    for (size_t i = 0; i < rep.event_frames.size(); i++)
+        printf("%s%lld", i ? ", " : "", rep.event_frames[i]);
     printf("], \"callsigns\": [");
     for (size_t i = 0; i < rep.callsigns.size(); i++)
         printf("%s\"%s\"", i ? ", " : "", rep.callsigns[i].c_str());
@@ -290,6 +306,59 @@ static int run_strain(const char *path, int rate, int n, int frames, int pool, b
     return 0;
 }
 
+
+// DecodeMode (rx/receiver.go:272-297): SetVFOOffset forces a peak at the VFO frequency and the single listener
+// decodes it; a second SetVFOOffset moves the listener.  Prints the listener's events and text as JSON.
+static int run_decode(const char *path, int rate, int n, int frames, long long vfo_offset)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f)
+        return 2;
+    std::vector<float> iq((size_t)frames * 2 * n);
+    if (fread(iq.data(), sizeof(float), iq.size(), f) != iq.size())
+        return 2;
+    fclose(f);
+    PrintReporter rep;
+    rx::Receiver r("rx", rx::DecodeMode);
+    r.AddReporter(&rep);
+    r.SetCenterFrequency(7020000);
+    r.SetEdgeWidth(70 * n / 512);
+    if (r.Start(rate, n, 256) != SDR_OK)
+        return 3;
+    if (r.SetVFOOffset(vfo_offset) != SDR_OK)
+        return 4;
+    const int half = frames / 2;
+    auto feed = [&](int from, int to) {
+        for (int f = from; f < to; f += 200) {
+            const int m = std::min(200, to - f);
+            if (r.IQData(rate, iq.data() + (size_t)f * 2 * n, (size_t)m * 2 * n) != SDR_OK || r.Process() != SDR_OK)
+                return false;
+        }
+        return true;
+    };
+    if (!feed(0, half))
+        return 5;
+    const auto l0 = r.Listeners().First();
+    const std::string text0 = l0 ? l0->Text() : "";
+    const int bin0 = l0 ? l0->SignalBin() : -1;
+    // retune to the same offset: the pool of one is reset and a fresh listener (new decoder) takes over
+    if (r.SetVFOOffset(vfo_offset) != SDR_OK)
+        return 6;
+    if (!feed(half, frames))
+        return 7;
+    const auto l1 = r.Listeners().First();
+    printf("{\"frames\": %lld, \"bin\": %d, \"events\": [", (long long)r.FramesProcessed(), bin0);
+    for (size_t i = 0; i < rep.events.size(); i++)
+        printf("%s\"%s\"", i ? ", " : "", rep.events[i].c_str());
+    printf("], \"text0\": \"");
+    for (unsigned char c : text0)
+        printf("\\u%04x", c);
+    printf("\", \"text1\": \"");
+    for (unsigned char c : (l1 ? l1->Text() : std::string()))
+        printf("\\u%04x", c);
+    printf("\", \"peaks_found\": %d}\n", (int)r.LastPeaks().size());
+    return 0;
+}
 
 // ---- rx/text_processor_test.go ---------------------------------------------------------------
 static void TestTextWindow_Write()  // :10-69
@@ -454,7 +523,10 @@ int main(int argc, char **argv)
         return run_text();
     if (argc >= 7 && !strcmp(argv[1], "strain"))
         return run_strain(argv[2], atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]),
-                          argc >= 8 && !strcmp(argv[7], "strongest"));
+                          argc >= 8 && !strcmp(argv[7], "strongest"), argc >= 9 ? atof(argv[8]) : 1e9,
+                          argc >= 10 ? atof(argv[9]) : 1e9, argc >= 11 ? atoi(argv[10]) : 256);
+    if (argc >= 7 && !strcmp(argv[1], "decode"))
+        return run_decode(argv[2], atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoll(argv[6]));
     fprintf(stderr, "usage: %s cpu | text | strain <iq.f32> <rate> <N> <frames> <pool>\n", argv[0]);
     return 2;
 }

@@ -46,7 +46,7 @@ def test_library_loads_and_reports_abi(lib_path):
     assert ctypes.sizeof(capi.Config) == 56 and ctypes.sizeof(capi.Peak) == 40
     assert capi.FRAME_REC_DTYPE.itemsize == 40 and capi.EDGE_DTYPE.itemsize == 8
     # bulk delivery records (sdr_results and what it points to)
-    assert ctypes.sizeof(capi.Results) == 120 and capi.PEAK_DTYPE.itemsize == 40
+    assert ctypes.sizeof(capi.Results) == 128 and capi.PEAK_DTYPE.itemsize == 40
     assert capi.CHUNK_RESULT_DTYPE.itemsize == 24 and capi.LISTENER_RESULT_DTYPE.itemsize == 24
 
 

@@ -638,3 +638,41 @@ def test_drop_counters_are_exposed(capi):
     assert edges == 0 and kept <= 2048
     assert runes > 0 and kept == 2048, (runes, kept)
     bank.close()
+
+
+def test_scope_tap(capi):
+    """scope.Scope tap (scope/scope.go:14-37): the "spectrum" frame per completed cumulation (rx/receiver.go:428-457)
+    and the "demod" frames per listener per frame (cw/spectral.go:56-81) against the oracle's traces; inactive
+    (NullScope) unless the bank was created with trace."""
+    n, rate, tones, frames = 1024, 96000, 5, 230
+    iq, bins, _ = synth.make_band(frames, rate, n, tones, seed=4711)
+    edge = synth.default_edge_width(n)
+    ref = orc.Receiver(rate, n, edge)
+    quiet = capi.Bank(rate, n, edge_width=edge, max_batch_frames=256, max_listeners=tones)
+    assert not quiet.scope_active
+    quiet.process_host(iq)
+    with pytest.raises(capi.SdrError) as ei:
+        quiet.scope_spectral_frame(0, 0)
+    assert ei.value.code == capi.ERR_STATE
+    quiet.close()
+    bank = capi.Bank(rate, n, edge_width=edge, max_batch_frames=256, max_listeners=tones, trace=True)
+    assert bank.scope_active
+    for b in bins[1:]:  # pool order = attach order: the first listener's bin is the frequency marker
+        bank.attach(0, int(b))
+        ref.attach(int(b))
+    out = ref.process(iq)
+    assert bank.process_host(iq) == frames
+    for c in range(2):
+        hdr, vals = bank.scope_spectral_frame(0, c)
+        assert hdr["frame"] == 100 * (c + 1) - 1 and hdr["from_frequency"] == 0.0 and hdr["to_frequency"] == 1.0
+        assert hdr["signal_bin"] == float(bins[1]) and hdr["n_values"] == n
+        assert hdr["threshold"] == float(out["frames"]["peak_thr"][100 * (c + 1) - 1])
+        assert np.array_equal(vals, out["cumulation"][c].astype(np.float64) * (1.0 / 100.0))
+    for lid in range(tones - 1):
+        fr = bank.scope_demod_frames(0, lid)
+        assert len(fr) == frames
+        assert np.array_equal(fr["threshold"], out["frames"]["listen_thr"].astype(np.float64))
+        assert np.array_equal(fr["value"], out["values"][:, lid].astype(np.float64))
+        assert np.array_equal(fr["state"], np.where(out["raw"][:, lid] != 0, 100.0, -1.0))
+        assert np.array_equal(fr["debounced"], np.where(out["deb"][:, lid] != 0, 80.0, -1.0))
+    bank.close()

@@ -168,3 +168,119 @@ def test_strain_mode_strongest_first_many_listeners(exe, tmp_path):
         assert l["bin"] == sb and l["frequency"] == freq
         assert bytes(ord(ch) for ch in l["text"]).decode("utf-8") == ref.text(lid)
     assert len({a[1] for a in attached}) == pool  # sixteen different carriers
+
+
+def _simulate_strain(iq, rate, n, pool_size, silence, attachment, edge, center=7020000):
+    """The reference's strain loop (rx/receiver.go:353-463) frame by frame on the CPU oracle, with the stream clock
+    (frame f happens at (f + 1) * n / rate) and the deterministic FindNext (lowest new bin): time-outs are evaluated
+    after every frame's Listen, exactly where the reference evaluates them (:396-400)."""
+    from oracle import oracle as orc
+
+    ref = orc.Receiver(rate, n, edge, 15.0, 1, center_frequency=center)
+    ref.set_find_peaks(True)
+    T = float(n) / float(rate)
+    ids = [f"rx{pool_size - i}" for i in range(pool_size)]  # IDPool: Pop takes from the back
+    pool, table, events, event_frames, sessions = [], {}, [], [], []
+    for f in range(len(iq)):
+        now = float(f + 1) * T
+        res = ref.process(iq[f:f + 1])
+        detached = []
+        for l in pool:  # pool order
+            text = ref.text(l["lid"])
+            if len(text) > l["len"]:
+                l["len"] = len(text)
+                l["last_write"] = now
+            if now - l["last_attach"] > attachment or now - l["last_write"] > silence:
+                table[l["bin"]] = ("inactive", l["peak"])
+                ref.detach(l["lid"])
+                events.append(f"-{l['id']}@{l['peak'][4]}")
+                event_frames.append(f + 1)
+                detached.append(l)
+        for l in detached:  # ListenerPool.Release: swap-remove, id back on the stack
+            i = pool.index(l)
+            ids.append(l["id"])
+            if len(pool) > 1:
+                pool[i] = pool[-1]
+            pool.pop()
+            l["text"] = ref.text(l["lid"])
+            sessions.append(l)
+        if (f + 1) % 100 == 0 and len(pool) < pool_size and res["n_chunks"]:
+            for p in res["peaks"][0]:
+                sb = p[6]
+                if table.get(sb, ("none",))[0] in ("active", "inactive"):
+                    continue
+                table[sb] = ("new", p)
+            new = sorted(b for b, v in table.items() if v[0] == "new")
+            if new:
+                sb = new[0]
+                p = table[sb][1]
+                table[sb] = ("active", p)
+                l = {"id": ids.pop(), "lid": ref.attach(sb), "bin": sb, "peak": p, "last_attach": now, "last_write": now,
+                     "len": 0}
+                pool.append(l)
+                events.append(f"+{l['id']}@{p[4]}")
+                event_frames.append(f + 1)
+    for l in pool:
+        l["text"] = ref.text(l["lid"])
+    return events, event_frames, pool, sessions
+
+
+@pytest.mark.gpu
+def test_strain_mode_finite_timeouts_per_frame(exe, tmp_path):
+    """Listener time-outs fire at the frame the reference would fire them (rx/receiver.go:396-400,
+    rx/listener.go:126-136), not at the next batch boundary: attachment time-outs in the middle of long batches
+    with a full pool, silence time-outs after the signals stop, re-binding at the following cumulation boundary."""
+    from sdrainer_amd import synth
+
+    rate, n, pool, tones = 48000, 512, 2, 4
+    frames = 1900
+    iq, bins, _ = synth.make_band(frames, rate, n, tones, seed=31)
+    quiet, _, _ = synth.make_band(frames, rate, n, 0, seed=32)
+    iq[1200:] = quiet[1200:]  # every signal stops at frame 1200: silence time-outs follow
+    silence, attachment = 2.5, 6.3  # seconds = 234.4 and 590.6 frames of 10.67 ms
+    path = tmp_path / "iq.f32"
+    iq.astype(np.float32).tofile(path)
+    out = subprocess.run([exe, "strain", str(path), str(rate), str(n), str(frames), str(pool), "linear", str(silence),
+                          str(attachment), "256"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    got = json.loads(out.stdout)
+    events, event_frames, live, sessions = _simulate_strain(iq, rate, n, pool, silence, attachment, 70)
+    kinds = {e[0] for e in events}
+    assert kinds == {"+", "-"} and len([e for e in events if e[0] == "-"]) >= 3, events
+    assert got["events"] == events
+    assert got["event_frames"] == event_frames
+    assert [l["id"] for l in got["listeners"]] == [l["id"] for l in live]
+    for g, l in zip(got["listeners"], live):
+        assert g["bin"] == l["bin"] and bytes(ord(ch) for ch in g["text"]).decode("utf-8") == l["text"]
+
+
+@pytest.mark.gpu
+def test_decode_mode_vfo_listener(exe, tmp_path):
+    """DecodeMode (rx/receiver.go:272-297): SetVFOOffset forces a peak at the VFO frequency, the receiver's single
+    listener decodes it; retuning resets the pool of one and a fresh listener takes over.  No peak scan runs."""
+    from oracle import oracle as orc
+    from sdrainer_amd import synth
+
+    rate, n, frames, tones = 48000, 512, 1400, 3
+    iq, bins, _ = synth.make_band(frames, rate, n, tones, seed=9)
+    sb = int(bins[1])
+    center = 7020000
+    offset = int((sb - n // 2) * rate / n) + 20  # a frequency inside bin sb, relative to the centre
+    path = tmp_path / "iq.f32"
+    iq.astype(np.float32).tofile(path)
+    out = subprocess.run([exe, "decode", str(path), str(rate), str(n), str(frames), str(offset)], capture_output=True,
+                         text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    got = json.loads(out.stdout)
+    assert got["frames"] == frames and got["bin"] == sb and got["peaks_found"] == 0
+    half = frames // 2
+    ref = orc.Receiver(rate, n, 70, 15.0, 1, center_frequency=center)
+    a = ref.attach(sb)
+    ref.process(iq[:half])
+    ref.detach(a)
+    b = ref.attach(sb)
+    ref.process(iq[half:])
+    assert bytes(ord(ch) for ch in got["text0"]).decode("utf-8") == ref.text(a) != ""
+    assert bytes(ord(ch) for ch in got["text1"]).decode("utf-8") == ref.text(b) != ""
+    f = center + offset
+    assert got["events"] == [f"+rx1@{f}", f"-rx1@{f}", f"+rx1@{f}"]
