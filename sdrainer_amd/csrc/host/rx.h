@@ -18,7 +18,11 @@
 #include <cstdio>
 #include <functional>
 #include <memory>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/sdrainer_hip.h"
@@ -216,8 +220,24 @@ class Listener : private CallsignReporter {  // :19-148
 public:
     Listener(std::string id, const Clock *clock, Reporter *reporter)
         : id_(std::move(id)), clock_(clock), reporter_(reporter),
-          textProcessor_([clock] { return clock ? clock->Now() : 0.0; }, this)
+          textProcessor_([this] { return timeOverride_ ? overrideNow_ : (clock_ ? clock_->Now() : 0.0); }, this)
     {
+    }
+    // While the receiver feeds a segment's runes (possibly several listeners in parallel) each Write happens at
+    // the time of the rune's frame, and the reporter calls it triggers are kept until FlushEvents().
+    void BeginFeed() { deferEvents_ = true; }
+    void SetFeedTime(double t)
+    {
+        timeOverride_ = true;
+        overrideNow_ = t;
+    }
+    void EndFeed() { timeOverride_ = false; }
+    void FlushEvents()
+    {
+        deferEvents_ = false;
+        for (auto &e : deferred_)
+            e();
+        deferred_.clear();
     }
     Listener(const Listener &) = delete;
     Listener &operator=(const Listener &) = delete;
@@ -308,18 +328,33 @@ private:
     // :70-83 — the text processor's callbacks, forwarded with the listener's id and signal frequency
     void CallsignDecoded(const std::string &callsign, int count, int weight) override
     {
-        if (reporter_)
-            reporter_->CallsignDecoded(id_, callsign, peak_.signal_frequency, count, weight);
+        if (!reporter_)
+            return;
+        const int64_t f = peak_.signal_frequency;
+        if (deferEvents_)
+            deferred_.push_back([this, callsign, f, count, weight] { reporter_->CallsignDecoded(id_, callsign, f, count, weight); });
+        else
+            reporter_->CallsignDecoded(id_, callsign, f, count, weight);
     }
     void CallsignSpotted(const std::string &callsign) override
     {
-        if (reporter_)
-            reporter_->CallsignSpotted(id_, callsign, peak_.signal_frequency);
+        if (!reporter_)
+            return;
+        const int64_t f = peak_.signal_frequency;
+        if (deferEvents_)
+            deferred_.push_back([this, callsign, f] { reporter_->CallsignSpotted(id_, callsign, f); });
+        else
+            reporter_->CallsignSpotted(id_, callsign, f);
     }
     void SpotTimeout(const std::string &callsign) override
     {
-        if (reporter_)
-            reporter_->SpotTimeout(id_, callsign, peak_.signal_frequency);
+        if (!reporter_)
+            return;
+        const int64_t f = peak_.signal_frequency;
+        if (deferEvents_)
+            deferred_.push_back([this, callsign, f] { reporter_->SpotTimeout(id_, callsign, f); });
+        else
+            reporter_->SpotTimeout(id_, callsign, f);
     }
 
     std::string id_;
@@ -332,6 +367,9 @@ private:
     double lastAttach_ = 0;
     double silenceTimeout_ = kDefaultSilenceTimeout, attachmentTimeout_ = kDefaultAttachmentTimeout;
     std::string text_;
+    bool timeOverride_ = false, deferEvents_ = false;
+    double overrideNow_ = 0;
+    std::vector<std::function<void()>> deferred_;
 };
 
 class ListenerPool {  // :180-270
@@ -382,6 +420,85 @@ private:
     std::vector<std::shared_ptr<Listener>> listeners_;
     IDPool ids_;
     Factory factory_;
+};
+
+// A few long-lived worker threads for the per-listener text processing (the reference gives every
+// TextProcessor a goroutine of its own, rx/text_processor.go:161-171).  Run(n, fn) calls fn(i) for i in [0, n)
+// on the workers and the caller, and returns when all are done.
+class Workers {
+public:
+    explicit Workers(int n_threads)
+    {
+        for (int i = 0; i < n_threads; i++)
+            threads_.emplace_back([this] { loop(); });
+    }
+    ~Workers()
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : threads_)
+            t.join();
+    }
+    void Run(size_t n, const std::function<void(size_t)> &fn)
+    {
+        if (n == 0)
+            return;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            fn_ = &fn;
+            n_ = n;
+            next_ = 0;
+            done_ = 0;
+            generation_++;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> g(m_);
+        done_cv_.wait(g, [&] { return done_ == n_; });
+        fn_ = nullptr;
+    }
+
+private:
+    void work()
+    {
+        for (;;) {
+            size_t i;
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (!fn_ || next_ >= n_)
+                    return;
+                i = next_++;
+            }
+            (*fn_)(i);
+            std::lock_guard<std::mutex> g(m_);
+            if (++done_ == n_)
+                done_cv_.notify_all();
+        }
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return stop_ || generation_ != seen; });
+                if (stop_)
+                    return;
+                seen = generation_;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable cv_, done_cv_;
+    const std::function<void(size_t)> *fn_ = nullptr;
+    size_t n_ = 0, next_ = 0, done_ = 0;
+    uint64_t generation_ = 0;
+    bool stop_ = false;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -556,15 +673,15 @@ public:
         for (;;) {
             const int staged = sdr_staged_frames(bank_, 0);
             if (staged <= 0)
-                return SDR_OK;
+                return resolvePending();
             const int limit = segmentLimit(staged);
             int n = 0;
             int rc = sdr_process_staged_limit(bank_, limit, &n);
             if (rc != SDR_OK)
                 return rc;
             if (n == 0)
-                return SDR_OK;
-            rc = afterSegment(n);
+                return resolvePending();
+            rc = segmentLaunched(n);
             if (rc != SDR_OK)
                 return rc;
         }
@@ -579,12 +696,12 @@ public:
             int rc = sdr_process_device(bank_, iq_dev + (size_t)done * 2 * (size_t)blockSize_, n);
             if (rc != SDR_OK)
                 return rc;
-            rc = afterSegment(n);
+            rc = segmentLaunched(n);
             if (rc != SDR_OK)
                 return rc;
             done += n;
         }
-        return SDR_OK;
+        return resolvePending();
     }
 
     PeaksTable &Peaks() { return *peaks_; }
@@ -715,10 +832,35 @@ private:
         sdr_set_find_peaks(bank_, (hunting || (segExpiryAtEnd_ && ends_on_boundary)) ? 1 : 0);
         return limit;
     }
-    int afterSegment(int n)
+    // A segment has been enqueued.  Its results are needed before the next segment is cut only if a decision can
+    // depend on them: a free listener (discover at the boundary) or a time-out that may fire on its last frame.
+    // Otherwise - pool full, no time-out in sight: the steady state - up to two more segments are enqueued first,
+    // so the device pipeline stays full; the stale LastWrite this leaves in segmentLimit only makes the next cut
+    // earlier than necessary, never later.
+    int segmentLaunched(int n)
     {
-        const int64_t first = framesProcessed_;
         framesProcessed_ += n;
+        pending_.push_back(n);
+        const bool decide = mode_ == StrainMode && (listeners_.Available() || segExpiryAtEnd_);
+        if (decide || (int)pending_.size() >= 3)
+            return resolvePending(decide ? 0 : 1);
+        return SDR_OK;
+    }
+    int resolvePending(int keep = 0)
+    {
+        while ((int)pending_.size() > keep) {
+            int64_t ahead = 0;  // frames launched behind the segment being resolved
+            for (size_t i = 1; i < pending_.size(); i++)
+                ahead += pending_[i];
+            const int rc = afterSegment(framesProcessed_ - ahead);
+            if (rc != SDR_OK)
+                return rc;
+            pending_.erase(pending_.begin());
+        }
+        return SDR_OK;
+    }
+    int afterSegment(int64_t segment_end)  // results of the oldest unresolved segment, which ended before frame segment_end
+    {
         sdr_results r{};
         r.struct_size = sizeof r;
         r.chunks = resChunks_.data();
@@ -735,25 +877,47 @@ private:
         const int rc = sdr_poll(bank_, &r, 1);
         if (rc != SDR_OK)
             return rc;
-        (void)first;
-        // runes -> the listeners' text processors, each stamped with the time of its frame
+        // runes -> the listeners' text processors, each Write stamped with the time of its frame.  A listener's text
+        // processor is independent of every other's (in the reference each runs in a goroutine of its own,
+        // rx/text_processor.go:161-171), so listeners are fed in parallel; the reporter calls this triggers are
+        // replayed afterwards on this thread, listener by listener.
+        std::vector<std::pair<Listener *, const sdr_listener_result *>> work;
         for (int i = 0; i < r.n_listeners; i++) {
             const sdr_listener_result &lr = r.listeners[i];
-            for (auto &l : listeners_.Listeners()) {
-                if (!l->Attached() || l->DeviceID() != lr.listener)
-                    continue;
-                for (int k = 0; k < lr.n_runes; k++) {
-                    if (clock_ == &streamClock_)
-                        streamClock_.Set(frameTime(r.rune_frames[lr.first_rune + k]));
-                    l->WriteRune(r.runes[lr.first_rune + k]);
+            if (lr.n_runes == 0)
+                continue;
+            for (auto &l : listeners_.Listeners())
+                if (l->Attached() && l->DeviceID() == lr.listener) {
+                    work.emplace_back(l.get(), &lr);
+                    break;
                 }
-                break;
-            }
         }
-        streamClock_.Set(frameTime(framesProcessed_ - 1));
+        const bool stream_clock = clock_ == &streamClock_;
+        auto feed = [&](size_t w) {
+            Listener *l = work[w].first;
+            const sdr_listener_result &lr = *work[w].second;
+            l->BeginFeed();
+            for (int k = 0; k < lr.n_runes; k++) {
+                if (stream_clock)
+                    l->SetFeedTime(frameTime(r.rune_frames[lr.first_rune + k]));
+                l->WriteRune(r.runes[lr.first_rune + k]);
+            }
+            l->EndFeed();
+        };
+        if (work.size() >= 16 && r.n_runes >= 512) {
+            if (!workers_)
+                workers_.reset(new Workers((int)std::min(15u, std::max(1u, std::thread::hardware_concurrency()) - 1)));
+            workers_->Run(work.size(), feed);
+        } else {
+            for (size_t w = 0; w < work.size(); w++)
+                feed(w);
+        }
+        for (auto &w : work)
+            w.first->FlushEvents();
+        streamClock_.Set(frameTime(segment_end - 1));
         housekeeping();
         checkTimeouts();
-        if (mode_ == StrainMode && framesProcessed_ % kCumulationSize == 0 && listeners_.Available() && r.n_chunks > 0)
+        if (mode_ == StrainMode && segment_end % kCumulationSize == 0 && listeners_.Available() && r.n_chunks > 0)
             discover(r, r.n_chunks - 1);
         return SDR_OK;
     }
@@ -819,6 +983,8 @@ private:
     int64_t framesProcessed_ = 0;
     int maxBatchFrames_ = 256;
     bool segExpiryAtEnd_ = false;
+    std::vector<int> pending_;  // frames of the segments enqueued but not yet resolved (oldest first)
+    std::unique_ptr<Workers> workers_;
     double lastCleanup_ = 0;
     std::vector<Peak> lastPeaks_;
     // sdr_poll buffers

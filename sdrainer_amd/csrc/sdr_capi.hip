@@ -27,6 +27,7 @@
 #include <cstring>
 #include <deque>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/sdrainer_hip.h"
@@ -63,7 +64,12 @@ struct DevBuf {
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
         if (e != hipSuccess)
             return e;
-        return hipMemset(p, 0, count * sizeof(T));
+        e = hipMemset(p, 0, count * sizeof(T));
+        if (e != hipSuccess)
+            return e;
+        // the memset runs on the null stream, which non-blocking streams (the bank's own, the copy stream) do not
+        // wait for: finish it before anybody can write into the buffer
+        return hipStreamSynchronize(nullptr);
     }
     void release()
     {
@@ -158,7 +164,6 @@ struct sdr_bank {
     DevBuf<unsigned char> db_tab;   // gomath.h tables of the certified dB shortcut (k_cumulate)
     DevBuf<int32_t> tap_bins;       // [band][L] bin of every listener slot, -1 = free (k_fft_psd tap)
     DevBuf<float> spectrum_row;     // scratch of sdr_read_spectrum
-    DevBuf<float> iq_stage_dev;  // [band][max_batch][2N] for the host-staged path
     BatchSet set[RING];
     DevBuf<sdr::BandState> band_state;
     DevBuf<sdr::ListenerSlot> slots;  // [band][max_listeners]
@@ -191,12 +196,23 @@ struct sdr_bank {
     };
     std::deque<Parked> parked;
 
-    float *h_stage = nullptr;  // pinned [band][max_batch][2N]
+    // Host-fed input (sdr_push_iq / sdr_push_kiwi_snd -> sdr_process_staged).  Three staging sets rotate, so the
+    // caller's copy into pinned memory, the upload (its own stream) and the FFT of consecutive batches overlap:
+    // nothing on this path waits for the device unless the ring has wrapped around onto work still in flight.
+    struct Staging {
+        float *h_f32 = nullptr;        // pinned [band][max_batch][2N] float32 frames
+        uint8_t *h_raw = nullptr;      // pinned [band][max_batch][2N] big-endian int16 (KiwiSDR payloads), on demand
+        DevBuf<float> d_f32;           // [band][n][2N]: what the FFT kernel reads
+        DevBuf<uint8_t> d_raw;         // raw payload bytes, unpacked on the device (k_unpack.hip)
+        hipEvent_t uploaded = nullptr;  // the upload has left the pinned buffers (they may be overwritten)
+        hipEvent_t consumed = nullptr;  // the FFT has read d_f32 (it may be overwritten)
+    };
+    static constexpr int STAGE_RING = 3;
+    Staging stage[STAGE_RING];
+    int stage_cur = 0;  // the set sdr_push_* currently fills
+    hipStream_t copy_stream = nullptr;
     std::vector<int> staged;
-    // KiwiSDR source: raw big-endian int16 payloads staged as bytes, unpacked on the device
-    uint8_t *h_raw = nullptr;      // pinned [band][max_batch][2N * 2 bytes]
-    DevBuf<uint8_t> raw_stage_dev;  // same layout, uploaded per batch
-    std::vector<int> staged_kind;   // per band: 0 nothing staged, 1 float32 frames, 2 int16be frames
+    std::vector<int> staged_kind;  // per band: 0 nothing staged, 1 float32 frames, 2 int16be frames
 
     bool profiling = false;
     double prof_ms[sdr::K_COUNT] = {};
@@ -715,7 +731,6 @@ int sdr_destroy(sdr_bank *b)
     b->db_tab.release();
     b->tap_bins.release();
     b->spectrum_row.release();
-    b->iq_stage_dev.release();
     for (auto &S : b->set)
         S.release();
     b->band_state.release();
@@ -728,11 +743,22 @@ int sdr_destroy(sdr_bank *b)
     for (int s = 0; s < N_STAGES; s++)
         if (b->own_stream[s] && b->stream[s])
             (void)hipStreamDestroy(b->stream[s]);
-    if (b->h_stage)
-        (void)hipHostFree(b->h_stage);
-    if (b->h_raw)
-        (void)hipHostFree(b->h_raw);
-    b->raw_stage_dev.release();
+    if (b->copy_stream) {
+        (void)hipStreamSynchronize(b->copy_stream);
+        (void)hipStreamDestroy(b->copy_stream);
+    }
+    for (auto &st : b->stage) {
+        if (st.h_f32)
+            (void)hipHostFree(st.h_f32);
+        if (st.h_raw)
+            (void)hipHostFree(st.h_raw);
+        st.d_f32.release();
+        st.d_raw.release();
+        if (st.uploaded)
+            (void)hipEventDestroy(st.uploaded);
+        if (st.consumed)
+            (void)hipEventDestroy(st.consumed);
+    }
     delete b;
     return SDR_OK;
 }
@@ -750,6 +776,50 @@ int sdr_set_stream(sdr_bank *b, void *hip_stream)
     b->stream[S_FFT] = reinterpret_cast<hipStream_t>(hip_stream);
     return SDR_OK;
 }
+
+namespace {
+// the staging set the caller is filling, with its buffers in place (allocated on first use)
+// Copy into pinned staging memory.  One core moves about 12 GB/s into write-combined-free pinned pages; a large push
+// (a whole batch at once) is split over a few threads so that the copy keeps up with the PCIe upload behind it.
+static void staging_copy(void *dst, const void *src, size_t bytes)
+{
+    constexpr size_t kChunk = 8u << 20;
+    const size_t parts = std::min<size_t>(bytes / kChunk, 6);
+    if (parts < 2) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    std::vector<std::thread> th;
+    const size_t step = ((bytes / parts) + 4095) & ~(size_t)4095;
+    for (size_t i = 1; i < parts; i++) {
+        const size_t off = i * step, len = (i + 1 == parts) ? bytes - off : step;
+        th.emplace_back([=] { memcpy(static_cast<char *>(dst) + off, static_cast<const char *>(src) + off, len); });
+    }
+    memcpy(dst, src, step);
+    for (auto &t : th)
+        t.join();
+}
+
+static int staging_ready(sdr_bank *b, bool raw)
+{
+    const sdr_config &c = b->cfg;
+    sdr_bank::Staging &st = b->stage[b->stage_cur];
+    const size_t per = 2 * (size_t)c.block_size;
+    const size_t frames = (size_t)c.max_batch_frames * (size_t)c.n_bands;
+    HIP_TRY(hipSetDevice(b->device));
+    if (!b->copy_stream)
+        HIP_TRY(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
+    if (!st.uploaded) {
+        HIP_TRY(hipEventCreateWithFlags(&st.uploaded, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&st.consumed, hipEventDisableTiming));
+    }
+    if (!raw && !st.h_f32)
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&st.h_f32), sizeof(float) * per * frames, hipHostMallocDefault));
+    if (raw && !st.h_raw)
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&st.h_raw), 2 * per * frames, hipHostMallocDefault));
+    return SDR_OK;
+}
+}  // namespace
 
 int sdr_push_iq(sdr_bank *b, int band, int sample_rate, const float *iq, size_t n_floats)
 {
@@ -769,14 +839,12 @@ int sdr_push_iq(sdr_bank *b, int band, int sample_rate, const float *iq, size_t 
         return fail(SDR_ERR_WOULD_DROP, "IQ data skipped: staging queue full");
     if (b->staged[band] > 0 && b->staged_kind[band] != 1)
         return fail(SDR_ERR_STATE, "band already holds raw KiwiSDR frames in this batch");
+    rc = staging_ready(b, false);
+    if (rc)
+        return rc;
     b->staged_kind[band] = 1;
-    if (!b->h_stage) {
-        HIP_TRY(hipSetDevice(b->device));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_stage),
-                              sizeof(float) * per * (size_t)c.max_batch_frames * (size_t)c.n_bands, hipHostMallocDefault));
-    }
-    float *dst = b->h_stage + ((size_t)band * c.max_batch_frames + (size_t)b->staged[band]) * per;
-    memcpy(dst, iq, sizeof(float) * n_floats);  // copy on push: the caller may reuse its buffer (kiwi/client.go:203)
+    float *dst = b->stage[b->stage_cur].h_f32 + ((size_t)band * c.max_batch_frames + (size_t)b->staged[band]) * per;
+    staging_copy(dst, iq, sizeof(float) * n_floats);  // copy on push: the caller may reuse its buffer (kiwi/client.go:203)
     b->staged[band] += (int)nf;
     return SDR_OK;
 }
@@ -800,14 +868,12 @@ int sdr_push_kiwi_snd(sdr_bank *b, int band, int sample_rate, const uint8_t *pay
         return fail(SDR_ERR_WOULD_DROP, "IQ data skipped: staging queue full");
     if (b->staged[band] > 0 && b->staged_kind[band] != 2)
         return fail(SDR_ERR_STATE, "band already holds float32 frames in this batch");
+    rc = staging_ready(b, true);
+    if (rc)
+        return rc;
     b->staged_kind[band] = 2;
-    if (!b->h_raw) {
-        HIP_TRY(hipSetDevice(b->device));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_raw), per * (size_t)c.max_batch_frames * (size_t)c.n_bands,
-                              hipHostMallocDefault));
-    }
-    memcpy(b->h_raw + ((size_t)band * c.max_batch_frames + (size_t)b->staged[band]) * per, payload + kHeader,
-           n_bytes - kHeader);
+    staging_copy(b->stage[b->stage_cur].h_raw + ((size_t)band * c.max_batch_frames + (size_t)b->staged[band]) * per,
+                 payload + kHeader, n_bytes - kHeader);
     b->staged[band] += (int)nf;
     return SDR_OK;
 }
@@ -838,48 +904,72 @@ int sdr_process_staged_limit(sdr_bank *b, int max_frames, int *n_frames_out)
         return SDR_OK;
     HIP_TRY(hipSetDevice(b->device));
     const size_t per = 2 * (size_t)c.block_size;
-    if (!b->iq_stage_dev.p) {
-        hipError_t e = b->iq_stage_dev.alloc(per * (size_t)c.max_batch_frames * (size_t)c.n_bands);
+    const size_t F = (size_t)c.max_batch_frames;
+    sdr_bank::Staging &st = b->stage[b->stage_cur];
+    if (!st.d_f32.p) {
+        hipError_t e = st.d_f32.alloc(per * F * (size_t)c.n_bands);
         if (e != hipSuccess)
             return fail(SDR_ERR_HIP, "hipMalloc iq staging failed");
     }
+    // upload on the copy stream, once the FFT of this set's previous batch has read the device buffer
+    HIP_TRY(hipStreamWaitEvent(b->copy_stream, st.consumed, 0));
     for (int band = 0; band < c.n_bands; band++) {
-        float *dst = b->iq_stage_dev.p + (size_t)band * n * per;
+        float *dst = st.d_f32.p + (size_t)band * n * per;
         if (b->staged_kind[band] == 2) {
             // raw int16be payload: upload half the bytes, unpack in HBM (k_unpack.hip)
-            if (!b->raw_stage_dev.p) {
-                hipError_t e = b->raw_stage_dev.alloc(2 * per * (size_t)c.max_batch_frames * (size_t)c.n_bands);
+            if (!st.d_raw.p) {
+                hipError_t e = st.d_raw.alloc(2 * per * F * (size_t)c.n_bands);
                 if (e != hipSuccess)
                     return fail(SDR_ERR_HIP, "hipMalloc raw staging failed");
             }
-            uint8_t *rdst = b->raw_stage_dev.p + (size_t)band * c.max_batch_frames * per * 2;
-            HIP_TRY(hipMemcpyAsync(rdst, b->h_raw + (size_t)band * c.max_batch_frames * per * 2, 2 * per * (size_t)n,
-                                   hipMemcpyHostToDevice, b->stream[S_FFT]));
-            HIP_TRY(sdr::launch_unpack_be16(rdst, dst, per * (size_t)n, b->stream[S_FFT]));
+            uint8_t *rdst = st.d_raw.p + (size_t)band * F * per * 2;
+            HIP_TRY(hipMemcpyAsync(rdst, st.h_raw + (size_t)band * F * per * 2, 2 * per * (size_t)n, hipMemcpyHostToDevice,
+                                   b->copy_stream));
+            HIP_TRY(sdr::launch_unpack_be16(rdst, dst, per * (size_t)n, b->copy_stream));
         } else {
-            HIP_TRY(hipMemcpyAsync(dst, b->h_stage + (size_t)band * c.max_batch_frames * per, sizeof(float) * per * (size_t)n,
-                                   hipMemcpyHostToDevice, b->stream[S_FFT]));
+            HIP_TRY(hipMemcpyAsync(dst, st.h_f32 + (size_t)band * F * per, sizeof(float) * per * (size_t)n, hipMemcpyHostToDevice,
+                                   b->copy_stream));
         }
     }
-    int rc = process_device_impl(b, b->iq_stage_dev.p, n, n);
+    HIP_TRY(hipEventRecord(st.uploaded, b->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(b->stream[S_FFT], st.uploaded, 0));
+    int rc = process_device_impl(b, st.d_f32.p, n, n);
     if (rc)
         return rc;
-    // the staging buffers are reused: wait for the upload and the FFT, then keep what was not consumed
-    HIP_TRY(hipStreamSynchronize(b->stream[S_FFT]));
+    HIP_TRY(hipEventRecord(st.consumed, b->stream[S_FFT]));  // (behind the FFT launch: the only reader of d_f32)
+    // the caller goes on filling the next set; what this batch did not take moves to its front
+    const int next = (b->stage_cur + 1) % sdr_bank::STAGE_RING;
+    const int prev = b->stage_cur;
+    b->stage_cur = next;
+    bool any_left = false;
+    for (int band = 0; band < c.n_bands; band++)
+        any_left = any_left || b->staged[band] > n;
+    if (any_left) {
+        bool raw = false, f32 = false;
+        for (int band = 0; band < c.n_bands; band++)
+            if (b->staged[band] > n)
+                (b->staged_kind[band] == 2 ? raw : f32) = true;
+        if (f32 && (rc = staging_ready(b, false)))
+            return rc;
+        if (raw && (rc = staging_ready(b, true)))
+            return rc;
+    }
+    // the pinned buffers of the next set are free once ITS last upload has completed (two batches ago: a formality)
+    if (b->stage[next].uploaded)
+        HIP_TRY(hipEventSynchronize(b->stage[next].uploaded));
     for (int band = 0; band < c.n_bands; band++) {
         const int left = b->staged[band] - n;
         if (left > 0) {
-            if (b->staged_kind[band] == 2) {
-                uint8_t *base = b->h_raw + (size_t)band * c.max_batch_frames * per * 2;
-                memmove(base, base + (size_t)n * per * 2, per * 2 * (size_t)left);
-            } else {
-                float *base = b->h_stage + (size_t)band * c.max_batch_frames * per;
-                memmove(base, base + (size_t)n * per, sizeof(float) * per * (size_t)left);
-            }
+            if (b->staged_kind[band] == 2)
+                memcpy(b->stage[next].h_raw + (size_t)band * F * per * 2, b->stage[prev].h_raw + ((size_t)band * F + (size_t)n) * per * 2,
+                       per * 2 * (size_t)left);
+            else
+                memcpy(b->stage[next].h_f32 + (size_t)band * F * per, b->stage[prev].h_f32 + ((size_t)band * F + (size_t)n) * per,
+                       sizeof(float) * per * (size_t)left);
         } else {
             b->staged_kind[band] = 0;
         }
-        b->staged[band] = left;
+        b->staged[band] = std::max(left, 0);
     }
     return SDR_OK;
 }

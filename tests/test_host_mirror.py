@@ -16,7 +16,7 @@ def exe():
     from sdrainer_amd.csrc import build
     build.build()
     src = os.path.join(ROOT, "tests", "host", "test_rx_host.cpp")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-o", EXE, src, "-L" + CSRC, "-lsdrainer_hip",
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-pthread", "-o", EXE, src, "-L" + CSRC, "-lsdrainer_hip",
                            "-Wl,-rpath," + CSRC])
     return EXE
 

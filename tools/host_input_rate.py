@@ -21,11 +21,13 @@ for kind in ("float32", "kiwi"):
     if kind == "kiwi":
         per = n * 2
         q = np.clip(iq * 32767.0 * 8, -32768, 32767).astype(">i2")  # what a KiwiSDR sends: big-endian int16
-        payloads = [bytes(17) + q[f].tobytes() for f in range(frames)]
+        # (a payload may hold several frames: kiwi/kiwi.go:94-105 splits it; 256 frames per message here so that the
+        # Python call overhead does not bound the measurement)
+        payloads = [bytes(17) + q[f:f + 256].tobytes() for f in range(0, frames, 256)]
     for rep in range(3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        steps = 4
+        steps = 12
         for _ in range(steps):
             if kind == "float32":
                 assert bank.push_iq(0, rate, iq) == 0

@@ -1,0 +1,78 @@
+// Development aid: end-to-end strain mode through the C++ host mirror (rx::Receiver over the C ABI) on device-resident
+// IQ - discover -> attach -> decode -> callsign spots - timed in its two regimes: while the listener pool is still
+// filling (one listener bound per 100-frame cumulation, rx/receiver.go:409-426, so every segment is 100 frames and
+// is resolved before the next) and once it is full (segments of max_batch frames, three in flight).
+// Built as a shared library and driven by tools/strain_e2e.py, which owns the device buffer.
+#include <chrono>
+#include <cstdio>
+
+#include "../sdrainer_amd/csrc/host/rx.h"
+
+namespace {
+struct CountingReporter : rx::Reporter {
+    long activated = 0, deactivated = 0, decoded = 0, spotted = 0;
+    void ListenerActivated(const std::string &, int64_t) override { activated++; }
+    void ListenerDeactivated(const std::string &, int64_t) override { deactivated++; }
+    void CallsignDecoded(const std::string &, const std::string &, int64_t, int, int) override { decoded++; }
+    void CallsignSpotted(const std::string &, const std::string &, int64_t) override { spotted++; }
+};
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
+// iq_dev: [frames][2 n] float32 in HBM, replayed until `total_frames` frames have been processed after the pool is full.
+// out: [0] frames while hunting, [1] seconds while hunting, [2] frames with the pool full, [3] seconds with the pool
+// full, [4] listeners bound, [5] runes decoded, [6] callsigns decoded, [7] callsigns spotted
+extern "C" int strain_e2e(const float *iq_dev, int frames, int rate, int n, int pool, int max_batch, long total_frames, double *out)
+{
+    CountingReporter rep;
+    rx::Receiver r("rx", rx::StrainMode, nullptr, pool);
+    r.AddReporter(&rep);
+    r.SetCenterFrequency(14000000);
+    r.SetSelectionPolicy(rx::PeaksTable::StrongestFirst);
+    r.SetSilenceTimeout(1e9);
+    r.SetAttachmentTimeout(1e9);
+    r.SetEdgeWidth(70 * n / 512);
+    int rc = r.Start(rate, n, max_batch);
+    if (rc != SDR_OK) {
+        fprintf(stderr, "Start: %s\n", sdr_last_error());
+        return rc;
+    }
+    // phase 1: hunting.  The buffer is replayed from a cumulation-aligned offset so segments stay 100 frames.
+    double t0 = now_s();
+    long hunted = 0;
+    int pos = 0;
+    while (r.Listeners().Available() && hunted < 400L * pool) {
+        const int m = std::min(100, frames - pos);
+        rc = r.ProcessDevice(iq_dev + (size_t)pos * 2 * (size_t)n, m);
+        if (rc != SDR_OK)
+            return rc;
+        hunted += m;
+        pos = (pos + m) % frames;
+        if (frames - pos < 100)
+            pos = 0;
+    }
+    sdr_sync(r.Bank());
+    double t1 = now_s();
+    // phase 2: pool full
+    long full = 0;
+    while (full < total_frames) {
+        rc = r.ProcessDevice(iq_dev, frames);
+        if (rc != SDR_OK)
+            return rc;
+        full += frames;
+    }
+    sdr_sync(r.Bank());
+    double t2 = now_s();
+    long runes = 0;
+    for (auto &l : r.Listeners().Listeners())
+        runes += (long)l->Text().size();
+    out[0] = (double)hunted;
+    out[1] = t1 - t0;
+    out[2] = (double)full;
+    out[3] = t2 - t1;
+    out[4] = (double)r.Listeners().Listeners().size();
+    out[5] = (double)runes;
+    out[6] = (double)rep.decoded;
+    out[7] = (double)rep.spotted;
+    return SDR_OK;
+}
