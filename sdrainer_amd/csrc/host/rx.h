@@ -686,7 +686,10 @@ public:
                 return rc;
         }
     }
-    int ProcessDevice(const float *iq_dev, int n_frames)
+    // `drain` = false leaves the last segments in flight (their results arrive with a later call or Flush()): a
+    // caller that streams buffer after buffer keeps the device pipeline full across calls.
+    int Flush() { return bank_ ? resolvePending() : SDR_OK; }
+    int ProcessDevice(const float *iq_dev, int n_frames, bool drain = true)
     {
         if (!bank_)
             return SDR_OK;
@@ -701,7 +704,7 @@ public:
                 return rc;
             done += n;
         }
-        return resolvePending();
+        return drain ? resolvePending() : SDR_OK;
     }
 
     PeaksTable &Peaks() { return *peaks_; }
@@ -834,16 +837,16 @@ private:
     }
     // A segment has been enqueued.  Its results are needed before the next segment is cut only if a decision can
     // depend on them: a free listener (discover at the boundary) or a time-out that may fire on its last frame.
-    // Otherwise - pool full, no time-out in sight: the steady state - up to two more segments are enqueued first,
-    // so the device pipeline stays full; the stale LastWrite this leaves in segmentLimit only makes the next cut
-    // earlier than necessary, never later.
+    // Otherwise - pool full, no time-out in sight: the steady state - up to four more segments are enqueued first
+    // (the bank has six sets of buffers), so the device pipeline stays full; the stale LastWrite this leaves in
+    // segmentLimit only makes the next cut earlier than necessary, never later.
     int segmentLaunched(int n)
     {
         framesProcessed_ += n;
         pending_.push_back(n);
         const bool decide = mode_ == StrainMode && (listeners_.Available() || segExpiryAtEnd_);
-        if (decide || (int)pending_.size() >= 3)
-            return resolvePending(decide ? 0 : 1);
+        if (decide || (int)pending_.size() > 4)
+            return resolvePending(decide ? 0 : 4);
         return SDR_OK;
     }
     int resolvePending(int keep = 0)

@@ -90,7 +90,7 @@ int ilog2(int n)
 const char *kKernelNames[sdr::K_COUNT] = {"k_fft_psd",       "k_window_means", "k_noise_stats", "k_thresholds",
                                           "k_listen_gather", "k_cumulate",     "k_find_peaks",  "k_listen_decode"};
 
-constexpr int RING = 4;  // per-batch buffer sets in flight
+constexpr int RING = 6;  // per-batch buffer sets in flight (a batch lives about four FFT launches from its FFT to its last result)
 enum Stage { S_FFT = 0, S_NOISE, S_LISTEN, S_PEAKS, N_STAGES };  // the bank's streams
 
 // Everything one batch produces.

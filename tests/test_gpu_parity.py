@@ -581,7 +581,7 @@ def test_bulk_delivery_poll(capi):
         assert res["batch_index"] == delivered
         _check_delivery(res, out, a, e, tones, text)
         delivered += 1
-    # phase 2: seven batches without polling (ring holds four): the oldest are parked on the host, none is lost
+    # phase 2: seven batches without polling (the ring holds six): the oldest is parked on the host, none is lost
     for a, e in spans[3:10]:
         assert bank.process_host(iq[a:e]) == e - a
     assert bank.results_pending == 7

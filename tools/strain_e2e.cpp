@@ -56,11 +56,14 @@ extern "C" int strain_e2e(const float *iq_dev, int frames, int rate, int n, int 
     // phase 2: pool full
     long full = 0;
     while (full < total_frames) {
-        rc = r.ProcessDevice(iq_dev, frames);
+        rc = r.ProcessDevice(iq_dev, frames, false);  // results of the last segments arrive with the next call
         if (rc != SDR_OK)
             return rc;
         full += frames;
     }
+    rc = r.Flush();
+    if (rc != SDR_OK)
+        return rc;
     sdr_sync(r.Bank());
     double t2 = now_s();
     long runes = 0;
