@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--kernel-breakdown", action="store_true", help="print per-kernel HIP-event times to stderr")
     ap.add_argument("--serial", action="store_true",
                     help="diagnostic: run all stages on one stream (no overlap) so per-kernel times are standalone")
+    ap.add_argument("--graph", action="store_true",
+                    help="A/B: the steady state as a captured hipGraph (sdr_graph_*), one replay = sdr_graph_batches() steps; "
+                         "--steps and --warmup are rounded up to whole replays")
     ap.add_argument("--no-delivery", action="store_true",
                     help="diagnostic: leave results in HBM (no sdr_poll in the timed loop), as round 1 measured")
     return ap.parse_args()
@@ -212,6 +215,9 @@ def main():
                      max_listeners=shared.max_listeners, max_batch_frames=frames, max_peaks=1024, find_peaks=True,
                      trace=False, device_id=local_rank)
     stream = torch.cuda.current_stream()
+    if args.graph:
+        stream = torch.cuda.Stream()  # the null stream cannot be captured
+        torch.cuda.set_stream(stream)
     bank.set_stream(stream.cuda_stream)
 
     # inputs: `ring` distinct batches, layout [band][frame][N][2] float32, generated in HBM
@@ -252,6 +258,19 @@ def main():
         bank.process_device(ring[i % len(ring)].data_ptr(), frames)
         if delivery:
             take()
+
+    if args.graph:
+        K = bank.graph_batches
+        args.steps = -(-args.steps // K) * K
+        args.warmup = -(-args.warmup // K) * K
+        torch.cuda.synchronize()
+        bank.graph_capture(frames)
+
+        def step(i):  # noqa: F811  (one replay per K steps)
+            if i % K == 0:
+                bank.graph_launch([ring[(i + k) % len(ring)].data_ptr() for k in range(K)])
+            if delivery:
+                take()
 
     # run-in (untimed, not counted as warmup): the clocks ramp up from idle over the first few hundred
     # milliseconds of load; then the W warmup steps of the contract
@@ -298,6 +317,16 @@ def main():
     # dominant kernel: HIP events on the launch stream, live, same workload, after the timed region
     # (same pipelined run, continued: a run-in so the pipeline is full again, then up to 200 measured steps;
     # the first profiled steps of a drained pipeline see no co-running stages and read 10 % short)
+    if args.graph:
+        bank.sync()
+        if delivery:
+            take(wait=True)
+        bank.graph_release()  # the per-kernel events below are taken on the eager path
+
+        def step(i):  # noqa: F811
+            bank.process_device(ring[i % len(ring)].data_ptr(), frames)
+            if delivery:
+                take()
     bank.profile_enable(True)
     for i in range(min(args.steps, 20)):
         step(i)
@@ -356,6 +385,8 @@ def main():
             "samples_per_step_per_gpu": samples_per_step_rank, "input": "complex64 IQ resident in HBM",
             "sharding": f"{bands_per_gpu * world} independent bands, {bands_per_gpu} per GPU, no data-path collective",
             "clock_settle_ms": args.settle_ms,
+            "launch": (f"hipGraph: {bank.graph_batches} batches per replay (sdr_graph_launch)" if args.graph
+                       else "eager: every kernel launched per step over the bank's four streams"),
             "delivery": ("sdr_poll after every step inside the timed region: peaks, keying edges and decoded runes of "
                          "every batch copied to host buffers, drop counters asserted zero") if delivery
                         else "none (results left in HBM)",

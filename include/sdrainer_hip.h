@@ -247,6 +247,19 @@ int sdr_results_pending(sdr_bank *bank);
  * buffer was full, and keying edges beyond the edge buffer of the batches so far. */
 int sdr_read_drop_counters(sdr_bank *bank, uint64_t *runes_dropped, uint64_t *edges_dropped);
 
+/* graph mode --------------------------------------------------------------------------------- */
+/* The steady state of Receiver.run (rx/receiver.go:353-463) for sdr_graph_batches() consecutive batches of
+ * n_frames frames each - every kernel launch with its fork / join over the bank's streams - captured once as a
+ * hipGraph and replayed with a single launch.  Needs a bank on a real stream (sdr_set_stream with a non-null
+ * stream) and, once captured, all processing to go through sdr_graph_launch (sdr_process_* return SDR_ERR_STATE
+ * until sdr_graph_release).  Attaching or detaching a listener invalidates the capture (capture again).  Results are
+ * read / polled exactly as after sdr_process_device; the "last batch" of the read calls is the replay's last. */
+int sdr_graph_batches(sdr_bank *bank);
+int sdr_graph_capture(sdr_bank *bank, int n_frames);
+/* iq_dev: sdr_graph_batches() device pointers, one batch each, layout and alignment as sdr_process_device. */
+int sdr_graph_launch(sdr_bank *bank, const float *const *iq_dev);
+int sdr_graph_release(sdr_bank *bank);
+
 /* scope tap ---------------------------------------------------------------------------------- */
 /* The reference shows its inner workings through scope.Scope (scope/scope.go:33-37); NullScope is the default
  * and so is "no tap" here: the two reads below need a bank created with trace = 1 (that is scope.Active()).

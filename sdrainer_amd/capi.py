@@ -88,7 +88,7 @@ SYMBOLS = (
     "sdr_set_peak_threshold sdr_set_edge_width sdr_set_signal_debounce sdr_set_center_frequency sdr_set_find_peaks "
     "sdr_last_batch_frames sdr_total_frames sdr_last_batch_chunks sdr_read_peaks sdr_read_cumulation sdr_read_text "
     "sdr_read_edges sdr_read_keying_bits sdr_read_frame_records sdr_read_trace sdr_read_spectrum "
-    "sdr_read_decoder_state sdr_scope_active sdr_scope_read_spectral sdr_scope_read_demod sdr_enable_results sdr_poll sdr_results_pending sdr_read_drop_counters sdr_profile_enable sdr_profile_read sdr_profile_reset sdr_kernel_name sdr_audio_create "
+    "sdr_read_decoder_state sdr_graph_batches sdr_graph_capture sdr_graph_launch sdr_graph_release sdr_scope_active sdr_scope_read_spectral sdr_scope_read_demod sdr_enable_results sdr_poll sdr_results_pending sdr_read_drop_counters sdr_profile_enable sdr_profile_read sdr_profile_reset sdr_kernel_name sdr_audio_create "
     "sdr_audio_destroy sdr_audio_blocksize sdr_audio_set_scale sdr_audio_set_debounce "
     "sdr_audio_set_magnitude_threshold sdr_audio_write sdr_audio_close sdr_audio_read_text sdr_audio_read_trace"
 ).split()
@@ -153,6 +153,10 @@ def load():
     sig("sdr_read_trace", C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int)
     sig("sdr_read_spectrum", C.c_int, vp, C.c_int, C.c_int, vp, vp)
     sig("sdr_read_decoder_state", C.c_int, vp, C.c_int, C.c_int, C.POINTER(C.c_double))
+    sig("sdr_graph_batches", C.c_int, vp)
+    sig("sdr_graph_capture", C.c_int, vp, C.c_int)
+    sig("sdr_graph_launch", C.c_int, vp, C.POINTER(C.c_void_p))
+    sig("sdr_graph_release", C.c_int, vp)
     sig("sdr_scope_active", C.c_int, vp)
     sig("sdr_scope_read_spectral", C.c_int, vp, C.c_int, C.c_int, C.POINTER(ScopeSpectralFrame), C.POINTER(C.c_double), C.c_int)
     sig("sdr_scope_read_demod", C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, ip)
@@ -364,6 +368,22 @@ class Bank:
         out = np.empty(12)
         _check(self._L.sdr_read_decoder_state(self._h, band, lid, out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
+
+    # graph mode -------------------------------------------------------------------------------
+    @property
+    def graph_batches(self) -> int:
+        return self._L.sdr_graph_batches(self._h)
+
+    def graph_capture(self, n_frames: int):
+        _check(self._L.sdr_graph_capture(self._h, n_frames))
+
+    def graph_launch(self, iq_dev_ptrs):
+        arr = (C.c_void_p * len(iq_dev_ptrs))(*[C.c_void_p(int(p)) for p in iq_dev_ptrs])
+        assert len(iq_dev_ptrs) == self.graph_batches
+        _check(self._L.sdr_graph_launch(self._h, arr))
+
+    def graph_release(self):
+        _check(self._L.sdr_graph_release(self._h))
 
     # scope tap --------------------------------------------------------------------------------
     @property

@@ -227,7 +227,7 @@ __device__ __forceinline__ void store_psd(const double (&xr)[fft64::Plan<LOGN>::
 // (second launch bound = waves per SIMD the register allocation must leave room for: four, i.e. one 1024-thread
 // workgroup or two 512-thread ones per CU)
 template <int LOGN, bool MULTI>
-__global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 ? 4 : 1)) void k_fft_psd(const float *__restrict__ iq,
+__global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 ? 4 : 1)) void k_fft_psd(const float *__restrict__ iq_arg, const BatchCursor *__restrict__ cur,
                                                                   const fft64::cplx *__restrict__ tw,
                                                                   float *__restrict__ psd, int in_stride, int out_stride,
                                                                   int n_frames, int fpw, const int *__restrict__ tap_bins,
@@ -247,6 +247,7 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
     rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     SDR_STAMP(0);
+    const float *__restrict__ iq = cur ? cur->iq : iq_arg;  // graph replay: the batch's input pointer lives in device memory
     const int frame0 = MULTI ? blockIdx.x * fpw : blockIdx.x;
     const int frame_end = MULTI ? min(frame0 + fpw, n_frames) : frame0 + 1;
     const size_t in_band = (size_t)blockIdx.y * in_stride, out_band = (size_t)blockIdx.y * out_stride;
@@ -389,8 +390,8 @@ static int fft_fpw()
 }
 
 template <int LOGN>
-static hipError_t launch_fft_t(const float *iq, const fft64::cplx *tw, float *psd, int n_frames, int n_bands, int in_stride,
-                               int out_stride, FftTap tap, hipStream_t stream)
+static hipError_t launch_fft_t(const float *iq, const BatchCursor *cur, const fft64::cplx *tw, float *psd, int n_frames,
+                               int n_bands, int in_stride, int out_stride, FftTap tap, hipStream_t stream)
 {
     using PL = fft64::Plan<LOGN>;
     // the > 64 KB dynamic LDS attribute is per device: set it once on each device a bank launches on
@@ -421,23 +422,23 @@ static hipError_t launch_fft_t(const float *iq, const fft64::cplx *tw, float *ps
         fpw /= 2;
     if (fpw > 1)
         hipLaunchKernelGGL((k_fft_psd<LOGN, true>), dim3((n_frames + fpw - 1) / fpw, n_bands), dim3(PL::T), PL::LDS_BYTES, stream,
-                           iq, tw, psd, in_stride, out_stride, n_frames, fpw, tap.bins, tap.out, tap.n, tap.stride);
+                           iq, cur, tw, psd, in_stride, out_stride, n_frames, fpw, tap.bins, tap.out, tap.n, tap.stride);
     else
-        hipLaunchKernelGGL((k_fft_psd<LOGN, false>), dim3(n_frames, n_bands), dim3(PL::T), PL::LDS_BYTES, stream, iq, tw, psd,
-                           in_stride, out_stride, n_frames, 1, tap.bins, tap.out, tap.n, tap.stride);
+        hipLaunchKernelGGL((k_fft_psd<LOGN, false>), dim3(n_frames, n_bands), dim3(PL::T), PL::LDS_BYTES, stream, iq, cur, tw,
+                           psd, in_stride, out_stride, n_frames, 1, tap.bins, tap.out, tap.n, tap.stride);
     return hipGetLastError();
 }
 
-hipError_t launch_fft(int logn, const float *iq, const fft64::cplx *tw, float *psd, int n_frames, int n_bands, int in_stride,
-                      int out_stride, FftTap tap, hipStream_t stream)
+hipError_t launch_fft(int logn, const float *iq, const BatchCursor *cur, const fft64::cplx *tw, float *psd, int n_frames,
+                      int n_bands, int in_stride, int out_stride, FftTap tap, hipStream_t stream)
 {
     switch (logn) {
-    case 9: return launch_fft_t<9>(iq, tw, psd, n_frames, n_bands, in_stride, out_stride, tap, stream);
-    case 10: return launch_fft_t<10>(iq, tw, psd, n_frames, n_bands, in_stride, out_stride, tap, stream);
-    case 11: return launch_fft_t<11>(iq, tw, psd, n_frames, n_bands, in_stride, out_stride, tap, stream);
-    case 12: return launch_fft_t<12>(iq, tw, psd, n_frames, n_bands, in_stride, out_stride, tap, stream);
-    case 13: return launch_fft_t<13>(iq, tw, psd, n_frames, n_bands, in_stride, out_stride, tap, stream);
-    case 14: return launch_fft_t<14>(iq, tw, psd, n_frames, n_bands, in_stride, out_stride, tap, stream);
+    case 9: return launch_fft_t<9>(iq, cur, tw, psd, n_frames, n_bands, in_stride, out_stride, tap, stream);
+    case 10: return launch_fft_t<10>(iq, cur, tw, psd, n_frames, n_bands, in_stride, out_stride, tap, stream);
+    case 11: return launch_fft_t<11>(iq, cur, tw, psd, n_frames, n_bands, in_stride, out_stride, tap, stream);
+    case 12: return launch_fft_t<12>(iq, cur, tw, psd, n_frames, n_bands, in_stride, out_stride, tap, stream);
+    case 13: return launch_fft_t<13>(iq, cur, tw, psd, n_frames, n_bands, in_stride, out_stride, tap, stream);
+    case 14: return launch_fft_t<14>(iq, cur, tw, psd, n_frames, n_bands, in_stride, out_stride, tap, stream);
     default: return hipErrorInvalidValue;
     }
 }

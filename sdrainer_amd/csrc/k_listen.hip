@@ -93,9 +93,12 @@ __global__ __launch_bounds__(64) void k_listen_decode(ListenerSlot *__restrict__
                                                       uint64_t *__restrict__ deb_bits, uint32_t *__restrict__ text,
                                                       uint32_t *__restrict__ text_frames, sdr_edge *__restrict__ edges,
                                                       uint32_t *__restrict__ edge_counts, uint8_t *__restrict__ tr_deb,
-                                                      DropCounters *__restrict__ drops, ListenGeom g, int n_frames,
+                                                      DropCounters *__restrict__ drops,
+                                                      const BatchCursor *__restrict__ cur, ListenGeom g, int n_frames,
                                                       int n_total)
 {
+    if (cur)
+        g.frame_base = cur->frame_base;
     // the 512-entry code table is hit on every decoded character, on the serial path: keep it in LDS
     __shared__ uint16_t s_morse[cw::kMorseTableSize];
     for (int i = threadIdx.x; i < cw::kMorseTableSize; i += blockDim.x)
@@ -205,12 +208,12 @@ hipError_t launch_listen_gather(const float *tap, const sdr_frame_rec *recs, con
 
 hipError_t launch_listen_decode(ListenerSlot *slots, const uint16_t *morse, const uint64_t *raw_bits,
                                 uint64_t *deb_bits, uint32_t *text, uint32_t *text_frames, sdr_edge *edges,
-                                uint32_t *edge_counts, uint8_t *tr_deb, DropCounters *drops, ListenGeom g, int n_frames,
-                                int n_bands, hipStream_t stream)
+                                uint32_t *edge_counts, uint8_t *tr_deb, DropCounters *drops, const BatchCursor *cur, ListenGeom g,
+                                int n_frames, int n_bands, hipStream_t stream)
 {
     const int n_total = n_bands * g.max_listeners;
     hipLaunchKernelGGL(k_listen_decode, dim3((n_total + DECODE_LANES - 1) / DECODE_LANES), dim3(64), 0, stream, slots, morse, raw_bits,
-                       deb_bits, text, text_frames, edges, edge_counts, tr_deb, drops, g, n_frames, n_total);
+                       deb_bits, text, text_frames, edges, edge_counts, tr_deb, drops, cur, g, n_frames, n_total);
     return hipGetLastError();
 }
 

@@ -29,9 +29,21 @@ __device__ __forceinline__ float spectrum_value(float psd, gomath::DbTables t, d
 }
 
 __global__ __launch_bounds__(1024) void k_cumulate(const float *__restrict__ psd, const void *__restrict__ db_tab,
-                                                   const float *__restrict__ carry_in, float *__restrict__ carry_out,
-                                                   float *__restrict__ cum_out, CumGeom g, double inv_n2)
+                                                   float *__restrict__ carry0, float *__restrict__ carry1, int carry_in_arg,
+                                                   float *__restrict__ cum_out, const BatchCursor *__restrict__ cur, CumGeom g,
+                                                   double inv_n2)
 {
+    int carry_sel = carry_in_arg;
+    if (cur) {  // graph replay: this batch's cumulation phase comes from device memory; the grid covers every slot a
+        g.count0 = cur->count0;  // batch of this length can have, surplus workgroups leave
+        carry_sel = cur->carry_in;
+        const int first = SDR_CUMULATION_SIZE - g.count0;
+        const int slots = g.n_frames <= first ? 1 : 1 + (g.n_frames - first + SDR_CUMULATION_SIZE - 1) / SDR_CUMULATION_SIZE;
+        if ((int)blockIdx.y >= slots)
+            return;
+    }
+    const float *__restrict__ carry_in = carry_sel ? carry1 : carry0;
+    float *__restrict__ carry_out = carry_sel ? carry0 : carry1;
     __shared__ __attribute__((aligned(16))) unsigned char s_tab[gomath::kDbTabBytes];
     {
         const uint4 *src = static_cast<const uint4 *>(db_tab);
@@ -105,10 +117,16 @@ __global__ __launch_bounds__(256) void k_spectrum_row(const float *__restrict__ 
 // sum, and let the thread that owns a run start walk it (first maximum wins, strict `<`, :270).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_find_peaks(const float *__restrict__ cum, const sdr_frame_rec *__restrict__ recs,
-                                                    DevPeak *__restrict__ peaks, int *__restrict__ counts, PeakGeom g)
+                                                    DevPeak *__restrict__ peaks, int *__restrict__ counts,
+                                                    const BatchCursor *__restrict__ cur, PeakGeom g, int n_frames)
 {
     __shared__ int s_scan[256];
     const int chunk = blockIdx.x, band = blockIdx.y, tid = threadIdx.x;
+    if (cur) {
+        g.count0 = cur->count0;
+        if (chunk >= chunks_completed(g.count0, n_frames))
+            return;
+    }
     const int first_len = SDR_CUMULATION_SIZE - g.count0;
     const int end_frame = first_len + chunk * SDR_CUMULATION_SIZE - 1;  // frame that completes this chunk
     const float thr = recs[(size_t)band * g.stride + end_frame].peak_thr;
@@ -171,13 +189,13 @@ __global__ __launch_bounds__(256) void k_find_peaks(const float *__restrict__ cu
     }
 }
 
-hipError_t launch_cumulate(const float *psd, const void *db_tab, const float *carry_in, float *carry_out, float *cum_out,
-                           CumGeom g, int n_slots, int n_bands, hipStream_t stream)
+hipError_t launch_cumulate(const float *psd, const void *db_tab, float *carry0, float *carry1, int carry_in, float *cum_out,
+                           const BatchCursor *cur, CumGeom g, int n_slots, int n_bands, hipStream_t stream)
 {
     const int threads = g.n < 1024 ? g.n : 1024;
     const double inv_n2 = 1.0 / ((double)g.n * (double)g.n);
     hipLaunchKernelGGL(k_cumulate, dim3((g.n + threads - 1) / threads, n_slots, n_bands), dim3(threads), 0, stream, psd, db_tab,
-                       carry_in, carry_out, cum_out, g, inv_n2);
+                       carry0, carry1, carry_in, cum_out, cur, g, inv_n2);
     return hipGetLastError();
 }
 
@@ -188,12 +206,12 @@ hipError_t launch_spectrum_row(const float *psd_row, float *out, int n, hipStrea
     return hipGetLastError();
 }
 
-hipError_t launch_find_peaks(const float *cum, const sdr_frame_rec *recs, DevPeak *peaks, int *counts, PeakGeom g,
-                             int n_chunks, int n_bands, hipStream_t stream)
+hipError_t launch_find_peaks(const float *cum, const sdr_frame_rec *recs, DevPeak *peaks, int *counts, const BatchCursor *cur,
+                             PeakGeom g, int n_frames, int n_chunks, int n_bands, hipStream_t stream)
 {
     if (n_chunks == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(k_find_peaks, dim3(n_chunks, n_bands), dim3(256), 0, stream, cum, recs, peaks, counts, g);
+    hipLaunchKernelGGL(k_find_peaks, dim3(n_chunks, n_bands), dim3(256), 0, stream, cum, recs, peaks, counts, cur, g, n_frames);
     return hipGetLastError();
 }
 

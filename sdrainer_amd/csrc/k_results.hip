@@ -56,9 +56,12 @@ __global__ __launch_bounds__(64) void k_pack_listen(ListenerSlot *__restrict__ s
 
 // one workgroup per (completed cumulation, band)
 __global__ __launch_bounds__(64) void k_pack_peaks(const DevPeak *__restrict__ peaks, const int *__restrict__ counts,
-                                                   ResultsLayout lay, int find_peaks, unsigned char *__restrict__ host)
+                                                   const BatchCursor *__restrict__ cur, ResultsLayout lay, int find_peaks,
+                                                   int n_frames, unsigned char *__restrict__ host)
 {
     const int chunk = blockIdx.x, band = blockIdx.y, lane = threadIdx.x;
+    if (cur && chunk >= chunks_completed(cur->count0, n_frames))
+        return;
     const size_t cidx = (size_t)band * lay.max_chunks + chunk;
     const int n_all = find_peaks ? counts[cidx] : 0;
     const int n = min(n_all, lay.max_peaks);
@@ -83,12 +86,13 @@ hipError_t launch_pack_listen(ListenerSlot *slots, const sdr_edge *edges, const 
     return hipGetLastError();
 }
 
-hipError_t launch_pack_peaks(const DevPeak *peaks, const int *counts, ResultsLayout lay, int find_peaks, int n_chunks,
-                             int n_bands, unsigned char *host, hipStream_t stream)
+hipError_t launch_pack_peaks(const DevPeak *peaks, const int *counts, const BatchCursor *cur, ResultsLayout lay, int find_peaks,
+                             int n_frames, int n_chunks, int n_bands, unsigned char *host, hipStream_t stream)
 {
     if (n_chunks <= 0)
         return hipSuccess;
-    hipLaunchKernelGGL(k_pack_peaks, dim3(n_chunks, n_bands), dim3(64), 0, stream, peaks, counts, lay, find_peaks, host);
+    hipLaunchKernelGGL(k_pack_peaks, dim3(n_chunks, n_bands), dim3(64), 0, stream, peaks, counts, cur, lay, find_peaks, n_frames,
+                       host);
     return hipGetLastError();
 }
 

@@ -185,6 +185,13 @@ struct sdr_bank {
     int find_peaks = 1;
     bool failed = false;  // a HIP call failed in the middle of a launch sequence: device state is unknown
     DevBuf<sdr::DropCounters> drops;
+    // graph mode (sdr_graph_*): RING consecutive batches captured as one hipGraph
+    DevBuf<sdr::BatchCursor> cursors;  // [RING]
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    hipGraphNode_t graph_cursor_node = nullptr;
+    int graph_frames = 0, graph_slots = 0;
+    std::vector<hipEvent_t> graph_join;
     // bulk delivery
     bool results_on = false;
     sdr::ResultsLayout res_layout{};
@@ -316,7 +323,7 @@ size_t utf8_encode(uint32_t r, char *out)
     return 3;
 }
 
-int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_stride);
+int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_stride, int capture_k = -1);
 
 // A failure after the first launch leaves the pipeline half enqueued (some stages of this batch ran, the
 // carried state of others did not advance): no later batch can be trusted, so the bank refuses further work.
@@ -324,6 +331,8 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
 {
     if (b->failed)
         return fail(SDR_ERR_STATE, "an earlier process call failed half way; destroy the bank");
+    if (b->graph_exec)
+        return fail(SDR_ERR_STATE, "a graph is captured: process through sdr_graph_launch, or sdr_graph_release first");
     const int rc = process_device_body(b, iq_dev, n_frames, in_stride);
     if (rc == SDR_ERR_HIP)
         b->failed = true;
@@ -389,8 +398,14 @@ constexpr int kDefaultPlan[sdr::K_COUNT] = {
     /* fft */ S_FFT, /* window means */ S_NOISE, /* noise stats */ S_NOISE, /* thresholds */ S_PEAKS,
     /* gather */ S_LISTEN, /* cumulate */ S_PEAKS, /* find peaks */ S_PEAKS, /* decode */ S_LISTEN};
 
-int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_stride)
+// capture_k >= 0: the call is being recorded into a graph as its batch number capture_k (sdr_graph_capture).  Then
+// the batch uses buffer set capture_k, everything that differs from batch to batch comes from the device-side
+// cursor of that number instead of the launch parameters, grids cover the most chunks a batch of this length can
+// complete, nothing is asked of the host (no event queries, no profiling, no parking) and no host state changes.
+int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_stride, int capture_k)
 {
+    const bool cap = capture_k >= 0;
+    const sdr::BatchCursor *cur = cap ? b->cursors.p + capture_k : nullptr;
     const sdr_config &c = b->cfg;
     if (n_frames <= 0)
         return SDR_OK;
@@ -399,7 +414,7 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     HIP_TRY(hipSetDevice(b->device));
     const int B = c.n_bands, N = c.block_size, stride = c.max_batch_frames;
     const sdr::NoiseGeom ng = b->noise_geom();
-    const int si = (int)(b->batch_index % RING);
+    const int si = cap ? capture_k : (int)(b->batch_index % RING);
     BatchSet &S = b->set[si];
     int plan[sdr::K_COUNT];
     for (int k = 0; k < sdr::K_COUNT; k++)
@@ -437,13 +452,14 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     // FFT + PSD + tap, once every reader of this set (batch i - RING) is done with it (with RING sets the
     // previous user is four batches back and has almost always finished: ask the host first, a barrier packet in
     // the FFT queue costs the command processor tens of microseconds)
-    for (int k = 1; k < sdr::K_COUNT; k++)
+    // (inside a graph a set is used once per replay and replays are serialised by their stream)
+    for (int k = 1; k < sdr::K_COUNT && !cap; k++)
         if (stream_of(k) != stream_of(sdr::K_FFT) && hipEventQuery(S.done[k]) != hipSuccess)
             HIP_TRY(hipStreamWaitEvent(stream_of(sdr::K_FFT), S.done[k], 0));
     int max_slots = 0;
     for (int i = 0; i < B; i++)
         max_slots = std::max(max_slots, b->n_slots[i]);
-    if (b->results_on) {
+    if (b->results_on && !cap) {
         const int prc = park_results(b, S);
         if (prc)
             return prc;
@@ -451,7 +467,7 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     {
         ProfScope ps(b, sdr::K_FFT, stream_of(sdr::K_FFT));
         const sdr::FftTap tap{b->tap_bins.p, S.tap.p, max_slots, c.max_listeners};
-        SDR_LAUNCH(sdr::K_FFT, sdr::launch_fft(b->logn, iq_dev, b->tw.p, S.psd.p, n_frames, B, in_stride, stride, tap,
+        SDR_LAUNCH(sdr::K_FFT, sdr::launch_fft(b->logn, iq_dev, cur, b->tw.p, S.psd.p, n_frames, B, in_stride, stride, tap,
                                                stream_of(sdr::K_FFT)));
     }
     SDR_DONE(sdr::K_FFT);
@@ -502,8 +518,8 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     if (max_slots > 0) {
         ProfScope ps(b, sdr::K_LISTEN_DECODE, stream_of(sdr::K_LISTEN_DECODE));
         SDR_LAUNCH(sdr::K_LISTEN_DECODE, sdr::launch_listen_decode(b->slots.p, b->morse.p, S.raw_bits.p, S.bits.p, b->text.p,
-                                                                   b->text_frames.p, S.edges.p, S.edge_counts.p, S.tr_deb.p, b->drops.p, lg, n_frames,
-                                                                   B, stream_of(sdr::K_LISTEN_DECODE)));
+                                                                   b->text_frames.p, S.edges.p, S.edge_counts.p, S.tr_deb.p, b->drops.p, cur,
+                                                                   lg, n_frames, B, stream_of(sdr::K_LISTEN_DECODE)));
     }
     if (b->results_on) {
         // delivery of this batch's edges and runes, behind the decoder on its stream; the decoder's event is
@@ -523,13 +539,16 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         const int rem = (n_frames - first_len) % SDR_CUMULATION_SIZE;
         n_slots_c = n_chunks + (rem > 0 ? 1 : 0);
     }
+    if (cap) {  // whatever cumulationCount the replayed batch starts at
+        n_chunks = sdr::chunks_completed(SDR_CUMULATION_SIZE - 1, n_frames);
+        n_slots_c = n_chunks + 1;
+    }
     SDR_AFTER(sdr::K_CUMULATE, sdr::K_FFT);
     {
         ProfScope ps(b, sdr::K_CUMULATE, stream_of(sdr::K_CUMULATE));
         sdr::CumGeom cg{N, stride, n_frames, count0, b->max_chunks};
-        SDR_LAUNCH(sdr::K_CUMULATE, sdr::launch_cumulate(S.psd.p, b->db_tab.p, b->carry[b->carry_cur].p,
-                                                         b->carry[b->carry_cur ^ 1].p, S.cum_out.p, cg, n_slots_c, B,
-                                                         stream_of(sdr::K_CUMULATE)));
+        SDR_LAUNCH(sdr::K_CUMULATE, sdr::launch_cumulate(S.psd.p, b->db_tab.p, b->carry[0].p, b->carry[1].p, b->carry_cur,
+                                                         S.cum_out.p, cur, cg, n_slots_c, B, stream_of(sdr::K_CUMULATE)));
     }
     SDR_DONE(sdr::K_CUMULATE);
     const int new_count = (count0 + n_frames) % SDR_CUMULATION_SIZE;
@@ -538,25 +557,29 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         SDR_AFTER(sdr::K_FIND_PEAKS, sdr::K_THRESHOLDS);  // needs the completing frame's peak threshold
         ProfScope ps(b, sdr::K_FIND_PEAKS, stream_of(sdr::K_FIND_PEAKS));
         sdr::PeakGeom pg{N, stride, count0, b->max_chunks, c.max_peaks};
-        SDR_LAUNCH(sdr::K_FIND_PEAKS, sdr::launch_find_peaks(S.cum_out.p, S.recs.p, S.dev_peaks.p, S.peak_counts.p, pg, n_chunks, B,
-                                                             stream_of(sdr::K_FIND_PEAKS)));
+        SDR_LAUNCH(sdr::K_FIND_PEAKS, sdr::launch_find_peaks(S.cum_out.p, S.recs.p, S.dev_peaks.p, S.peak_counts.p, cur, pg, n_frames,
+                                                             n_chunks, B, stream_of(sdr::K_FIND_PEAKS)));
     }
     if (b->results_on) {
-        HIP_TRY(sdr::launch_pack_peaks(S.dev_peaks.p, S.peak_counts.p, b->res_layout, b->find_peaks, n_chunks, B, S.res_host,
-                                       stream_of(sdr::K_FIND_PEAKS)));
+        HIP_TRY(sdr::launch_pack_peaks(S.dev_peaks.p, S.peak_counts.p, cur, b->res_layout, b->find_peaks, n_frames, n_chunks, B,
+                                       S.res_host, stream_of(sdr::K_FIND_PEAKS)));
         HIP_TRY(hipEventRecord(S.res_peaks, stream_of(sdr::K_FIND_PEAKS)));
-        S.res_batch = b->batch_index;
-        S.res_first_frame = b->total_frames;
-        S.res_frames = n_frames;
-        S.res_chunks = n_chunks;
-        S.res_count0 = count0;
-        S.res_slots = max_slots;
+        if (!cap) {
+            S.res_batch = b->batch_index;
+            S.res_first_frame = b->total_frames;
+            S.res_frames = n_frames;
+            S.res_chunks = n_chunks;
+            S.res_count0 = count0;
+            S.res_slots = max_slots;
+        }
     }
     SDR_DONE(sdr::K_FIND_PEAKS);
 #undef SDR_AFTER
 #undef SDR_DONE
 #undef SDR_LAUNCH
 
+    if (cap)
+        return SDR_OK;
     // every launch of the batch is enqueued: commit the host's view of the carried state in one go.
     // The carry buffer flips only when this batch wrote a new partial cumulation; if the batch ended
     // exactly on a chunk boundary the next batch starts from zero (count0 == 0 ignores the carry)
@@ -570,6 +593,17 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     b->total_frames += n_frames;
     b->batch_index++;
     return SDR_OK;
+}
+
+// graph mode: the values that differ between the batches of a replay, written to the device-side cursors by the
+// graph's first node from its kernel arguments
+struct CursorBlock {
+    sdr::BatchCursor c[RING];
+};
+__global__ void k_set_cursors(sdr::BatchCursor *dst, CursorBlock v)
+{
+    if (threadIdx.x < RING)
+        dst[threadIdx.x] = v.c[threadIdx.x];
 }
 
 }  // namespace
@@ -679,6 +713,7 @@ int sdr_create(const sdr_config *cfg, sdr_bank **out)
     }
     ALLOC(b->band_state, B);
     ALLOC(b->drops, 1);
+    ALLOC(b->cursors, RING);
     ALLOC(b->spectrum_row, (size_t)N);
     ALLOC(b->tap_bins, B * std::max<size_t>(L, 1));
     {
@@ -726,8 +761,15 @@ int sdr_destroy(sdr_bank *b)
     for (int s = 0; s < N_STAGES; s++)
         (void)hipStreamSynchronize(b->stream[s]);
     resolve_profile(b);
+    if (b->graph_exec)
+        (void)hipGraphExecDestroy(b->graph_exec);
+    if (b->graph)
+        (void)hipGraphDestroy(b->graph);
+    for (auto e : b->graph_join)
+        (void)hipEventDestroy(e);
     b->tw.release();
     b->drops.release();
+    b->cursors.release();
     b->db_tab.release();
     b->tap_bins.release();
     b->spectrum_row.release();
@@ -1356,6 +1398,205 @@ int sdr_read_decoder_state(sdr_bank *b, int band, int lid, double *out12)
     out12[9] = d.offThreshold.high;
     out12[10] = d.offThreshold.last;
     out12[11] = d.offThreshold.threshold;
+    return SDR_OK;
+}
+
+// ---- graph mode ------------------------------------------------------------------------------------------------
+// RING consecutive batches - every launch of process_device_body with its fork / join over the bank's four
+// streams - recorded once as a hipGraph and replayed with one hipGraphLaunch.  What differs between batches
+// (input pointer, frame numbering, cumulation phase, carry buffer) is read by the kernels from device-side
+// cursors; the graph's first node writes them from its kernel arguments, which are the only thing a replay
+// updates (hipGraphExecKernelNodeSetParams), so no host memory is read while a replay runs.
+int sdr_graph_batches(sdr_bank *b) { return b ? RING : 0; }
+
+int sdr_graph_release(sdr_bank *b)
+{
+    if (!b)
+        return fail(SDR_ERR_BAD_ARG, "null bank");
+    int rc = sync_bank(b);
+    if (rc)
+        return rc;
+    if (b->graph_exec)
+        (void)hipGraphExecDestroy(b->graph_exec);
+    if (b->graph)
+        (void)hipGraphDestroy(b->graph);
+    b->graph_exec = nullptr;
+    b->graph = nullptr;
+    b->graph_cursor_node = nullptr;
+    return SDR_OK;
+}
+
+int sdr_graph_capture(sdr_bank *b, int n_frames)
+{
+    if (!b)
+        return fail(SDR_ERR_BAD_ARG, "null bank");
+    if (n_frames <= 0 || n_frames > b->cfg.max_batch_frames)
+        return fail(SDR_ERR_BAD_ARG, "n_frames out of range");
+    if (b->failed)
+        return fail(SDR_ERR_STATE, "an earlier process call failed half way; destroy the bank");
+    if (b->batch_index % RING != 0)
+        return fail(SDR_ERR_STATE, "capture needs the bank at a multiple of sdr_graph_batches() processed batches");
+    if (!b->own_stream[S_NOISE])
+        return fail(SDR_ERR_STATE, "graph mode needs the bank's own side streams (SDR_NO_OVERLAP is set)");
+    int rc = sdr_graph_release(b);  // (also drains the pipeline)
+    if (rc)
+        return rc;
+    if (b->results_on)
+        for (auto &S : b->set)
+            if ((rc = park_results(b, S)))
+                return rc;
+    HIP_TRY(hipSetDevice(b->device));
+    const bool was_profiling = b->profiling;
+    b->profiling = false;
+    hipStream_t s0 = b->stream[S_FFT];
+    // (legacy default stream cannot be captured: the bank must have been given a stream, sdr_set_stream)
+    hipError_t e = hipStreamBeginCapture(s0, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) {
+        b->profiling = was_profiling;
+        return fail(SDR_ERR_HIP, std::string("hipStreamBeginCapture (the bank's stream must not be the null stream): ") + hipGetErrorString(e));
+    }
+    CursorBlock zero{};
+    hipLaunchKernelGGL(k_set_cursors, dim3(1), dim3(64), 0, s0, b->cursors.p, zero);
+    int max_slots = 0;
+    for (int i = 0; i < b->cfg.n_bands; i++)
+        max_slots = std::max(max_slots, b->n_slots[i]);
+    rc = SDR_OK;
+    for (int k = 0; k < RING && rc == SDR_OK; k++)
+        rc = process_device_body(b, nullptr, n_frames, n_frames, k);
+    // join: the capture ends on the origin stream with every forked stream merged back
+    if (b->graph_join.empty())
+        for (int st = 1; st < N_STAGES; st++) {
+            hipEvent_t ev;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess)
+                b->graph_join.push_back(ev);
+        }
+    for (int st = 1; st < N_STAGES && rc == SDR_OK; st++) {
+        if (hipEventRecord(b->graph_join[st - 1], b->stream[st]) != hipSuccess ||
+            hipStreamWaitEvent(s0, b->graph_join[st - 1], 0) != hipSuccess)
+            rc = fail(SDR_ERR_HIP, "joining the captured streams failed");
+    }
+    hipGraph_t g = nullptr;
+    e = hipStreamEndCapture(s0, &g);
+    b->profiling = was_profiling;
+    if (rc != SDR_OK) {
+        if (g)
+            (void)hipGraphDestroy(g);
+        return rc;
+    }
+    if (e != hipSuccess || !g)
+        return fail(SDR_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    // the cursor node: the kernel node that runs k_set_cursors
+    size_t n_nodes = 0;
+    HIP_TRY(hipGraphGetNodes(g, nullptr, &n_nodes));
+    std::vector<hipGraphNode_t> nodes(n_nodes);
+    HIP_TRY(hipGraphGetNodes(g, nodes.data(), &n_nodes));
+    hipGraphNode_t cursor_node = nullptr;
+    for (hipGraphNode_t nd : nodes) {
+        hipGraphNodeType t;
+        if (hipGraphNodeGetType(nd, &t) != hipSuccess || t != hipGraphNodeTypeKernel)
+            continue;
+        hipKernelNodeParams kp{};
+        if (hipGraphKernelNodeGetParams(nd, &kp) == hipSuccess && kp.func == reinterpret_cast<void *>(&k_set_cursors)) {
+            cursor_node = nd;
+            break;
+        }
+    }
+    if (!cursor_node) {
+        (void)hipGraphDestroy(g);
+        return fail(SDR_ERR_HIP, "captured graph has no cursor node");
+    }
+    hipGraphExec_t ex = nullptr;
+    e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        return fail(SDR_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    }
+    b->graph = g;
+    b->graph_exec = ex;
+    b->graph_cursor_node = cursor_node;
+    b->graph_frames = n_frames;
+    b->graph_slots = max_slots;
+    return SDR_OK;
+}
+
+int sdr_graph_launch(sdr_bank *b, const float *const *iq_dev)
+{
+    if (!b || !iq_dev)
+        return fail(SDR_ERR_BAD_ARG, "null argument");
+    if (!b->graph_exec)
+        return fail(SDR_ERR_STATE, "no graph captured (sdr_graph_capture)");
+    if (b->failed)
+        return fail(SDR_ERR_STATE, "an earlier process call failed half way; destroy the bank");
+    int max_slots = 0;
+    for (int i = 0; i < b->cfg.n_bands; i++)
+        max_slots = std::max(max_slots, b->n_slots[i]);
+    if (max_slots != b->graph_slots)
+        return fail(SDR_ERR_STATE, "listeners were attached since the capture: capture again");
+    HIP_TRY(hipSetDevice(b->device));
+    const int n_frames = b->graph_frames;
+    CursorBlock blk{};
+    int count = b->cum_count, carry = b->carry_cur;
+    int64_t total = b->total_frames;
+    struct Meta {
+        int count0, chunks;
+        int64_t first_frame;
+    } meta[RING];
+    for (int k = 0; k < RING; k++) {
+        if (!iq_dev[k] || (reinterpret_cast<uintptr_t>(iq_dev[k]) & 15))
+            return fail(SDR_ERR_BAD_ARG, "every input pointer must be non-null and 16-byte aligned");
+        blk.c[k].iq = iq_dev[k];
+        blk.c[k].frame_base = (uint32_t)total;
+        blk.c[k].count0 = count;
+        blk.c[k].carry_in = carry;
+        meta[k] = {count, sdr::chunks_completed(count, n_frames), total};
+        const int new_count = (count + n_frames) % SDR_CUMULATION_SIZE;
+        if (new_count != 0)
+            carry ^= 1;
+        count = new_count;
+        total += n_frames;
+    }
+    if (b->results_on)
+        for (int k = 0; k < RING; k++) {
+            const int prc = park_results(b, b->set[k]);
+            if (prc)
+                return prc;
+        }
+    void *args[2] = {&b->cursors.p, &blk};
+    hipKernelNodeParams kp{};
+    kp.func = reinterpret_cast<void *>(&k_set_cursors);
+    kp.gridDim = dim3(1);
+    kp.blockDim = dim3(64);
+    kp.sharedMemBytes = 0;
+    kp.kernelParams = args;
+    kp.extra = nullptr;
+    hipError_t e = hipGraphExecKernelNodeSetParams(b->graph_exec, b->graph_cursor_node, &kp);
+    if (e != hipSuccess)
+        return fail(SDR_ERR_HIP, std::string("hipGraphExecKernelNodeSetParams: ") + hipGetErrorString(e));
+    e = hipGraphLaunch(b->graph_exec, b->stream[S_FFT]);
+    if (e != hipSuccess) {
+        b->failed = true;
+        return fail(SDR_ERR_HIP, std::string("hipGraphLaunch: ") + hipGetErrorString(e));
+    }
+    // the host's view of the carried state, batch by batch, as the eager path commits it
+    for (int k = 0; k < RING; k++) {
+        BatchSet &S = b->set[k];
+        if (b->results_on) {
+            S.res_batch = b->batch_index;
+            S.res_first_frame = meta[k].first_frame;
+            S.res_frames = n_frames;
+            S.res_chunks = meta[k].chunks;
+            S.res_count0 = meta[k].count0;
+            S.res_slots = max_slots;
+        }
+        b->last_set = k;
+        b->last_frames = n_frames;
+        b->last_chunks = meta[k].chunks;
+        b->last_count0 = meta[k].count0;
+        b->batch_index++;
+    }
+    b->cum_count = count;
+    b->carry_cur = carry;
+    b->total_frames = total;
     return SDR_OK;
 }
 

@@ -52,6 +52,18 @@ struct NoiseGeom {
     double inv_n2;  // 1 / N^2 (exact power of two)
 };
 
+// What changes from batch to batch and would otherwise be a launch parameter.  In graph mode (sdr_graph_*) the
+// launches of several batches are captured once and replayed, so these values live in device memory: the host
+// writes the cursors of the batches of one replay into pinned memory and the graph's first node uploads them.
+// A null cursor pointer means "use the launch parameters" (the eager path).
+struct BatchCursor {
+    const float *iq;      // this batch's input frames
+    uint32_t frame_base;  // bank frame index of its first frame
+    int32_t count0;       // cumulationCount before its first frame
+    int32_t carry_in;     // which of the two carry buffers holds the cumulation carried in (0 / 1)
+    int32_t reserved;
+};
+
 struct ListenGeom {
     int n, stride, max_listeners, text_cap, edge_cap, bit_words, trace;
     uint32_t frame_base;
@@ -89,8 +101,8 @@ struct FftTap {
     int stride;           // max_listeners
 };
 
-hipError_t launch_fft(int logn, const float *iq, const fft64::cplx *tw, float *psd, int n_frames, int n_bands, int in_stride,
-                      int out_stride, FftTap tap, hipStream_t stream);
+hipError_t launch_fft(int logn, const float *iq, const BatchCursor *cur, const fft64::cplx *tw, float *psd, int n_frames,
+                      int n_bands, int in_stride, int out_stride, FftTap tap, hipStream_t stream);
 int twiddle_count(int logn);
 void build_twiddles(int logn, const double *wre, const double *wim, fft64::cplx *out);
 hipError_t launch_window_means(const float *psd, double *win_mean, NoiseGeom g, int n_frames, int n_bands, int stride,
@@ -104,21 +116,27 @@ hipError_t launch_listen_gather(const float *tap, const sdr_frame_rec *recs, con
                                 hipStream_t stream);
 hipError_t launch_listen_decode(ListenerSlot *slots, const uint16_t *morse, const uint64_t *raw_bits,
                                 uint64_t *deb_bits, uint32_t *text, uint32_t *text_frames, sdr_edge *edges,
-                                uint32_t *edge_counts, uint8_t *tr_deb, DropCounters *drops, ListenGeom g, int n_frames,
-                                int n_bands, hipStream_t stream);
+                                uint32_t *edge_counts, uint8_t *tr_deb, DropCounters *drops, const BatchCursor *cur, ListenGeom g,
+                                int n_frames, int n_bands, hipStream_t stream);
 hipError_t launch_listener_stop(ListenerSlot *slot, const uint16_t *morse, uint32_t *text, uint32_t *text_frames, int text_cap,
                                 uint32_t frame, DropCounters *drops, hipStream_t stream);
 hipError_t launch_set_debounce(ListenerSlot *slots, int n, int threshold, hipStream_t stream);
-hipError_t launch_cumulate(const float *psd, const void *db_tab, const float *carry_in, float *carry_out, float *cum_out,
-                           CumGeom g, int n_slots, int n_bands, hipStream_t stream);
+hipError_t launch_cumulate(const float *psd, const void *db_tab, float *carry0, float *carry1, int carry_in, float *cum_out,
+                           const BatchCursor *cur, CumGeom g, int n_slots, int n_bands, hipStream_t stream);
 hipError_t launch_spectrum_row(const float *psd_row, float *out, int n, hipStream_t stream);
 hipError_t launch_pack_listen(ListenerSlot *slots, const sdr_edge *edges, const uint32_t *edge_counts, const uint32_t *text,
                               const uint32_t *text_frames, const DropCounters *drops, ResultsLayout lay, int n_slots, int n_bands, unsigned char *host,
                               hipStream_t stream);
-hipError_t launch_pack_peaks(const DevPeak *peaks, const int *counts, ResultsLayout lay, int find_peaks, int n_chunks,
-                             int n_bands, unsigned char *host, hipStream_t stream);
+hipError_t launch_pack_peaks(const DevPeak *peaks, const int *counts, const BatchCursor *cur, ResultsLayout lay, int find_peaks,
+                             int n_frames, int n_chunks, int n_bands, unsigned char *host, hipStream_t stream);
+// cumulations a batch of n_frames completes when it starts at cumulationCount count0
+__host__ __device__ inline int chunks_completed(int count0, int n_frames)
+{
+    const int first_len = SDR_CUMULATION_SIZE - count0;
+    return n_frames >= first_len ? 1 + (n_frames - first_len) / SDR_CUMULATION_SIZE : 0;
+}
 hipError_t launch_unpack_be16(const uint8_t *raw, float *out, size_t n_values, hipStream_t stream);
-hipError_t launch_find_peaks(const float *cum, const sdr_frame_rec *recs, DevPeak *peaks, int *counts, PeakGeom g,
-                             int n_chunks, int n_bands, hipStream_t stream);
+hipError_t launch_find_peaks(const float *cum, const sdr_frame_rec *recs, DevPeak *peaks, int *counts, const BatchCursor *cur,
+                             PeakGeom g, int n_frames, int n_chunks, int n_bands, hipStream_t stream);
 
 }  // namespace sdr

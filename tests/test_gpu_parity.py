@@ -676,3 +676,57 @@ def test_scope_tap(capi):
         assert np.array_equal(fr["state"], np.where(out["raw"][:, lid] != 0, 100.0, -1.0))
         assert np.array_equal(fr["debounced"], np.where(out["deb"][:, lid] != 0, 80.0, -1.0))
     bank.close()
+
+
+def test_graph_mode_bit_exact(capi):
+    """sdr_graph_*: the steady state captured as one hipGraph (BASELINE config 5's "hipGraph-captured steady
+    state").  Two replays of sdr_graph_batches() batches each - batch length 130, so the cumulation phase, the
+    carry buffer and the frame numbering differ from batch to batch and from replay to replay, all of it read from
+    the device-side cursors - must deliver exactly what the oracle computes for the whole stream."""
+    import torch
+
+    n, rate, tones, per = 1024, 96000, 5, 130
+    edge = synth.default_edge_width(n)
+    bank = capi.Bank(rate, n, edge_width=edge, max_batch_frames=per, max_listeners=tones, max_peaks=128)
+    K = bank.graph_batches
+    frames = 2 * K * per
+    iq, bins, _ = synth.make_band(frames, rate, n, tones, seed=808)
+    ref = orc.Receiver(rate, n, edge, 15.0, 1, center_frequency=10100000)
+    bank.set_center_frequency(0, 10100000)
+    stream = torch.cuda.Stream()
+    bank.set_stream(stream.cuda_stream)
+    for b in bins:
+        assert bank.attach(0, int(b)) == ref.attach(int(b))
+    out = ref.process(iq)
+    bank.enable_results(True)
+    with pytest.raises(capi.SdrError):  # nothing captured yet
+        bank.graph_launch([0] * K)
+    bank.graph_capture(per)
+    dev = torch.from_numpy(iq).cuda()
+    torch.cuda.synchronize()
+    text = ["" for _ in range(tones)]
+    delivered = 0
+    for rep in range(2):
+        ptrs = [dev[(rep * K + k) * per].data_ptr() for k in range(K)]
+        bank.graph_launch(ptrs)
+        with pytest.raises(capi.SdrError) as ei:  # eager calls are refused while a graph is captured
+            bank.process_device(ptrs[0], per)
+        assert ei.value.code == capi.ERR_STATE
+        for k in range(K):
+            res = bank.poll(wait=True)
+            a = (rep * K + k) * per
+            assert res["batch_index"] == delivered
+            _check_delivery(res, out, a, a + per, tones, text)
+            delivered += 1
+    bank.sync()
+    assert bank.total_frames == frames and bank.last_batch_frames == per
+    _assert_records_equal(bank.read_frame_records(0), out["frames"][frames - per:])
+    for lid in range(tones):
+        assert text[lid] == ref.text(lid) and len(text[lid]) > 0
+        assert np.array_equal(bank.read_keying_bits(0, lid), out["deb"][frames - per:, lid])
+        assert np.array_equal(bank.read_decoder_state(0, lid), ref.decoder_state(lid))
+    # back to eager processing after the release
+    bank.graph_release()
+    bank.process_device(dev[0].data_ptr(), per)
+    bank.sync()
+    bank.close()
