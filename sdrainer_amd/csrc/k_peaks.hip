@@ -20,15 +20,30 @@ namespace sdr {
 // Slot 0 continues the cumulation carried over from the previous batch; a slot that reaches 100
 // frames is written out for the peak scan, an incomplete last slot becomes the next carry.
 // ---------------------------------------------------------------------------------------------
+// the literal Go algorithm, out of line: it is rare, and inlined its float64 temporaries set the kernel's register count
+__device__ __attribute__((noinline)) float db_slow(float psd, double inv_n2) { return gomath::psd_value_in_db(psd, inv_n2); }
+
 __device__ __forceinline__ float spectrum_value(float psd, gomath::DbTables t, double inv_n2)
 {
     float db;
     if (!gomath::psd_value_in_db_fast(psd, t, &db))
-        db = gomath::psd_value_in_db(psd, inv_n2);
+        db = db_slow(psd, inv_n2);
     return db + (float)SDR_DBM_SHIFT;
 }
 
-__global__ __launch_bounds__(1024) void k_cumulate(const float *__restrict__ psd, const void *__restrict__ db_tab,
+// 256-thread workgroups, 20 KB of LDS (the tables), at most 64 VGPRs: eight waves per SIMD.  (A 32-VGPR build -
+// what a CU has left beside a resident k_fft_psd workgroup, so that the two could share a CU - measured the same
+// step, so the registers go to a software pipeline instead.)
+#if !defined(SDR_CUM_THREADS)
+#define SDR_CUM_THREADS 256
+#endif
+#if !defined(SDR_CUM_U)
+#define SDR_CUM_U 4
+#endif
+#if !defined(SDR_CUM_VGPR)
+#define SDR_CUM_VGPR 32
+#endif
+__global__ __launch_bounds__(SDR_CUM_THREADS) __attribute__((amdgpu_num_vgpr(SDR_CUM_VGPR))) void k_cumulate(const float *__restrict__ psd, const void *__restrict__ db_tab,
                                                    float *__restrict__ carry0, float *__restrict__ carry1, int carry_in_arg,
                                                    float *__restrict__ cum_out, const BatchCursor *__restrict__ cur, CumGeom g,
                                                    double inv_n2)
@@ -65,16 +80,33 @@ __global__ __launch_bounds__(1024) void k_cumulate(const float *__restrict__ psd
     float acc = 0.f;
     if (slot == 0 && g.count0 > 0)
         acc = carry_in[(size_t)band * g.n + bin];
-    const float *col = psd + (size_t)band * g.stride * g.n + bin;
-    constexpr int U = 10;  // loads in flight, and independent dB evaluations between two ordered adds
+    // (wave-uniform base in SGPRs + one 32-bit per-lane offset)
+    const float *__restrict__ base = psd + (size_t)band * g.stride * g.n;
+    const unsigned n = (unsigned)g.n;
+    unsigned off = (unsigned)begin * n + (unsigned)bin;
+    constexpr int U = SDR_CUM_U;  // loads in flight, and independent dB evaluations between two ordered adds
     int f = begin;
-    for (; f + U <= end; f += U) {
-        float v[U], db[U];
+    // software pipeline: the next U values are on their way while these U are projected and added
+    float v[U], nv[U];
+    const bool any = f + U <= end;
+    if (any) {
 #pragma unroll
         for (int k = 0; k < U; k++)
-            v[k] = __builtin_nontemporal_load(col + (size_t)(f + k) * g.n);
-        // the shortcut for all of them, straight-line (ten independent float64 chains keep the pipe full); the
-        // literal algorithm only where the certificate failed - about one iteration in a hundred has such a lane
+            nv[k] = __builtin_nontemporal_load(base + (off + (unsigned)k * n));
+    }
+    for (; f + U <= end; f += U) {
+#pragma unroll
+        for (int k = 0; k < U; k++)
+            v[k] = nv[k];
+        off += U * n;
+        if (f + 2 * U <= end) {
+#pragma unroll
+            for (int k = 0; k < U; k++)
+                nv[k] = __builtin_nontemporal_load(base + (off + (unsigned)k * n));
+        }
+        float db[U];
+        // the shortcut for all of them, straight-line (independent float64 chains); the literal algorithm only
+        // where the certificate failed - about one iteration in a few hundred has such a lane
         bool bad = false;
 #pragma unroll
         for (int k = 0; k < U; k++)
@@ -84,15 +116,15 @@ __global__ __launch_bounds__(1024) void k_cumulate(const float *__restrict__ psd
             for (int k = 0; k < U; k++) {
                 float t;
                 if (!gomath::psd_value_in_db_fast(v[k], tab, &t))
-                    db[k] = gomath::psd_value_in_db(v[k], inv_n2);
+                    db[k] = db_slow(v[k], inv_n2);
             }
         }
 #pragma unroll
         for (int k = 0; k < U; k++)
             acc += db[k] + (float)SDR_DBM_SHIFT;  // MagnitudeIndB + dBmShift (float32 add), then the ordered sum
     }
-    for (; f < end; f++)
-        acc += spectrum_value(__builtin_nontemporal_load(col + (size_t)f * g.n), tab, inv_n2);
+    for (; f < end; f++, off += n)
+        acc += spectrum_value(__builtin_nontemporal_load(base + off), tab, inv_n2);
     const bool complete = (begin + len) <= g.n_frames;
     if (complete) {
         // completed chunk index == slot (slot 0 completes first if it completes at all)
@@ -192,7 +224,7 @@ __global__ __launch_bounds__(256) void k_find_peaks(const float *__restrict__ cu
 hipError_t launch_cumulate(const float *psd, const void *db_tab, float *carry0, float *carry1, int carry_in, float *cum_out,
                            const BatchCursor *cur, CumGeom g, int n_slots, int n_bands, hipStream_t stream)
 {
-    const int threads = g.n < 1024 ? g.n : 1024;
+    const int threads = g.n < SDR_CUM_THREADS ? g.n : SDR_CUM_THREADS;
     const double inv_n2 = 1.0 / ((double)g.n * (double)g.n);
     hipLaunchKernelGGL(k_cumulate, dim3((g.n + threads - 1) / threads, n_slots, n_bands), dim3(threads), 0, stream, psd, db_tab,
                        carry0, carry1, carry_in, cum_out, cur, g, inv_n2);
