@@ -82,6 +82,17 @@ constexpr bool later_lds_exchange(int e)
 
 // `lds_free()` is called once, when the frame's last exchange through LDS is over (a following frame's
 // input may be staged into the exchange area from then on).
+// is the frame's last exchange through LDS the barrier-fenced cross-wave one?
+template <int LOGN>
+constexpr bool last_lds_exchange_is_cross()
+{
+    int last = -1;
+    for (int e = 0; e < fft64::Plan<LOGN>::NPASS - 1; e++)
+        if (!fft64::make_swap_plan<LOGN>(e).ok)
+            last = e;
+    return last >= 0 && fft64::Plan<LOGN>::cross_wave(last);
+}
+
 template <int LOGN, int P, bool FRAME_FOLLOWS, class LdsFree>
 __device__ __forceinline__ void run_passes(double (&xr)[fft64::Plan<LOGN>::R], double (&xi)[fft64::Plan<LOGN>::R],
                                            int t, rsrc_t tw, const fft64::cplx *__restrict__ tw_ptr, double *lds,
@@ -174,9 +185,10 @@ __device__ __forceinline__ void run_passes(double (&xr)[fft64::Plan<LOGN>::R], d
 
 // Epilogue (dsp/fft.go:54-57 fftshift, :71-73 PSD[float32]): psd[k] = float32(re^2 + im^2), two multiplies and an
 // add in float64, no FMA, rounded once.
-template <int LOGN>
+// LDS_COPY: the row also goes to LDS (float32 at byte 4 k), where the one-frame workgroup's tap picks its bins up.
+template <int LOGN, bool LDS_COPY>
 __device__ __forceinline__ void store_psd(const double (&xr)[fft64::Plan<LOGN>::R], const double (&xi)[fft64::Plan<LOGN>::R],
-                                          int t, float *__restrict__ pd)
+                                          int t, float *__restrict__ pd, unsigned char *lds_row, bool lds_copy)
 {
     using PL = fft64::Plan<LOGN>;
     const int tp = fft64::thread_part<LOGN, PL::NPASS - 1>(t);
@@ -196,6 +208,9 @@ __device__ __forceinline__ void store_psd(const double (&xr)[fft64::Plan<LOGN>::
 #else
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(p), pdr, tk * 4u, sk * 4, SDR_FFT_PSD_AUX);
 #endif
+        if constexpr (LDS_COPY)
+            if (lds_copy)  // (uniform) per-thread address once, the slot part in the instruction's offset field
+                *reinterpret_cast<float *>(lds_row + tk * 4u + (unsigned)(sk * 4)) = p;
     }
 }
 
@@ -220,10 +235,14 @@ __device__ __forceinline__ void store_psd(const double (&xr)[fft64::Plan<LOGN>::
 // workgroup taps frame f-1 near the end of frame f: by then every wave has waited for twiddles it loaded during
 // frame f - younger than its stores of frame f-1, and vector-memory operations retire in order - and has passed
 // the barriers of the cross-wave exchange since, so all of frame f-1's stores are complete; the tap then costs
-// two instructions per listener and no drain.  The workgroup's last frame is tapped after a final drain.
+// two instructions per listener and no drain; its last frame is tapped after a final drain.  A one-frame workgroup
+// (the default) would pay that drain - a microsecond of store latency with the whole CU held - on every frame, so
+// its epilogue also writes the psd row into LDS (the exchange area is free by then; LDS stores cost no vector ALU
+// time) and the tap reads its bins from there behind one barrier: no wait on memory at all.
 #if !defined(SDR_FFT_DMA_AT)
 #define SDR_FFT_DMA_AT 1
 #endif
+constexpr int kMaxLdsTap = 4096;  // listeners per band the LDS tap holds bins for (16 KB); more fall back to the drain
 // (second launch bound = waves per SIMD the register allocation must leave room for: four, i.e. one 1024-thread
 // workgroup or two 512-thread ones per CU)
 template <int LOGN, bool MULTI>
@@ -284,6 +303,12 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
         }
     };
     stage_frame(frame0, threadIdx.x);
+    // one-frame workgroup: its listeners' bins into LDS (behind the exchange area) while the frame is on its way
+    int *lds_bins = reinterpret_cast<int *>(smem + PL::LDS_BYTES);
+    const bool lds_tap = !MULTI && n_tap > 0 && n_tap <= kMaxLdsTap;
+    if (lds_tap)
+        for (int l = threadIdx.x; l < n_tap; l += PL::T)
+            lds_bins[l] = tap_bins[(size_t)blockIdx.y * tap_stride + l];
 
 #pragma nounroll
     for (int frame = frame0; frame < frame_end; frame++) {
@@ -329,7 +354,9 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
         const bool more = MULTI && frame + 1 < frame_end;
         // (no scheduling pin around the DMA: the compiler keeps it behind the exchanges' LDS accesses and behind the
         // twiddle loads already issued, which it waits for with counted vmcnt; a "memory" pin cost 46 spills)
-        run_passes<LOGN, 0, MULTI>(xr, xi, t, make_rsrc(tw, (unsigned)(PL::TW_TOTAL * sizeof(fft64::cplx))), tw, lds, [&] {
+        // (LDS is written again after the last exchange in both variants - the next frame's staging or the tap's
+        // copy of the psd row - so the exchange ends with its fence: a barrier when it crossed waves)
+        run_passes<LOGN, 0, true>(xr, xi, t, make_rsrc(tw, (unsigned)(PL::TW_TOTAL * sizeof(fft64::cplx))), tw, lds, [&] {
             if constexpr (MULTI && SDR_FFT_DMA_AT == 0)
                 if (more)
                     stage_frame(frame + 1, t);
@@ -337,7 +364,10 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
         if constexpr (MULTI && SDR_FFT_DMA_AT == 1)
             if (more)
                 stage_frame(frame + 1, t);
-        store_psd<LOGN>(xr, xi, t, psd + (out_band + frame) * PL::N);
+        if constexpr (!MULTI && !last_lds_exchange_is_cross<LOGN>())
+            if (lds_tap)
+                __syncthreads();  // a wave-local last exchange fences only its own wave; the row goes everywhere
+        store_psd<LOGN, !MULTI>(xr, xi, t, psd + (out_band + frame) * PL::N, smem, lds_tap);
         // (behind the DMA and the stores, so that its two dependent loads delay neither: the oldest waves - the
         // ones that tap - reach the end of a frame microseconds before the youngest)
         if constexpr (MULTI) {
@@ -347,7 +377,15 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
         }
         SDR_STAMP(10);
     }
-    if (n_tap > 0 && frame_end > frame0) {
+    if (lds_tap) {
+        __syncthreads();  // the row is in LDS (and lds_bins has been for a long time)
+        const float *row = reinterpret_cast<const float *>(smem);
+        float *out = tap_out + (out_band + frame0) * (size_t)tap_stride;
+        for (int l = threadIdx.x; l < n_tap; l += PL::T) {
+            const int bin = lds_bins[l];
+            out[l] = bin >= 0 ? row[bin] : 0.0f;
+        }
+    } else if (n_tap > 0 && frame_end > frame0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         tap_frame(frame_end - 1);
@@ -377,6 +415,7 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
 }
 
 // Tuning knob, read once per process: SDR_FFT_FPW = frames per workgroup.
+// (LDS behind the exchange area: the one-frame workgroup's copy of its listeners' bins)
 constexpr int kDefaultFpw = 1;  // in the pipeline short-lived workgroups win: 0.250 (1) / 0.253 (2) / 0.291 (4) / 0.294 ms (8) per step, standalone the other way round (0.174 / 0.166 / 0.165 / 0.164 ms)
 constexpr int kMaxDevices = 64;
 static int fft_fpw()
@@ -406,7 +445,7 @@ static hipError_t launch_fft_t(const float *iq, const BatchCursor *cur, const ff
     std::call_once(attr_once[dev], [&] {
         for (const void *k : {reinterpret_cast<const void *>(&k_fft_psd<LOGN, false>),
                               reinterpret_cast<const void *>(&k_fft_psd<LOGN, true>)}) {
-            const hipError_t ae = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, PL::LDS_BYTES);
+            const hipError_t ae = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, PL::LDS_BYTES + kMaxLdsTap * 4);
             if (ae != hipSuccess)
                 attr_err = ae;
         }
@@ -424,8 +463,9 @@ static hipError_t launch_fft_t(const float *iq, const BatchCursor *cur, const ff
         hipLaunchKernelGGL((k_fft_psd<LOGN, true>), dim3((n_frames + fpw - 1) / fpw, n_bands), dim3(PL::T), PL::LDS_BYTES, stream,
                            iq, cur, tw, psd, in_stride, out_stride, n_frames, fpw, tap.bins, tap.out, tap.n, tap.stride);
     else
-        hipLaunchKernelGGL((k_fft_psd<LOGN, false>), dim3(n_frames, n_bands), dim3(PL::T), PL::LDS_BYTES, stream, iq, cur, tw,
-                           psd, in_stride, out_stride, n_frames, 1, tap.bins, tap.out, tap.n, tap.stride);
+        hipLaunchKernelGGL((k_fft_psd<LOGN, false>), dim3(n_frames, n_bands), dim3(PL::T),
+                           PL::LDS_BYTES + (tap.n > 0 && tap.n <= kMaxLdsTap ? tap.n * 4 : 0), stream, iq, cur, tw, psd, in_stride,
+                           out_stride, n_frames, 1, tap.bins, tap.out, tap.n, tap.stride);
     return hipGetLastError();
 }
 

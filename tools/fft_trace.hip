@@ -61,7 +61,7 @@ int main(int argc, char **argv)
     float best = 1e9f;
     for (int rep = 0; rep < 8; rep++) {
         hipEventRecord(e0, 0);
-        sdr::launch_fft(logn, iq, tw, pd, frames, 1, frames, frames, tap, 0);
+        sdr::launch_fft(logn, iq, nullptr, tw, pd, frames, 1, frames, frames, tap, 0);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms;
@@ -76,7 +76,7 @@ int main(int argc, char **argv)
     {
         // 2 s of back-to-back launches, then the shader clock over one workgroup's lifetime
         for (int rep = 0; rep < 8000; rep++)
-            sdr::launch_fft(logn, iq, tw, pd, frames, 1, frames, frames, tap, 0);
+            sdr::launch_fft(logn, iq, nullptr, tw, pd, frames, 1, frames, frames, tap, 0);
         hipDeviceSynchronize();
         unsigned long long ck[2];
         hipMemcpyFromSymbol(ck, HIP_SYMBOL(sdr::g_fft_clock), sizeof ck);
@@ -86,7 +86,7 @@ int main(int argc, char **argv)
         static unsigned long long wg[2048][4];
         memset(wg, 0, sizeof wg);
         hipMemcpyToSymbol(HIP_SYMBOL(sdr::g_fft_wg), wg, sizeof wg);
-        sdr::launch_fft(logn, iq, tw, pd, frames, 1, frames, frames, tap, 0);
+        sdr::launch_fft(logn, iq, nullptr, tw, pd, frames, 1, frames, frames, tap, 0);
         hipDeviceSynchronize();
         hipMemcpyFromSymbol(wg, HIP_SYMBOL(sdr::g_fft_wg), sizeof wg);
         const int fpw = getenv("SDR_FFT_FPW") ? atoi(getenv("SDR_FFT_FPW")) : 1;
@@ -149,7 +149,7 @@ int main(int argc, char **argv)
         if (ns == 2)
             hipStreamWaitEvent(st[1], e0, 0);
         for (int rep = 0; rep < reps; rep++)
-            sdr::launch_fft(logn, iq, tw, pd, frames, 1, frames, frames, tap, st[rep % ns]);
+            sdr::launch_fft(logn, iq, nullptr, tw, pd, frames, 1, frames, frames, tap, st[rep % ns]);
         hipEvent_t ej;
         hipEventCreate(&ej);
         if (ns == 2) {
