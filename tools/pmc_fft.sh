@@ -4,7 +4,7 @@
 # Output: gpurun_out/pmc_fft.txt (per-dispatch averages over the kernel's launches).
 cd /tmp && export TMPDIR=/tmp
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-export SDR_TOOL_SHORT=1 SDR_FFT_FPW=${SDR_FFT_FPW:-8} SDR_TAP=256
+export SDR_TOOL_SHORT=1 SDR_FFT_FPW=${SDR_FFT_FPW:-1} SDR_TAP=256
 rm -rf gpurun_out/pmc_fft
 i=0
 for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
