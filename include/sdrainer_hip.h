@@ -40,7 +40,9 @@
  * frames per band, in order.
  *
  * Threading: a bank is single-producer (like the reference's run goroutine, all DSP state is owned
- * by one thread); different banks are independent.
+ * by one thread); different banks are independent.  One more thread may consume: sdr_poll and
+ * sdr_results_pending may be called from a thread of their own while the producer thread processes (the
+ * reference's Reporter callbacks arrive on other goroutines too).
  */
 #ifndef SDRAINER_HIP_H
 #define SDRAINER_HIP_H

@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -202,6 +203,11 @@ struct sdr_bank {
         std::vector<unsigned char> block;
     };
     std::deque<Parked> parked;
+    // sdr_poll may run on a consumer thread of its own beside the producer's process calls (the reference's
+    // Reporter is called from other goroutines too): the delivery bookkeeping - parked, deliver_next, the sets'
+    // res_* fields, batch_index as sdr_poll reads it - is guarded by this mutex.
+    std::mutex res_mu;
+    int64_t batches_enqueued = 0;  // == batch_index, published under res_mu
 
     // Host-fed input (sdr_push_iq / sdr_push_kiwi_snd -> sdr_process_staged).  Three staging sets rotate, so the
     // caller's copy into pinned memory, the upload (its own stream) and the FFT of consecutive batches overlap:
@@ -372,6 +378,7 @@ sdr::ResultsLayout make_results_layout(const sdr_bank *b)
 // the host (the reference's io.Writer never drops).  Only the used parts of the block are copied.
 int park_results(sdr_bank *b, BatchSet &S)
 {
+    std::lock_guard<std::mutex> guard(b->res_mu);
     if (S.res_batch < 0)
         return SDR_OK;
     HIP_TRY(hipEventSynchronize(S.res_listen));
@@ -565,12 +572,14 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
                                        S.res_host, stream_of(sdr::K_FIND_PEAKS)));
         HIP_TRY(hipEventRecord(S.res_peaks, stream_of(sdr::K_FIND_PEAKS)));
         if (!cap) {
+            std::lock_guard<std::mutex> guard(b->res_mu);
             S.res_batch = b->batch_index;
             S.res_first_frame = b->total_frames;
             S.res_frames = n_frames;
             S.res_chunks = n_chunks;
             S.res_count0 = count0;
             S.res_slots = max_slots;
+            b->batches_enqueued = b->batch_index + 1;
         }
     }
     SDR_DONE(sdr::K_FIND_PEAKS);
@@ -592,6 +601,10 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     b->last_count0 = count0;
     b->total_frames += n_frames;
     b->batch_index++;
+    if (!b->results_on) {
+        std::lock_guard<std::mutex> guard(b->res_mu);
+        b->batches_enqueued = b->batch_index;
+    }
     return SDR_OK;
 }
 
@@ -1578,6 +1591,7 @@ int sdr_graph_launch(sdr_bank *b, const float *const *iq_dev)
         return fail(SDR_ERR_HIP, std::string("hipGraphLaunch: ") + hipGetErrorString(e));
     }
     // the host's view of the carried state, batch by batch, as the eager path commits it
+    std::lock_guard<std::mutex> guard(b->res_mu);
     for (int k = 0; k < RING; k++) {
         BatchSet &S = b->set[k];
         if (b->results_on) {
@@ -1594,6 +1608,7 @@ int sdr_graph_launch(sdr_bank *b, const float *const *iq_dev)
         b->last_count0 = meta[k].count0;
         b->batch_index++;
     }
+    b->batches_enqueued = b->batch_index;
     b->cum_count = count;
     b->carry_cur = carry;
     b->total_frames = total;
@@ -1700,8 +1715,10 @@ int sdr_enable_results(sdr_bank *b, int on)
             S.res_batch = -1;
         b->parked.clear();
     }
+    std::lock_guard<std::mutex> guard(b->res_mu);
     b->results_on = on != 0;
     b->deliver_next = b->batch_index;
+    b->batches_enqueued = b->batch_index;
     return SDR_OK;
 }
 
@@ -1709,7 +1726,8 @@ int sdr_results_pending(sdr_bank *b)
 {
     if (!b || !b->results_on)
         return 0;
-    return (int)(b->batch_index - b->deliver_next);
+    std::lock_guard<std::mutex> guard(b->res_mu);
+    return (int)(b->batches_enqueued - b->deliver_next);
 }
 
 namespace {
@@ -1719,6 +1737,22 @@ struct BatchMeta {
 };
 
 // block (pinned set or parked copy) -> the caller's buffers
+static int deliver_block(sdr_bank *b, const unsigned char *blk, const BatchMeta &m, sdr_results *r);
+// res_mu held: the oldest undelivered batch sits in the parked queue
+static int sdr_poll_parked(sdr_bank *b, sdr_results *r)
+{
+    if (b->parked.empty() || b->parked.front().batch != b->deliver_next)
+        return fail(SDR_ERR_STATE, "results of the next batch are not where they should be");
+    const sdr_bank::Parked &p = b->parked.front();
+    const BatchMeta m{p.batch, p.first_frame, p.frames, p.chunks, p.count0, p.slots};
+    const int rc = deliver_block(b, p.block.data(), m, r);
+    if (rc == SDR_OK) {
+        b->parked.pop_front();
+        b->deliver_next++;
+    }
+    return rc;
+}
+
 static int deliver_block(sdr_bank *b, const unsigned char *blk, const BatchMeta &m, sdr_results *r)
 {
     const sdr_config &c = b->cfg;
@@ -1822,26 +1856,26 @@ int sdr_poll(sdr_bank *b, sdr_results *r, int wait)
         return fail(SDR_ERR_BAD_ARG, "sdr_results.struct_size mismatch (ABI)");
     if (!b->results_on)
         return fail(SDR_ERR_STATE, "bulk delivery is off (sdr_enable_results)");
-    if (b->deliver_next >= b->batch_index)
+    std::unique_lock<std::mutex> guard(b->res_mu);
+    if (b->deliver_next >= b->batches_enqueued)
         return fail(SDR_ERR_WOULD_BLOCK, "no batch waiting");
     // oldest first: parked batches are older than anything still in the ring
-    if (!b->parked.empty() && b->parked.front().batch == b->deliver_next) {
-        const sdr_bank::Parked &p = b->parked.front();
-        const BatchMeta m{p.batch, p.first_frame, p.frames, p.chunks, p.count0, p.slots};
-        const int rc = deliver_block(b, p.block.data(), m, r);
-        if (rc == SDR_OK) {
-            b->parked.pop_front();
-            b->deliver_next++;
-        }
-        return rc;
-    }
+    if (!b->parked.empty() && b->parked.front().batch == b->deliver_next)
+        return sdr_poll_parked(b, r);
     BatchSet &S = b->set[b->deliver_next % RING];
     if (S.res_batch != b->deliver_next)
         return fail(SDR_ERR_STATE, "results of the next batch are not where they should be");
     HIP_TRY(hipSetDevice(b->device));
     for (hipEvent_t e : {S.res_listen, S.res_peaks}) {
         if (wait) {
-            HIP_TRY(hipEventSynchronize(e));
+            // (the producer must not be held up while this thread waits for the device: the set cannot be parked
+            // or reused meanwhile - its batch is the oldest undelivered one and parking waits for the same events)
+            guard.unlock();
+            const hipError_t we = hipEventSynchronize(e);
+            guard.lock();
+            HIP_TRY(we);
+            if (S.res_batch != b->deliver_next)  // the producer parked it in the meantime: take it from there
+                return sdr_poll_parked(b, r);
         } else {
             const hipError_t q = hipEventQuery(e);
             if (q == hipErrorNotReady)
