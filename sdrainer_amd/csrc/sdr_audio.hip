@@ -172,17 +172,27 @@ int sdr_audio_create(int n_streams, double pitch, int sample_rate, int max_block
     a->g.scale = 1.f;  // NewAudioDemodulator, cw/audio.go:45
     a->pending.resize((size_t)n_streams);
 
+    // (a failure half way frees what was allocated so far: sdr_audio_destroy tolerates null members)
+#define ACREATE(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            const std::string _msg = std::string(#expr) + ": " + hipGetErrorString(_e);     \
+            sdr_audio_destroy(a);                                                           \
+            return afail(SDR_ERR_HIP, _msg);                                                \
+        }                                                                                   \
+    } while (0)
     const size_t S = (size_t)n_streams, Bk = (size_t)max_blocks;
-    AHIP(hipMalloc((void **)&a->d_samples, sizeof(float) * S * Bk * (size_t)a->g.blocksize));
-    AHIP(hipMalloc((void **)&a->d_mags, sizeof(double) * S * Bk));
-    AHIP(hipMalloc((void **)&a->d_raw, S * Bk));
-    AHIP(hipMalloc((void **)&a->d_deb, S * Bk));
-    AHIP(hipMalloc((void **)&a->d_state, sizeof(AudioStreamState) * S));
-    AHIP(hipMalloc((void **)&a->d_morse, sizeof(uint16_t) * cw::kMorseTableSize));
-    AHIP(hipMalloc((void **)&a->d_text, sizeof(uint32_t) * S * (size_t)a->text_cap));
+    ACREATE(hipMalloc((void **)&a->d_samples, sizeof(float) * S * Bk * (size_t)a->g.blocksize));
+    ACREATE(hipMalloc((void **)&a->d_mags, sizeof(double) * S * Bk));
+    ACREATE(hipMalloc((void **)&a->d_raw, S * Bk));
+    ACREATE(hipMalloc((void **)&a->d_deb, S * Bk));
+    ACREATE(hipMalloc((void **)&a->d_state, sizeof(AudioStreamState) * S));
+    ACREATE(hipMalloc((void **)&a->d_morse, sizeof(uint16_t) * cw::kMorseTableSize));
+    ACREATE(hipMalloc((void **)&a->d_text, sizeof(uint32_t) * S * (size_t)a->text_cap));
     std::vector<uint16_t> morse(cw::kMorseTableSize);
     cw::build_morse_table(morse.data());
-    AHIP(hipMemcpy(a->d_morse, morse.data(), sizeof(uint16_t) * cw::kMorseTableSize, hipMemcpyHostToDevice));
+    ACREATE(hipMemcpy(a->d_morse, morse.data(), sizeof(uint16_t) * cw::kMorseTableSize, hipMemcpyHostToDevice));
     std::vector<AudioStreamState> st(S);
     for (auto &s : st) {
         memset(&s, 0, sizeof s);
@@ -191,7 +201,8 @@ int sdr_audio_create(int n_streams, double pitch, int sample_rate, int max_block
         cw::debouncer_init(s.deb, 3);                                   // cw/audio.go:18
         cw::decoder_init(s.dec, sample_rate, a->g.blocksize);           // cw/audio.go:53
     }
-    AHIP(hipMemcpy(a->d_state, st.data(), sizeof(AudioStreamState) * S, hipMemcpyHostToDevice));
+    ACREATE(hipMemcpy(a->d_state, st.data(), sizeof(AudioStreamState) * S, hipMemcpyHostToDevice));
+#undef ACREATE
     *out = a;
     return SDR_OK;
 }
