@@ -730,3 +730,53 @@ def test_graph_mode_bit_exact(capi):
     bank.process_device(dev[0].data_ptr(), per)
     bank.sync()
     bank.close()
+
+
+def test_poll_from_a_consumer_thread(capi):
+    """sdr_poll on a thread of its own while the producer thread keeps processing (the reference's Reporter and
+    TextProcessor run on goroutines of their own): every batch arrives exactly once, in order, nothing is dropped,
+    and the text adds up to the oracle's."""
+    import threading
+    import time
+
+    n, rate, tones, per, batches = 1024, 96000, 4, 100, 40
+    frames = per * batches
+    iq, bins, _ = synth.make_band(frames, rate, n, tones, seed=909)
+    edge = synth.default_edge_width(n)
+    ref = orc.Receiver(rate, n, edge)
+    bank = capi.Bank(rate, n, edge_width=edge, max_batch_frames=per, max_listeners=tones, max_peaks=128)
+    for b in bins:
+        assert bank.attach(0, int(b)) == ref.attach(int(b))
+    out = ref.process(iq)
+    bank.enable_results(True)
+    got, text, stop = [], ["" for _ in range(tones)], threading.Event()
+
+    def consume():
+        while True:
+            res = bank.poll(wait=True)
+            if res is None:
+                if stop.is_set():
+                    return
+                time.sleep(1e-4)
+                continue
+            got.append((res["batch_index"], res["first_frame"], len(res["edges"]), res["runes_dropped"], res["edges_dropped"]))
+            for r in res["listeners"]:
+                text[int(r["listener"])] += "".join(chr(int(x)) for x in res["runes"][r["first_rune"]:r["first_rune"] + r["n_runes"]])
+
+    t = threading.Thread(target=consume)
+    t.start()
+    for k in range(batches):
+        assert bank.process_host(iq[k * per:(k + 1) * per]) == per
+    bank.sync()
+    while bank.results_pending:
+        time.sleep(1e-3)
+    stop.set()
+    t.join(timeout=30)
+    assert not t.is_alive()
+    assert [g[0] for g in got] == list(range(batches)) and [g[1] for g in got] == [k * per for k in range(batches)]
+    assert all(g[3] == 0 and g[4] == 0 for g in got)
+    total_edges = sum(int(np.count_nonzero(np.diff(np.concatenate([[0], out["deb"][:, l].astype(np.int8)])))) for l in range(tones))
+    assert sum(g[2] for g in got) == total_edges
+    for lid in range(tones):
+        assert text[lid] == ref.text(lid) and len(text[lid]) > 0
+    bank.close()
