@@ -55,6 +55,43 @@ SDR_HD inline bool debounce(Debouncer &d, bool raw)
     return d.effectiveState != 0;
 }
 
+// `cnt` (1..64) consecutive Debounce calls at once, raw states in the low bits of `raw` (bit j = call j), results in
+// the same positions.  Debounce only counts the length of the current run of equal raw states, so a whole run is
+// handled in closed form: the run's value v becomes the effective state at the call where the count reaches the
+// threshold - call k = max(0, threshold - c0 - 1) of the run, c0 = the count carried into it - and stays it.
+SDR_HD inline uint64_t debounce_word(Debouncer &d, uint64_t raw, int cnt)
+{
+    const uint64_t valid = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
+    if (d.threshold < 2)
+        return raw & valid;  // dsp/dsp.go:165-167: a pass-through that keeps no state
+    uint64_t out = 0;
+    int pos = 0;
+    while (pos < cnt) {
+        const int32_t v = (int32_t)((raw >> pos) & 1ull);
+        const uint64_t diff = ((v ? ~raw : raw) & valid) >> pos;  // 1 where a later call's state differs from v
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int run = diff ? (__ffsll((long long)diff) - 1) : (cnt - pos);
+#else
+        const int run = diff ? __builtin_ctzll(diff) : (cnt - pos);
+#endif
+        const int32_t c0 = v == d.lastRawState ? d.stateCount : 0;
+        int k = d.threshold - c0 - 1;
+        k = k < 0 ? 0 : (k > run ? run : k);  // calls of this run that still return the old effective state
+        // (k, run - k <= 64 - pos, and a 64-bit span only occurs at pos 0)
+        if (d.effectiveState && k > 0)
+            out |= (k >= 64 ? ~0ull : ((1ull << k) - 1ull)) << pos;
+        if (k < run) {
+            if (v)
+                out |= ((run - k) >= 64 ? ~0ull : ((1ull << (run - k)) - 1ull)) << (pos + k);
+            d.effectiveState = v;
+        }
+        d.lastRawState = v;
+        d.stateCount = c0 + run;
+        pos += run;
+    }
+    return out;
+}
+
 // cw/decode.go:360-369
 struct AdaptiveThreshold {
     double preset, upperBound, low, high, last, threshold;

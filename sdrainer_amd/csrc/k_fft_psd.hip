@@ -460,10 +460,10 @@ static hipError_t launch_fft_t(const float *iq, const BatchCursor *cur, const ff
     while (fpw > 1 && (long)((n_frames + fpw - 1) / fpw) * n_bands < 256)
         fpw /= 2;
     if (fpw > 1)
-        hipLaunchKernelGGL((k_fft_psd<LOGN, true>), dim3((n_frames + fpw - 1) / fpw, n_bands), dim3(PL::T), PL::LDS_BYTES, stream,
+        launch_kernel((k_fft_psd<LOGN, true>), dim3((n_frames + fpw - 1) / fpw, n_bands), dim3(PL::T), PL::LDS_BYTES, stream,
                            iq, cur, tw, psd, in_stride, out_stride, n_frames, fpw, tap.bins, tap.out, tap.n, tap.stride);
     else
-        hipLaunchKernelGGL((k_fft_psd<LOGN, false>), dim3(n_frames, n_bands), dim3(PL::T),
+        launch_kernel((k_fft_psd<LOGN, false>), dim3(n_frames, n_bands), dim3(PL::T),
                            PL::LDS_BYTES + (tap.n > 0 && tap.n <= kMaxLdsTap ? tap.n * 4 : 0), stream, iq, cur, tw, psd, in_stride,
                            out_stride, n_frames, 1, tap.bins, tap.out, tap.n, tap.stride);
     return hipGetLastError();

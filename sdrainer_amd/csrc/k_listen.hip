@@ -6,7 +6,7 @@
 //   k_listen_gather  data-parallel over (signal, frame): one lane takes 64 consecutive frames of one
 //                    signal, reads the psd values the FFT kernel tapped for it, projects them to dB,
 //                    compares against each frame's threshold and packs the 64 results into one word.
-//   k_listen_decode  one LANE per signal (64 signals per wave): the debouncer and the decoder are
+//   k_listen_decode  one LANE per signal (4 signals per wave): the debouncer and the decoder are
 //                    inherently serial per signal, but between keying edges Decoder.Tick only counts, so
 //                    the lane walks RUNS of equal bits (ffs on the XOR-ed word) and handles each run in
 //                    closed form (cw::decoder_advance) — a few hundred edges per batch instead of
@@ -24,15 +24,28 @@ namespace sdr {
 // wrote the psd value of the slot's bin there, k_fft_psd.hip "The tap"; neighbouring lanes read neighbouring
 // words), projects it to dB with the literal Go algorithm (0.5 M values per batch: no shortcut needed) and
 // collects its own 64 comparison results into one word.
-__global__ __launch_bounds__(64) void k_listen_gather(const float *__restrict__ tap, const sdr_frame_rec *__restrict__ recs,
+// Waves per workgroup (development knobs, tools/build_abl.sh).  One: a workgroup with several of these waves keeps
+// them on one CU, where they slow each other down far more than their issue rate explains (decode 0.141 ms with one
+// wave per workgroup, 0.178 with two, 0.242 with four, each wave on a SIMD of its own), and the listen stream is as
+// long as its slowest wave.
+#ifndef SDR_GATHER_WAVES
+#define SDR_GATHER_WAVES 1
+#endif
+#ifndef SDR_DECODE_WAVES
+#define SDR_DECODE_WAVES 1
+#endif
+constexpr int GATHER_WAVES = SDR_GATHER_WAVES;  // 64-frame words per workgroup, one per wave
+constexpr int DECODE_WAVES = SDR_DECODE_WAVES;  // signal groups per workgroup, one per wave
+
+__global__ __launch_bounds__(64 * GATHER_WAVES) void k_listen_gather(const float *__restrict__ tap, const sdr_frame_rec *__restrict__ recs,
                                                       const ListenerSlot *__restrict__ slots,
                                                       uint64_t *__restrict__ raw_bits, float *__restrict__ tr_values,
                                                       uint8_t *__restrict__ tr_raw, ListenGeom g, int n_frames,
                                                       int n_slots, double inv_n2)
 {
-    const int word = blockIdx.x, band = blockIdx.z;
-    const int l = blockIdx.y * 64 + threadIdx.x;
-    if (l >= n_slots)
+    const int word = blockIdx.x * GATHER_WAVES + (int)(threadIdx.x >> 6), band = blockIdx.z;
+    const int l = blockIdx.y * 64 + (int)(threadIdx.x & 63);
+    if (l >= n_slots || word * 64 >= n_frames)
         return;
     const size_t lidx = (size_t)band * g.max_listeners + l;
     if (!slots[lidx].active)
@@ -64,7 +77,15 @@ __global__ __launch_bounds__(64) void k_listen_gather(const float *__restrict__ 
     raw_bits[lidx * g.bit_words + word] = mask;
 }
 
-constexpr int DECODE_LANES = 16;
+// Signals per decoder wave.  The lanes of a wave walk their signals' edges in lockstep and take every branch any of
+// them takes, so fewer signals per wave means a shorter wave - and the decoder is the long pole of the listen stream,
+// which was the longest of the four (it bounded the step): 16 lanes 0.176 ms standalone / 0.2536 ms per pipelined
+// step, 8: 0.163 / 0.2367, 4: 0.147 / 0.2345, 2: 0.125 / 0.2465 (by then the 128 one-wave workgroups take more CUs
+// from the FFT than the shorter stream gives back).
+#ifndef SDR_DECODE_LANES
+#define SDR_DECODE_LANES 4
+#endif
+constexpr int DECODE_LANES = SDR_DECODE_LANES;
 
 // The io.Writer of a listener's decoder (cw/decode.go:352): runes and, beside each, the bank frame index of the
 // Tick that wrote it (the host stamps TextProcessor.Write with that frame's time: rx/text_processor.go:208-209,
@@ -88,7 +109,7 @@ struct TextSink {
     }
 };
 
-__global__ __launch_bounds__(64) void k_listen_decode(ListenerSlot *__restrict__ slots, const uint16_t *morse,
+__global__ __launch_bounds__(64 * DECODE_WAVES) void k_listen_decode(ListenerSlot *__restrict__ slots, const uint16_t *morse,
                                                       const uint64_t *__restrict__ raw_bits,
                                                       uint64_t *__restrict__ deb_bits, uint32_t *__restrict__ text,
                                                       uint32_t *__restrict__ text_frames, sdr_edge *__restrict__ edges,
@@ -105,11 +126,10 @@ __global__ __launch_bounds__(64) void k_listen_decode(ListenerSlot *__restrict__
         s_morse[i] = morse[i];
     __syncthreads();
     morse = s_morse;
-    // 16 signals per wave: the lanes of a wave advance in lockstep through the union of their edges, so
-    // fewer signals per wave means fewer wasted iterations (and the waves spread over more CUs)
-    if (threadIdx.x >= DECODE_LANES)
+    const int lane = threadIdx.x & 63;
+    if (lane >= DECODE_LANES)
         return;
-    const int idx = blockIdx.x * DECODE_LANES + threadIdx.x;  // (band, slot) flattened
+    const int idx = (blockIdx.x * DECODE_WAVES + (int)(threadIdx.x >> 6)) * DECODE_LANES + lane;  // (band, slot) flattened
     if (idx >= n_total)
         return;
     ListenerSlot *slot = &slots[idx];
@@ -125,15 +145,21 @@ __global__ __launch_bounds__(64) void k_listen_decode(ListenerSlot *__restrict__
     uint32_t n_edges = 0;
     const int band = idx / g.max_listeners, l = idx - band * g.max_listeners;
 
+    // The words of raw states are fetched four ahead: a load per word in the loop would put a trip to memory on the
+    // serial path of every 64 frames (32 of them per 2048-frame batch).
+    const int n_words = (n_frames + 63) >> 6;
+    uint64_t ahead[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        ahead[k] = rw[min(k, n_words - 1)];
     for (int f0 = 0; f0 < n_frames; f0 += 64) {
         const int cnt = min(64, n_frames - f0);
-        const uint64_t raw = rw[f0 >> 6];
-        uint64_t d = raw;
-        if (deb.threshold >= 2) {  // dsp/dsp.go:165-167: threshold < 2 is a passthrough
-            d = 0;
-            for (int j = 0; j < cnt; j++)
-                d |= (uint64_t)cw::debounce(deb, (raw >> j) & 1ull) << j;
-        }
+        const uint64_t raw = ahead[0];
+        ahead[0] = ahead[1];
+        ahead[1] = ahead[2];
+        ahead[2] = ahead[3];
+        ahead[3] = rw[min((f0 >> 6) + 4, n_words - 1)];
+        const uint64_t d = cw::debounce_word(deb, raw, cnt);  // dsp/dsp.go:164-182, a run of equal raw states at a time
         dw[f0 >> 6] = d;
         // walk the runs of equal debounced bits
         int pos = 0;
@@ -201,7 +227,8 @@ hipError_t launch_listen_gather(const float *tap, const sdr_frame_rec *recs, con
                                 hipStream_t stream)
 {
     const double inv_n2 = 1.0 / ((double)g.n * (double)g.n);
-    hipLaunchKernelGGL(k_listen_gather, dim3((n_frames + 63) / 64, (n_slots + 63) / 64, n_bands), dim3(64), 0, stream, tap, recs,
+    launch_kernel(k_listen_gather, dim3(((n_frames + 63) / 64 + GATHER_WAVES - 1) / GATHER_WAVES, (n_slots + 63) / 64, n_bands),
+                       dim3(64 * GATHER_WAVES), 0, stream, tap, recs,
                        slots, raw_bits, tr_values, tr_raw, g, n_frames, n_slots, inv_n2);
     return hipGetLastError();
 }
@@ -212,7 +239,8 @@ hipError_t launch_listen_decode(ListenerSlot *slots, const uint16_t *morse, cons
                                 int n_frames, int n_bands, hipStream_t stream)
 {
     const int n_total = n_bands * g.max_listeners;
-    hipLaunchKernelGGL(k_listen_decode, dim3((n_total + DECODE_LANES - 1) / DECODE_LANES), dim3(64), 0, stream, slots, morse, raw_bits,
+    launch_kernel(k_listen_decode, dim3((n_total + DECODE_LANES * DECODE_WAVES - 1) / (DECODE_LANES * DECODE_WAVES)), dim3(64 * DECODE_WAVES), 0,
+                       stream, slots, morse, raw_bits,
                        deb_bits, text, text_frames, edges, edge_counts, tr_deb, drops, cur, g, n_frames, n_total);
     return hipGetLastError();
 }

@@ -19,9 +19,20 @@ namespace sdr {
 
 constexpr int TILE = 64;
 constexpr int HALF = TILE / 2;
-constexpr int N_PRODUCERS = 15;                        // wave 0 = consumer (the chains), waves 1..15 = producers
-constexpr int CHAIN_THREADS = 64 * (1 + N_PRODUCERS);  // 1024 threads, 128 VGPRs per lane
-
+constexpr int MAX_WAVES = 16;  // a workgroup is 1024 threads: one or two chain groups, each one consumer wave + producers
+// window sums: two chain groups of eight waves (consumer + 7 producers) share a workgroup.  One group of sixteen
+// waves leaves no room for a second workgroup on the CU (102 VGPRs), so 320 groups took two rounds over 256 CUs;
+// half-size workgroups fit two to a CU and are faster standalone, but they spread over every CU and each one keeps
+// an FFT workgroup (which needs a whole CU) off it: 0.2495 ms per pipelined step against 0.2465.
+#ifndef SDR_WM_GROUPS
+#define SDR_WM_GROUPS 2
+#endif
+constexpr int WM_GROUPS = SDR_WM_GROUPS;
+#ifndef SDR_NS_GROUPS
+#define SDR_NS_GROUPS 1
+#endif
+constexpr int NS_GROUPS = SDR_NS_GROUPS;  // variance chains
+constexpr int CHAIN_THREADS = 64 * MAX_WAVES;
 // SLOTS = LDS tiles between producers and consumer: 4 (133 KB, one workgroup per CU) for the long
 // variance chains, 2 (67 KB, two workgroups per CU) for the short window sums.
 template <int SLOTS>
@@ -34,12 +45,12 @@ struct ChainShared {
     int n_terms[TILE];                        // per chain: number of leading terms that count
     int ready[SLOTS][2];                      // ready[t % SLOTS][h] == t + 1  <=>  rows 32h..32h+31 of tile t are published
     int consumed;                             // tiles the consumer has finished with
-    int simd_of_wave[1 + N_PRODUCERS];        // which SIMD each wave landed on (see chain_run)
+    int simd_of_wave[MAX_WAVES];           // which SIMD each of the group's waves landed on (see chain_run)        // which SIMD each wave landed on (see chain_run)
 };
 
 #if defined(SDR_NOISE_TRACE)
 // diagnostic builds (tools/abl): where does the consumer of workgroup 0 spend its time?
-__device__ unsigned long long g_noise_trace[8];  // [0] total, [1] waiting for tiles, [2] tiles, [3] spins
+__device__ unsigned long long g_noise_trace[8];  // [0] total, [1] waiting for tiles, [2] tiles, [3] spins, [4] total in shader clocks
 extern "C" __attribute__((visibility("default"))) int sdr_debug_noise_trace(unsigned long long *out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_noise_trace), sizeof(g_noise_trace));
@@ -47,15 +58,16 @@ extern "C" __attribute__((visibility("default"))) int sdr_debug_noise_trace(unsi
 #endif
 
 // The rings live at file scope so that the consumer can be a function of its own (see chain_consumer).
-__shared__ ChainShared<2> g_ring2;
-__shared__ ChainShared<4> g_ring4;
+constexpr int NS_SLOTS = NS_GROUPS == 1 ? 4 : 2;
+__shared__ ChainShared<2> g_ring2[WM_GROUPS > NS_GROUPS ? WM_GROUPS : NS_GROUPS];
+__shared__ ChainShared<4> g_ring4[1];
 template <int SLOTS>
-__device__ __forceinline__ ChainShared<SLOTS> &ring()
+__device__ __forceinline__ ChainShared<SLOTS> &ring(int group)
 {
     if constexpr (SLOTS == 2)
-        return g_ring2;
+        return g_ring2[group];
     else
-        return g_ring4;
+        return g_ring4[group];
 }
 
 // Ordering between a wave's LDS accesses and its flag accesses.  A wave's DS instructions execute in issue
@@ -170,10 +182,10 @@ __device__ __forceinline__ void chain_producer(Shared &sh, const float *__restri
 // and conversions in the same function and ends up spilling the chain's operands; as a function of its
 // own the consumer gets a clean allocation (about 70 VGPRs, nothing spilled).
 template <int SLOTS>
-__device__ __attribute__((noinline)) double chain_consumer(int n_tiles_any_lane, int lane)
+__device__ __attribute__((noinline)) double chain_consumer(int n_tiles_any_lane, int lane, int group_any_lane)
 {
     const int n_tiles = __builtin_amdgcn_readfirstlane(n_tiles_any_lane);  // wave-uniform: scalar loop control
-    ChainShared<SLOTS> &sh = ring<SLOTS>();
+    ChainShared<SLOTS> &sh = ring<SLOTS>(__builtin_amdgcn_readfirstlane(group_any_lane));
     constexpr int RING_SLOTS = SLOTS;
     constexpr int CH = 8;
     double sum = 0;
@@ -183,6 +195,7 @@ __device__ __attribute__((noinline)) double chain_consumer(int n_tiles_any_lane,
 #if defined(SDR_NOISE_TRACE)
     unsigned long long tr_wait = 0, tr_spins = 0;
     const unsigned long long tr_start = wall_clock64();
+    const unsigned long long tr_clk0 = clock64();
 #endif
     auto wait_tile = [&](int t, int f0, int f1) {
         const int slot = t % RING_SLOTS;
@@ -260,6 +273,7 @@ __device__ __attribute__((noinline)) double chain_consumer(int n_tiles_any_lane,
         g_noise_trace[1] = tr_wait;
         g_noise_trace[2] = (unsigned long long)n_tiles;
         g_noise_trace[3] = tr_spins;
+        g_noise_trace[4] = clock64() - tr_clk0;
     }
 #endif
     return sum;
@@ -268,19 +282,21 @@ __device__ __attribute__((noinline)) double chain_consumer(int n_tiles_any_lane,
 // Runs 64 chains (lane i of wave 0 owns chain i).  `my_terms` / `my_mean` are the consumer lane's chain
 // length and mean; returns the chain's sum in the consumer lanes.  All waits are on waves of the same
 // workgroup (co-resident by construction), so every spin terminates.
-template <bool VARIANCE, class Shared>
-__device__ __forceinline__ double chain_run(Shared &sh, const float *__restrict__ base, size_t row_stride,
-                                            int rows, int n_cols, int my_terms, double my_mean)
+template <bool VARIANCE, int GROUPS, class Shared>
+__device__ __forceinline__ double chain_run(Shared &sh, int group, int wig, const float *__restrict__ base,
+                                            size_t row_stride, int rows, int n_cols, int my_terms, double my_mean)
 {
-    // (readfirstlane: the role split below becomes a scalar branch instead of an exec-masked region)
-    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // `group` = which of the workgroup's chain groups this wave belongs to (sh is that group's ring), `wig` = the
+    // wave's index in the group, wave-uniform both; wave 0 of a group is its consumer.
+    constexpr int N_PRODUCERS = MAX_WAVES / GROUPS - 1;
+    const int lane = threadIdx.x & 63;
     // HW_REG_HW_ID bits 5:4 = SIMD this wave runs on.  The consumer's additions are a pure latency chain;
     // a producer on the same SIMD puts its float64 instructions between them (measured: 13.5 instead of
-    // 6.5 clocks per term).  Producers that share the consumer's SIMD therefore sit the chain out.
+    // 6.5 clocks per term).  Producers that share their consumer's SIMD therefore sit the chain out.
     const int my_simd = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
     if (lane == 0)
-        sh.simd_of_wave[wave] = my_simd;
-    if (wave == 0) {
+        sh.simd_of_wave[wig] = my_simd;
+    if (wig == 0) {
         sh.n_terms[lane] = my_terms;
         sh.mean[lane] = my_mean;
         if (lane < Shared::RING_SLOTS) {
@@ -304,22 +320,22 @@ __device__ __forceinline__ double chain_run(Shared &sh, const float *__restrict_
     const int consumer_simd = sh.simd_of_wave[0];
     for (int w = 1; w <= N_PRODUCERS; w++) {
         const bool active = sh.simd_of_wave[w] != consumer_simd;
-        p += (active && w < wave) ? 1 : 0;
+        p += (active && w < wig) ? 1 : 0;
         np += active ? 1 : 0;
     }
     p = __builtin_amdgcn_readfirstlane(p);
     np = __builtin_amdgcn_readfirstlane(np);
-    const bool sits_out = np > 0 && my_simd == consumer_simd;  // (np == 0 cannot happen with 16 waves on 4 SIMDs)
-    if (np == 0) {
-        p = wave - 1;
+    const bool sits_out = np > 0 && my_simd == consumer_simd;
+    if (np == 0) {  // (every producer on the consumer's SIMD: not with 8 or 16 waves dealt over 4 SIMDs)
+        p = wig - 1;
         np = N_PRODUCERS;
     }
     double sum = 0;
-    if (wave == 0)
-        sum = chain_consumer<Shared::RING_SLOTS>(n_tiles, lane);
+    if (wig == 0)
+        sum = chain_consumer<Shared::RING_SLOTS>(n_tiles, lane, group);
     else if (!sits_out)
         chain_producer<VARIANCE>(sh, base, (unsigned)row_stride, rows, n_cols, n_tiles, min_terms, p, np, lane);
-    __syncthreads();  // everyone is done with the ring before a caller re-initialises it
+    __syncthreads();  // everyone is done with the rings before a caller re-initialises them
     return sum;
 }
 
@@ -330,16 +346,22 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_window_means(const float *__r
                                                                 double *__restrict__ win_mean, NoiseGeom g,
                                                                 int n_frames, int stride, int windows_per_block)
 {
-    ChainShared<2> &sh = ring<2>();
-    const int lane = threadIdx.x & 63;
-    const int f0 = blockIdx.x * TILE, band = blockIdx.z;
-    const int rows = min(TILE, n_frames - f0);
+    constexpr int WPG = MAX_WAVES / WM_GROUPS;
+    // (readfirstlane: the role split in chain_run becomes scalar branches instead of exec-masked regions)
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int group = wave / WPG;
+    // group k's consumer is its wave k, so that the consumers of a workgroup sit on different SIMDs (waves are dealt
+    // to SIMDs round-robin; chain_run asks the hardware where each one landed anyway)
+    const int wig = (wave - group * WPG - group + WPG) % WPG;
+    ChainShared<2> &sh = ring<2>(group);
+    const int f0 = (blockIdx.x * WM_GROUPS + group) * TILE, band = blockIdx.z;
+    const int rows = max(0, min(TILE, n_frames - f0));  // (0: the odd group out at the end of a band sums nothing)
     const size_t frame0 = (size_t)band * stride + f0;
     const int w_end = min(g.n_windows, (int)(blockIdx.y + 1) * windows_per_block);
     for (int w = blockIdx.y * windows_per_block; w < w_end; w++) {
         const float *base = psd + frame0 * g.n + g.edge + (size_t)w * g.window;
-        const double sum = chain_run<false>(sh, base, g.n, rows, g.window, lane < rows ? g.window : 0, 0.0);
-        if (threadIdx.x < rows)
+        const double sum = chain_run<false, WM_GROUPS>(sh, group, wig, base, g.n, rows, g.window, lane < rows ? g.window : 0, 0.0);
+        if (wig == 0 && lane < rows)
             win_mean[(frame0 + lane) * 10 + w] = sum / (double)g.window;
     }
 }
@@ -352,11 +374,14 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_noise_stats(const float *__re
                                                                sdr_frame_rec *__restrict__ recs, NoiseGeom g,
                                                                int n_frames, int stride)
 {
-    ChainShared<4> &sh = ring<4>();
-    const int lane = threadIdx.x & 63;
-    const bool consumer = threadIdx.x < TILE;
-    const int f0 = blockIdx.x * TILE, band = blockIdx.y;
-    const int rows = min(TILE, n_frames - f0);
+    constexpr int WPG = MAX_WAVES / NS_GROUPS;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int group = wave / WPG;
+    const int wig = (wave - group * WPG - group + WPG) % WPG;  // (as in k_window_means)
+    ChainShared<NS_SLOTS> &sh = ring<NS_SLOTS>(group);
+    const bool consumer = wig == 0;
+    const int f0 = (blockIdx.x * NS_GROUPS + group) * TILE, band = blockIdx.y;
+    const int rows = max(0, min(TILE, n_frames - f0));
     const size_t frame0 = (size_t)band * stride + f0;
     const bool valid = consumer && lane < rows;
     const size_t frame = frame0 + (lane < rows ? lane : 0);
@@ -381,7 +406,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_noise_stats(const float *__re
     }
     // sdr_create guarantees n_windows >= 9, so every chain starts at `edge`
     const float *base = psd + frame0 * g.n + g.edge;
-    const double sum = chain_run<true>(sh, base, g.n, rows, g.n - g.edge, n_terms, resultMean);
+    const double sum = chain_run<true, NS_GROUPS>(sh, group, wig, base, g.n, rows, g.n - g.edge, n_terms, resultMean);
     if (!valid)
         return;
     const double variance = sum / (double)g.window;
@@ -490,20 +515,20 @@ __global__ __launch_bounds__(256) void k_thresholds(sdr_frame_rec *__restrict__ 
 hipError_t launch_window_means(const float *psd, double *win_mean, NoiseGeom g, int n_frames, int n_bands, int stride,
                                hipStream_t stream)
 {
-    // enough workgroups to cover the chip (two fit per CU), but no more than needed
-    const int groups = ((n_frames + TILE - 1) / TILE) * n_bands;
-    int wpb = (groups * g.n_windows) / 512;
+    // a workgroup fills its CU: enough of them to cover the chip, but no more than two rounds
+    const int per_band = ((n_frames + TILE - 1) / TILE + WM_GROUPS - 1) / WM_GROUPS;
+    int wpb = (per_band * n_bands * g.n_windows) / 512;
     wpb = wpb < 1 ? 1 : (wpb > g.n_windows ? g.n_windows : wpb);
 
-    hipLaunchKernelGGL(k_window_means, dim3((n_frames + TILE - 1) / TILE, (g.n_windows + wpb - 1) / wpb, n_bands),
-                       dim3(CHAIN_THREADS), 0, stream, psd, win_mean, g, n_frames, stride, wpb);
+    launch_kernel(k_window_means, dim3(per_band, (g.n_windows + wpb - 1) / wpb, n_bands), dim3(CHAIN_THREADS), 0, stream, psd,
+                       win_mean, g, n_frames, stride, wpb);
     return hipGetLastError();
 }
 
 hipError_t launch_noise_stats(const float *psd, const double *win_mean, sdr_frame_rec *recs, NoiseGeom g, int n_frames,
                               int n_bands, int stride, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_noise_stats, dim3((n_frames + TILE - 1) / TILE, n_bands), dim3(CHAIN_THREADS), 0, stream, psd, win_mean,
+    launch_kernel(k_noise_stats, dim3(((n_frames + TILE - 1) / TILE + NS_GROUPS - 1) / NS_GROUPS, n_bands), dim3(CHAIN_THREADS), 0, stream, psd, win_mean,
                        recs, g, n_frames, stride);
     return hipGetLastError();
 }
@@ -511,7 +536,7 @@ hipError_t launch_noise_stats(const float *psd, const double *win_mean, sdr_fram
 hipError_t launch_thresholds(sdr_frame_rec *recs, BandState *st, int n_frames, int n_bands, int stride,
                              hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_thresholds, dim3(n_bands), dim3(256), 0, stream, recs, st, n_frames, stride);
+    launch_kernel(k_thresholds, dim3(n_bands), dim3(256), 0, stream, recs, st, n_frames, stride);
     return hipGetLastError();
 }
 

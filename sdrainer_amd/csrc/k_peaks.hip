@@ -226,7 +226,7 @@ hipError_t launch_cumulate(const float *psd, const void *db_tab, float *carry0, 
 {
     const int threads = g.n < SDR_CUM_THREADS ? g.n : SDR_CUM_THREADS;
     const double inv_n2 = 1.0 / ((double)g.n * (double)g.n);
-    hipLaunchKernelGGL(k_cumulate, dim3((g.n + threads - 1) / threads, n_slots, n_bands), dim3(threads), 0, stream, psd, db_tab,
+    launch_kernel(k_cumulate, dim3((g.n + threads - 1) / threads, n_slots, n_bands), dim3(threads), 0, stream, psd, db_tab,
                        carry0, carry1, carry_in, cum_out, cur, g, inv_n2);
     return hipGetLastError();
 }
@@ -243,7 +243,7 @@ hipError_t launch_find_peaks(const float *cum, const sdr_frame_rec *recs, DevPea
 {
     if (n_chunks == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(k_find_peaks, dim3(n_chunks, n_bands), dim3(256), 0, stream, cum, recs, peaks, counts, cur, g, n_frames);
+    launch_kernel(k_find_peaks, dim3(n_chunks, n_bands), dim3(256), 0, stream, cum, recs, peaks, counts, cur, g, n_frames);
     return hipGetLastError();
 }
 

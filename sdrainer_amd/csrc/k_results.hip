@@ -11,15 +11,22 @@
 
 namespace sdr {
 
-// one workgroup per (listener slot, band)
-__global__ __launch_bounds__(64) void k_pack_listen(ListenerSlot *__restrict__ slots, const sdr_edge *__restrict__ edges,
+#ifndef SDR_PACK_WAVES
+#define SDR_PACK_WAVES 1
+#endif
+constexpr int PACK_WAVES = SDR_PACK_WAVES;
+
+// one wave per (listener slot, band)
+__global__ __launch_bounds__(64 * PACK_WAVES) void k_pack_listen(ListenerSlot *__restrict__ slots, const sdr_edge *__restrict__ edges,
                                                     const uint32_t *__restrict__ edge_counts,
                                                     const uint32_t *__restrict__ text,
                                                     const uint32_t *__restrict__ text_frames,
                                                     const DropCounters *__restrict__ drops, ResultsLayout lay,
-                                                    unsigned char *__restrict__ host)
+                                                    int n_slots, unsigned char *__restrict__ host)
 {
-    const int l = blockIdx.x, band = blockIdx.y, lane = threadIdx.x;
+    const int l = blockIdx.x * PACK_WAVES + (int)(threadIdx.x >> 6), band = blockIdx.y, lane = threadIdx.x & 63;
+    if (l > 0 && l >= n_slots)
+        return;
     const size_t idx = (size_t)band * lay.max_listeners + l;
     ListenerSlot *slot = &slots[idx];
     uint32_t *h_edge_counts = reinterpret_cast<uint32_t *>(host + lay.off_edge_counts);
@@ -54,13 +61,13 @@ __global__ __launch_bounds__(64) void k_pack_listen(ListenerSlot *__restrict__ s
     }
 }
 
-// one workgroup per (completed cumulation, band)
-__global__ __launch_bounds__(64) void k_pack_peaks(const DevPeak *__restrict__ peaks, const int *__restrict__ counts,
+// one wave per (completed cumulation, band)
+__global__ __launch_bounds__(64 * PACK_WAVES) void k_pack_peaks(const DevPeak *__restrict__ peaks, const int *__restrict__ counts,
                                                    const BatchCursor *__restrict__ cur, ResultsLayout lay, int find_peaks,
-                                                   int n_frames, unsigned char *__restrict__ host)
+                                                   int n_frames, int n_chunks, unsigned char *__restrict__ host)
 {
-    const int chunk = blockIdx.x, band = blockIdx.y, lane = threadIdx.x;
-    if (cur && chunk >= chunks_completed(cur->count0, n_frames))
+    const int chunk = blockIdx.x * PACK_WAVES + (int)(threadIdx.x >> 6), band = blockIdx.y, lane = threadIdx.x & 63;
+    if (chunk >= n_chunks || (cur && chunk >= chunks_completed(cur->count0, n_frames)))
         return;
     const size_t cidx = (size_t)band * lay.max_chunks + chunk;
     const int n_all = find_peaks ? counts[cidx] : 0;
@@ -81,8 +88,8 @@ hipError_t launch_pack_listen(ListenerSlot *slots, const sdr_edge *edges, const 
                               hipStream_t stream)
 {
     // (at least one workgroup: it also delivers the drop counters)
-    hipLaunchKernelGGL(k_pack_listen, dim3(n_slots > 0 ? n_slots : 1, n_bands), dim3(64), 0, stream, slots, edges, edge_counts, text,
-                       text_frames, drops, lay, host);
+    launch_kernel(k_pack_listen, dim3(n_slots > 0 ? (n_slots + PACK_WAVES - 1) / PACK_WAVES : 1, n_bands), dim3(64 * PACK_WAVES),
+                       0, stream, slots, edges, edge_counts, text, text_frames, drops, lay, n_slots, host);
     return hipGetLastError();
 }
 
@@ -91,8 +98,8 @@ hipError_t launch_pack_peaks(const DevPeak *peaks, const int *counts, const Batc
 {
     if (n_chunks <= 0)
         return hipSuccess;
-    hipLaunchKernelGGL(k_pack_peaks, dim3(n_chunks, n_bands), dim3(64), 0, stream, peaks, counts, cur, lay, find_peaks, n_frames,
-                       host);
+    launch_kernel(k_pack_peaks, dim3((n_chunks + PACK_WAVES - 1) / PACK_WAVES, n_bands), dim3(64 * PACK_WAVES), 0, stream, peaks,
+                       counts, cur, lay, find_peaks, n_frames, n_chunks, host);
     return hipGetLastError();
 }
 

@@ -454,15 +454,47 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         if (_rc)                   \
             return _rc;            \
     } while (0)
-#define SDR_DONE(k) HIP_TRY(hipEventRecord(S.done[k], stream_of(k)))
+    // A stage's event is recorded by its kernel's own dispatch (sdr::launch_kernel, sdr_device.h): SDR_ARM hands the
+    // event to the next launch, SDR_DONE records it the ordinary way if no launch took it (stage left out, capture)
+    static const bool stop_events = !(getenv("SDR_STOP_EVENTS") && atoi(getenv("SDR_STOP_EVENTS")) == 0);
+    const bool ride = stop_events && !cap;
+#define SDR_ARM(k) (sdr::t_done_event = ride ? S.done[k] : nullptr)
+#define SDR_DONE(k)                                              \
+    do {                                                         \
+        if (!ride || sdr::t_done_event) {                        \
+            sdr::t_done_event = nullptr;                         \
+            HIP_TRY(hipEventRecord(S.done[k], stream_of(k)));    \
+        }                                                        \
+    } while (0)
 
     // FFT + PSD + tap, once every reader of this set (batch i - RING) is done with it (with RING sets the
     // previous user is four batches back and has almost always finished: ask the host first, a barrier packet in
     // the FFT queue costs the command processor tens of microseconds)
     // (inside a graph a set is used once per replay and replays are serialised by their stream)
-    for (int k = 1; k < sdr::K_COUNT && !cap; k++)
-        if (stream_of(k) != stream_of(sdr::K_FFT) && hipEventQuery(S.done[k]) != hipSuccess)
-            HIP_TRY(hipStreamWaitEvent(stream_of(sdr::K_FFT), S.done[k], 0));
+    // A caller that enqueues faster than the GPU works is soon more than RING batches ahead; then none of these
+    // events has happened yet at enqueue time, every FFT would sit behind up to seven barrier packets, and the FFT
+    // queue - the one that bounds the step - idled 25-35 us per batch.  So the wait is the HOST's: the call blocks
+    // until the set is free (back-pressure, at most RING batches in flight) and the FFT queue holds kernels only.
+    static const bool host_waits = getenv("SDR_HOST_THROTTLE") && atoi(getenv("SDR_HOST_THROTTLE")) != 0;
+    if (!cap) {
+        // the last stage launched on a stream stands for all of that stream's
+        static const int launch_order[] = {sdr::K_WINDOW_MEANS, sdr::K_NOISE_STATS, sdr::K_THRESHOLDS, sdr::K_LISTEN_GATHER,
+                                           sdr::K_LISTEN_DECODE, sdr::K_CUMULATE,   sdr::K_FIND_PEAKS};
+        int last_on[N_STAGES];
+        for (int &l : last_on)
+            l = -1;
+        for (int k : launch_order)
+            last_on[plan[k]] = k;
+        for (int st = 0; st < N_STAGES; st++) {
+            const int k = last_on[st];
+            if (k < 0 || st == plan[sdr::K_FFT] || hipEventQuery(S.done[k]) == hipSuccess)
+                continue;
+            if (host_waits)
+                HIP_TRY(hipEventSynchronize(S.done[k]));
+            else
+                HIP_TRY(hipStreamWaitEvent(stream_of(sdr::K_FFT), S.done[k], 0));
+        }
+    }
     int max_slots = 0;
     for (int i = 0; i < B; i++)
         max_slots = std::max(max_slots, b->n_slots[i]);
@@ -473,6 +505,7 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     }
     {
         ProfScope ps(b, sdr::K_FFT, stream_of(sdr::K_FFT));
+        SDR_ARM(sdr::K_FFT);
         const sdr::FftTap tap{b->tap_bins.p, S.tap.p, max_slots, c.max_listeners};
         SDR_LAUNCH(sdr::K_FFT, sdr::launch_fft(b->logn, iq_dev, cur, b->tw.p, S.psd.p, n_frames, B, in_stride, stride, tap,
                                                stream_of(sdr::K_FFT)));
@@ -483,6 +516,7 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     SDR_AFTER(sdr::K_WINDOW_MEANS, sdr::K_FFT);
     {
         ProfScope ps(b, sdr::K_WINDOW_MEANS, stream_of(sdr::K_WINDOW_MEANS));
+        SDR_ARM(sdr::K_WINDOW_MEANS);
         SDR_LAUNCH(sdr::K_WINDOW_MEANS, sdr::launch_window_means(S.psd.p, S.win_mean.p, ng, n_frames, B, stride,
                                                                  stream_of(sdr::K_WINDOW_MEANS)));
     }
@@ -490,6 +524,7 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     SDR_AFTER(sdr::K_NOISE_STATS, sdr::K_WINDOW_MEANS);
     {
         ProfScope ps(b, sdr::K_NOISE_STATS, stream_of(sdr::K_NOISE_STATS));
+        SDR_ARM(sdr::K_NOISE_STATS);
         SDR_LAUNCH(sdr::K_NOISE_STATS, sdr::launch_noise_stats(S.psd.p, S.win_mean.p, S.recs.p, ng, n_frames, B, stride,
                                                                stream_of(sdr::K_NOISE_STATS)));
     }
@@ -497,6 +532,7 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     SDR_AFTER(sdr::K_THRESHOLDS, sdr::K_NOISE_STATS);
     {
         ProfScope ps(b, sdr::K_THRESHOLDS, stream_of(sdr::K_THRESHOLDS));
+        SDR_ARM(sdr::K_THRESHOLDS);
         SDR_LAUNCH(sdr::K_THRESHOLDS, sdr::launch_thresholds(S.recs.p, b->band_state.p, n_frames, B, stride,
                                                              stream_of(sdr::K_THRESHOLDS)));
     }
@@ -516,6 +552,7 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     SDR_AFTER(sdr::K_LISTEN_GATHER, sdr::K_FFT);
     if (max_slots > 0) {
         ProfScope ps(b, sdr::K_LISTEN_GATHER, stream_of(sdr::K_LISTEN_GATHER));
+        SDR_ARM(sdr::K_LISTEN_GATHER);
         SDR_LAUNCH(sdr::K_LISTEN_GATHER, sdr::launch_listen_gather(S.tap.p, S.recs.p, b->slots.p, S.raw_bits.p, S.tr_values.p,
                                                                    S.tr_raw.p, lg, n_frames, max_slots, B,
                                                                    stream_of(sdr::K_LISTEN_GATHER)));
@@ -524,6 +561,8 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     SDR_AFTER(sdr::K_LISTEN_DECODE, sdr::K_LISTEN_GATHER);
     if (max_slots > 0) {
         ProfScope ps(b, sdr::K_LISTEN_DECODE, stream_of(sdr::K_LISTEN_DECODE));
+        if (!b->results_on)
+            SDR_ARM(sdr::K_LISTEN_DECODE);
         SDR_LAUNCH(sdr::K_LISTEN_DECODE, sdr::launch_listen_decode(b->slots.p, b->morse.p, S.raw_bits.p, S.bits.p, b->text.p,
                                                                    b->text_frames.p, S.edges.p, S.edge_counts.p, S.tr_deb.p, b->drops.p, cur,
                                                                    lg, n_frames, B, stream_of(sdr::K_LISTEN_DECODE)));
@@ -531,6 +570,7 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     if (b->results_on) {
         // delivery of this batch's edges and runes, behind the decoder on its stream; the decoder's event is
         // recorded behind it so that the set is not reused before the copy to the host has happened
+        SDR_ARM(sdr::K_LISTEN_DECODE);
         HIP_TRY(sdr::launch_pack_listen(b->slots.p, S.edges.p, S.edge_counts.p, b->text.p, b->text_frames.p, b->drops.p, b->res_layout, max_slots, B,
                                         S.res_host, stream_of(sdr::K_LISTEN_DECODE)));
         HIP_TRY(hipEventRecord(S.res_listen, stream_of(sdr::K_LISTEN_DECODE)));
@@ -553,6 +593,7 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     SDR_AFTER(sdr::K_CUMULATE, sdr::K_FFT);
     {
         ProfScope ps(b, sdr::K_CUMULATE, stream_of(sdr::K_CUMULATE));
+        SDR_ARM(sdr::K_CUMULATE);
         sdr::CumGeom cg{N, stride, n_frames, count0, b->max_chunks};
         SDR_LAUNCH(sdr::K_CUMULATE, sdr::launch_cumulate(S.psd.p, b->db_tab.p, b->carry[0].p, b->carry[1].p, b->carry_cur,
                                                          S.cum_out.p, cur, cg, n_slots_c, B, stream_of(sdr::K_CUMULATE)));
@@ -563,11 +604,14 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     if (b->find_peaks && n_chunks > 0) {
         SDR_AFTER(sdr::K_FIND_PEAKS, sdr::K_THRESHOLDS);  // needs the completing frame's peak threshold
         ProfScope ps(b, sdr::K_FIND_PEAKS, stream_of(sdr::K_FIND_PEAKS));
+        if (!b->results_on)
+            SDR_ARM(sdr::K_FIND_PEAKS);
         sdr::PeakGeom pg{N, stride, count0, b->max_chunks, c.max_peaks};
         SDR_LAUNCH(sdr::K_FIND_PEAKS, sdr::launch_find_peaks(S.cum_out.p, S.recs.p, S.dev_peaks.p, S.peak_counts.p, cur, pg, n_frames,
                                                              n_chunks, B, stream_of(sdr::K_FIND_PEAKS)));
     }
     if (b->results_on) {
+        SDR_ARM(sdr::K_FIND_PEAKS);
         HIP_TRY(sdr::launch_pack_peaks(S.dev_peaks.p, S.peak_counts.p, cur, b->res_layout, b->find_peaks, n_frames, n_chunks, B,
                                        S.res_host, stream_of(sdr::K_FIND_PEAKS)));
         HIP_TRY(hipEventRecord(S.res_peaks, stream_of(sdr::K_FIND_PEAKS)));
@@ -585,6 +629,7 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     SDR_DONE(sdr::K_FIND_PEAKS);
 #undef SDR_AFTER
 #undef SDR_DONE
+#undef SDR_ARM
 #undef SDR_LAUNCH
 
     if (cap)
@@ -717,7 +762,10 @@ int sdr_create(const sdr_config *cfg, sdr_bank **out)
         ALLOC(S.dev_peaks, B * (size_t)b->max_chunks * (size_t)cfg->max_peaks);
         ALLOC(S.peak_counts, B * (size_t)b->max_chunks);
         for (auto &e : S.done) {
-            hipError_t he = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+#ifndef SDR_STAGE_EVENT_FLAGS
+#define SDR_STAGE_EVENT_FLAGS hipEventDisableTiming
+#endif
+            hipError_t he = hipEventCreateWithFlags(&e, SDR_STAGE_EVENT_FLAGS);
             if (he != hipSuccess) {
                 sdr_destroy(b);
                 return fail(SDR_ERR_HIP, "hipEventCreate failed");

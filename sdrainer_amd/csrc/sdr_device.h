@@ -1,5 +1,6 @@
 // sdr_device.h — HBM-resident state and launch geometry shared by the kernels and the C-ABI host code.
 #pragma once
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -92,6 +93,23 @@ enum KernelId {
     K_FFT = 0, K_WINDOW_MEANS, K_NOISE_STATS, K_THRESHOLDS, K_LISTEN_GATHER, K_CUMULATE, K_FIND_PEAKS, K_LISTEN_DECODE,
     K_COUNT
 };
+
+// A stage's completion event can ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL's stopEvent)
+// instead of a hipEventRecord behind the kernel.  The record is a barrier packet of its own: the queue's next kernel
+// waits for the command processor to retire it, which on the FFT queue was 27-36 us per batch with nothing running
+// (0.200 ms per step for a 0.166 ms kernel launched back to back).  The caller arms `t_done_event` right before a
+// launch_* call; the first kernel launched through launch_kernel takes it.
+inline thread_local hipEvent_t t_done_event = nullptr;
+template <class F, class... A>
+inline void launch_kernel(F kernel, dim3 grid, dim3 block, unsigned lds_bytes, hipStream_t stream, A... args)
+{
+    hipEvent_t done = t_done_event;
+    t_done_event = nullptr;
+    if (done)
+        hipExtLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, nullptr, done, 0, args...);
+    else
+        hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, args...);
+}
 
 // The listeners' bins of every band and where their psd values go (k_fft_psd.hip "The tap").
 struct FftTap {

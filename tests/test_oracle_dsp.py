@@ -325,6 +325,19 @@ def test_fast_db_path_is_certified(tmp_path):
     assert "mismatches 0" in out.stdout
 
 
+def test_debounce_word_matches_the_literal_debouncer(tmp_path):
+    """The decoder kernel debounces a 64-frame word a run at a time (cw_decoder.h debounce_word); that is the same
+    function as 64 literal BoolDebouncer.Debounce calls, state included: 2M words, thresholds 0-9, on the CPU."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "emu_debounce")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(root, "tests", "emu", "emu_debounce.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "mismatches 0" in out.stdout
+
+
 def test_fft_phase_functions_match_oracle_bit_for_bit(tmp_path):
     """The register/LDS index math and per-pass twiddle layout of the FFT kernel (fft_f64.h), emulated
     thread by thread on the CPU, against the oracle's stage-by-stage radix-2 FFT for every block size."""

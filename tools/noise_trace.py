@@ -1,13 +1,21 @@
-"""Development aid: consumer-side timing of one k_noise_stats workgroup (diagnostic library libnoisetr.so)."""
-import ctypes, os, subprocess, sys
-os.environ["SDR_HIP_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "abl", "libnoisetr.so")
-sys.argv = ["bench.py", "--no-cpu-baseline", "--steps", "50", "--warmup", "10", "--serial", "--settle-ms", "200"]
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench
-bench.main()
-lib = ctypes.CDLL(os.environ["SDR_HIP_LIB"])
-out = (ctypes.c_ulonglong * 8)()
-print("rc", lib.sdr_debug_noise_trace(out))
+"""Development aid: where the variance chain's consumer (workgroup 7 of k_noise_stats) spends its time.
+Needs a library built with -DSDR_NOISE_TRACE (tools/build_abl.sh ntrace "-DSDR_NOISE_TRACE"; SDR_HIP_LIB=...)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.getcwd())
+import torch
+from sdrainer_amd import capi, synth
+rate, n, tones, frames = 2_000_000, 16384, 256, 2048
+bank = capi.Bank(rate, n, max_batch_frames=frames, max_listeners=tones, max_peaks=1024)
+iq, bins, _ = synth.make_band_torch(frames, rate, n, tones, seed=1, device="cuda", free_last_window=True)
+for b in bins: bank.attach(0, int(b))
+for i in range(4):
+    bank.process_device(iq.data_ptr(), frames)
+    bank.sync()
+out = (C.c_ulonglong * 8)()
+L = capi._lib
+L.sdr_debug_noise_trace.restype = C.c_int
+assert L.sdr_debug_noise_trace(out) == 0
 total, wait, tiles, spins = out[0], out[1], out[2], out[3]
-print(f"consumer of workgroup 7: {total/100:.1f} us total, {wait/100:.1f} us waiting for tiles, {tiles} tiles, {spins} spins; "
-      f"{(total-wait)/100/max(tiles,1)*1000:.0f} ns per tile busy, {total/100/max(tiles,1)*1000:.0f} ns per tile overall")
+print("consumer: total %d ticks (100 MHz) = %.1f us, waiting for tiles %.1f us (%.0f%%), %d tiles, %.3f us per tile, %d spins"
+      % (total, total / 100.0, wait / 100.0, 100.0 * wait / max(total, 1), tiles, total / 100.0 / max(tiles, 1), spins))
+print("shader clock during the chain: %.2f GHz; %.1f clocks per term outside the waits" % (out[4] / (total * 10.0), (out[4] * (1 - wait / total)) / (tiles * 64.0)))
