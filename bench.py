@@ -270,12 +270,16 @@ def main():
         consumer.start()
 
     def take(wait=False):
-        """wait: until everything enqueued so far has been delivered."""
-        while wait and bank.results_pending > 0:
+        """wait: until everything enqueued so far has been delivered AND counted by the consumer thread (the library
+        reports a batch delivered inside sdr_poll, a moment before the consumer adds it to `got`)."""
+        while wait and (bank.results_pending > 0 or got["batches"] < enqueued[0]):
             time.sleep(20e-6)
+
+    enqueued = [0]  # batches handed to the bank so far
 
     def step(i):
         bank.process_device(ring[i % len(ring)].data_ptr(), frames)
+        enqueued[0] += 1
 
     if args.graph:
         K = bank.graph_batches
@@ -287,6 +291,7 @@ def main():
         def step(i):  # noqa: F811  (one replay per K steps)
             if i % K == 0:
                 bank.graph_launch([ring[(i + k) % len(ring)].data_ptr() for k in range(K)])
+                enqueued[0] += K
 
     # run-in (untimed, not counted as warmup): the clocks ramp up from idle over the first few hundred
     # milliseconds of load; then the W warmup steps of the contract
@@ -302,8 +307,7 @@ def main():
     torch.cuda.synchronize()
     if delivery:
         take(wait=True)
-    for k_ in got:
-        got[k_] = 0
+    base = dict(got)  # the timed region counts from here
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -317,10 +321,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    delivered = {k_: got[k_] - (base[k_] if k_ in ("batches", "peaks", "edges", "runes") else 0) for k_ in got}
     if delivery:
-        assert got["batches"] == args.steps, f"delivered {got['batches']} of {args.steps} batches"
-        assert got["runes_dropped"] == 0 and got["edges_dropped"] == 0, got
-    delivered = dict(got)
+        assert delivered["batches"] == args.steps, f"delivered {delivered['batches']} of {args.steps} batches"
+        assert delivered["runes_dropped"] == 0 and delivered["edges_dropped"] == 0, delivered
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

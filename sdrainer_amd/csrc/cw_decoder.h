@@ -350,17 +350,20 @@ SDR_HD inline void decoder_advance(DecoderState &d, int k, const uint16_t *table
 {
     if (k <= 0)
         return;
+    const double end = d.ticks + (double)k;
     if (d.decoding) {
         const double start = d.lastState ? d.onStart : d.offStart;
         const double upperBound = d.offThreshold.threshold * (double)d.abortDecodeAfterDits;
-        const double first_now = ::floor(upperBound) + 1.0 + start;  // smallest integer now with now-start > upperBound
-        if (first_now <= d.ticks + (double)k) {  // (first_now <= ticks cannot happen while decoding is still set)
+        // the check fires within the run iff the run's last tick has end - start > upperBound (both sides of the
+        // subtraction are exact integers; it cannot have fired before the run while decoding is still set)
+        if (end - start > upperBound) {
+            const double first_now = ::floor(upperBound) + 1.0 + start;  // smallest integer now with now-start > upperBound
             d.decoding = 0;
             out.at_run_tick((int)(first_now - d.ticks) - 1);  // which of the run's k ticks writes (0-based)
             decode_current_char(d, table, out);
         }
     }
-    d.ticks += (double)k;
+    d.ticks = end;
 }
 
 template <class Sink>

@@ -28,6 +28,16 @@ namespace sdr {
 // stamps cost a third of the kernel's speed (every one waits for the scalar-memory counter LDS shares), so they
 // show the order of things, not their durations; durations come from SDR_FFT_CLOCK (per-workgroup spans, two
 // scalar loads per workgroup) and the SDR_ABLATE timing-only builds.
+#if defined(SDR_FFT_CLOCK_LIB)
+// diagnostic LIBRARY build (tools/build_abl.sh fftclk "-DSDR_FFT_CLOCK -DSDR_FFT_CLOCK_LIB", tools/insitu_fft.py):
+// the per-workgroup spans of the FFT launches inside the running pipeline
+__device__ unsigned long long g_fft_clock[2];
+__device__ unsigned long long g_fft_wg[2048][4];
+extern "C" __attribute__((visibility("default"))) int sdr_debug_fft_wg(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fft_wg), sizeof(g_fft_wg));
+}
+#endif
 #if defined(SDR_FFT_TRACE)
 __shared__ int s_fft_trace_frame;  // which of the workgroup's frames is being stamped
 #define SDR_STAMP(k)                                                                                  \

@@ -471,10 +471,12 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     // previous user is four batches back and has almost always finished: ask the host first, a barrier packet in
     // the FFT queue costs the command processor tens of microseconds)
     // (inside a graph a set is used once per replay and replays are serialised by their stream)
-    // A caller that enqueues faster than the GPU works is soon more than RING batches ahead; then none of these
-    // events has happened yet at enqueue time, every FFT would sit behind up to seven barrier packets, and the FFT
-    // queue - the one that bounds the step - idled 25-35 us per batch.  So the wait is the HOST's: the call blocks
-    // until the set is free (back-pressure, at most RING batches in flight) and the FFT queue holds kernels only.
+    // A caller that enqueues faster than the GPU works is soon more than RING batches ahead; then these events have
+    // not happened yet at enqueue time and the FFT queue gets barrier packets: one per other stream (its last stage
+    // stands for the stream), not one per stage - with nothing else running that was 0.200 -> 0.177 ms per step for a
+    // 0.166 ms kernel.  SDR_HOST_THROTTLE=1 (development) makes the HOST wait instead (the call blocks until the
+    // set is free, the FFT queue holds kernels only): 0.161 ms with nothing else running, but 0.237 against 0.234
+    // with the whole pipeline, where the FFT launches are spaced by the CUs the tail holds, not by their queue.
     static const bool host_waits = getenv("SDR_HOST_THROTTLE") && atoi(getenv("SDR_HOST_THROTTLE")) != 0;
     if (!cap) {
         // the last stage launched on a stream stands for all of that stream's

@@ -1,9 +1,15 @@
 #!/bin/bash
-# pipelined step time under different stream plans (diagnostic library).  Plan = stream (0-5) of each kernel:
-# fft, window means, noise stats, thresholds, gather, cumulate, find peaks, decode.   usage: ab_plan.sh [ENV=..] plan ...
+# pipelined step time under different stream plans (diagnostic library).  Plan = stream (0-3) of each kernel:
+# fft, window means, noise stats, thresholds, gather, cumulate, find peaks, decode.
+# usage: [R=3] [LIB=diag] ab_plan.sh plan ...     (interleaved rounds on one box, minimum last)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-export SDR_HIP_LIB=$PWD/tools/abl/libdiag.so
+export SDR_HIP_LIB=$PWD/tools/abl/lib${LIB:-diag}.so
+declare -A all
+for i in $(seq 1 ${R:-3}); do
 for plan in "$@"; do
-  p=$(SDR_DIAG_PLAN=$plan timeout -k 10 200 python bench.py --no-cpu-baseline --steps 1000 --warmup 100 2>&1 | grep -o '"ms_per_step": [0-9.]*' | awk '{print $2}')
-  echo "GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-default} plan $plan: pipelined_step=$p ms"
+  p=$(SDR_DIAG_PLAN=$plan timeout -k 10 200 python bench.py --no-cpu-baseline --steps 1500 --warmup 150 2>&1 | grep -o '"ms_per_step": [0-9.]*' | awk '{print $2}')
+  all[$plan]="${all[$plan]} $p"
+done; done
+for plan in "$@"; do
+  echo "${LIB:-diag} plan $plan: pipelined_step ms:${all[$plan]}  min $(echo ${all[$plan]} | tr ' ' '\n' | sort -n | head -1)"
 done

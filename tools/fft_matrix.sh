@@ -7,7 +7,7 @@ run() { # bin fpw frames [tap]
   echo "== $1 FPW=$2 frames=$3 tap=${4:-256}" >> $out
   SDR_TAP=${4:-256} SDR_TRACE_QUIET=${QUIET:-1} SDR_FFT_FPW=$2 timeout -k 5 60 tools/bin/$1 $3 >> $out 2>&1 || exit 1
 }
-for fpw in 1 2 4 8 16; do run ft_time0 $fpw 2048; run ft_time1 $fpw 2048; done
+for fpw in 1 2 4 8 16; do run ft_time1 $fpw 2048; done
 run ft_time1 8 2048 0
 run ft_time1 1 2048 0
 run ft_clock1 8 2048
