@@ -24,15 +24,16 @@ namespace sdr {
 // wrote the psd value of the slot's bin there, k_fft_psd.hip "The tap"; neighbouring lanes read neighbouring
 // words), projects it to dB with the literal Go algorithm (0.5 M values per batch: no shortcut needed) and
 // collects its own 64 comparison results into one word.
-// Waves per workgroup (development knobs, tools/build_abl.sh).  One: a workgroup with several of these waves keeps
-// them on one CU, where they slow each other down far more than their issue rate explains (decode 0.141 ms with one
-// wave per workgroup, 0.178 with two, 0.242 with four, each wave on a SIMD of its own), and the listen stream is as
-// long as its slowest wave.
+// Waves per workgroup.  Four decoder waves (one per SIMD) share a workgroup: with every lane of a wave working
+// (k_listen_decode) they run as fast together as alone - 0.134 against 0.130 ms - and 16 workgroups keep 16 CUs from
+// the FFT instead of 64: 0.221 against 0.234 ms per pipelined step (eight waves: 0.159 ms / 0.247, sixteen: 0.240 /
+// 0.32; before the lanes were filled, four waves of four active lanes took 0.234 ms against 0.137 alone).  The gather
+// waves stay one to a workgroup (two, four, eight: no difference beyond the noise).
 #ifndef SDR_GATHER_WAVES
 #define SDR_GATHER_WAVES 1
 #endif
 #ifndef SDR_DECODE_WAVES
-#define SDR_DECODE_WAVES 1
+#define SDR_DECODE_WAVES 4
 #endif
 constexpr int GATHER_WAVES = SDR_GATHER_WAVES;  // 64-frame words per workgroup, one per wave
 constexpr int DECODE_WAVES = SDR_DECODE_WAVES;  // signal groups per workgroup, one per wave
@@ -78,10 +79,9 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) void k_listen_gather(const float
 }
 
 // Signals per decoder wave.  The lanes of a wave walk their signals' edges in lockstep and take every branch any of
-// them takes, so fewer signals per wave means a shorter wave - and the decoder is the long pole of the listen stream,
-// which was the longest of the four (it bounded the step): 16 lanes 0.176 ms standalone / 0.2536 ms per pipelined
-// step, 8: 0.163 / 0.2367, 4: 0.147 / 0.2345, 2: 0.125 / 0.2465 (by then the 128 one-wave workgroups take more CUs
-// from the FFT than the shorter stream gives back).
+// them takes, so fewer signals per wave means a shorter wave - and the decoder is the long pole of the listen stream.
+// Standalone / per pipelined step, four waves per workgroup: 1 signal 0.089 ms / 0.2327, 2: 0.115 / 0.2267,
+// 4: 0.134 / 0.2207, 8: 0.151 / 0.2349 (fewer signals per wave = more workgroups holding CUs the FFT wants).
 #ifndef SDR_DECODE_LANES
 #define SDR_DECODE_LANES 4
 #endif
@@ -96,18 +96,110 @@ struct TextSink {
     uint32_t count, cap, dropped;
     uint32_t frame;     // frame of the tick being processed
     uint32_t run_base;  // frame of the first tick of the run decoder_advance is walking
+    bool writer;        // false: a lane that only follows another lane's signal (k_listen_decode) and stores nothing
     __device__ void at_run_tick(int k) { frame = run_base + (uint32_t)k; }
     __device__ void put(uint32_t r)
     {
         if (count < cap) {
-            buf[count] = r;
-            frames[count] = frame;
+            if (writer) {
+                buf[count] = r;
+                frames[count] = frame;
+            }
             count++;
         } else {
             dropped++;
         }
     }
 };
+
+// ---------------------------------------------------------------------------------------------------------------
+// The decoder as the kernel runs it.  Same arithmetic as cw_decoder.h's decoder_advance / decoder_edge (which stay
+// the definition: the audio path and the CPU checks use them), arranged so that the loop body has ONE place where a
+// rune is looked up and written.  decodeCurrentChar (cw/decode.go:315-350) is reached from four places in a tick
+// (the abort check, a character gap, a word gap, a ninth symbol); inlined four times, each with its table lookup
+// and its two stores behind a divergent branch, it was most of the loop's branches - and a wave's taken branches
+// are what its neighbours on the CU feel: the decoder ran 0.137 ms alone on its CU and 0.234 ms with three more
+// decoder waves on the CU's other SIMDs.  At most one of the four can produce a rune in one tick (each of them empties
+// the current character), so they only TAKE the character here (a key, 0 = nothing) and the loop emits it at its end.
+constexpr uint32_t kUnknownCharacterRune = cw::kUnknownCharacter;
+constexpr uint32_t kInvalidChar = 0xFFFFFFFFu;  // a character with an over-long Da in it: decodes to kUnknownCharacter
+
+// the state changes of decodeCurrentChar, without the output: returns the table key of the character taken
+// (kInvalidChar for an invalid one), 0 if there was none
+__device__ __forceinline__ uint32_t take_char(cw::DecoderState &d)
+{
+    const bool has = d.charLen != 0;
+    const uint32_t key = d.currentCharInvalid ? kInvalidChar : ((1u << d.charLen) | d.charBits);
+    d.currentCharInvalid = has ? 0 : d.currentCharInvalid;  // (survives while there is no symbol to report it on)
+    d.charLen = 0;
+    d.charBits = 0;  // (zero already whenever charLen is)
+    return has ? key : 0u;
+}
+
+struct Emission {
+    uint32_t key;    // character to look up and write, 0 = none
+    uint32_t frame;  // the frame of the tick that writes it
+    bool space;      // a word gap: ' ' after the character, stamped with the edge's frame
+};
+
+// decoder_advance: k ticks without an edge
+__device__ __forceinline__ void advance_run(cw::DecoderState &d, int k, uint32_t run_base, Emission &em)
+{
+    const double end = d.ticks + (double)k;
+    const double start = d.lastState ? d.onStart : d.offStart;
+    const double upperBound = d.offThreshold.threshold * (double)d.abortDecodeAfterDits;
+    if (__builtin_expect(d.decoding && end - start > upperBound, 0)) {
+        const double first_now = ::floor(upperBound) + 1.0 + start;
+        d.decoding = 0;
+        const uint32_t key = take_char(d);
+        if (key) {
+            em.key = key;
+            em.frame = run_base + (uint32_t)((int)(first_now - d.ticks) - 1);
+        }
+    }
+    d.ticks = end;
+}
+
+// decoder_edge: the tick at which the debounced state changes to `state`
+__device__ __forceinline__ void edge_tick(cw::DecoderState &d, bool state, uint32_t frame, Emission &em)
+{
+    d.ticks += 1;
+    const double now = d.ticks;
+    const double duration = now - (state ? d.offStart : d.onStart);
+    d.onStart = state ? now : d.onStart;
+    d.offStart = state ? d.offStart : now;
+    if (duration >= cw::kMinDitTime) {
+        cw::AdaptiveThreshold t = state ? d.offThreshold : d.onThreshold;
+        cw::at_put(t, duration);
+        if (state)
+            d.offThreshold = t;
+        else
+            d.onThreshold = t;
+        uint32_t key = 0;
+        if (state) {  // onRisingEdge
+            const bool word_gap = duration >= 4.5 * t.low;
+            if (word_gap || duration >= t.threshold)
+                key = take_char(d);
+            em.space = word_gap;
+        } else if (duration >= 2 * t.high) {  // onFallingEdge
+            d.currentCharInvalid = 1;
+        } else {
+            const bool da = duration >= t.threshold;
+            if (__builtin_expect(d.charLen == cw::kMaxSymbolCount, 0))
+                key = take_char(d);
+            d.charBits = (d.charBits << 1) | (da ? 1u : 0u);
+            d.charLen++;
+            if (da)
+                d.wpm = (d.wpm + cw::dit_to_wpm(d, t.low)) / 2.0;
+        }
+        if (key) {  // (if the abort check of this iteration's run took the character, there is none left here)
+            em.key = key;
+            em.frame = frame;
+        }
+    }
+    d.decoding = 1;
+    d.lastState = state;
+}
 
 __global__ __launch_bounds__(64 * DECODE_WAVES) void k_listen_decode(ListenerSlot *__restrict__ slots, const uint16_t *morse,
                                                       const uint64_t *__restrict__ raw_bits,
@@ -126,19 +218,28 @@ __global__ __launch_bounds__(64 * DECODE_WAVES) void k_listen_decode(ListenerSlo
         s_morse[i] = morse[i];
     __syncthreads();
     morse = s_morse;
+    // Every lane of the wave works: lanes DECODE_LANES.. follow the signal of lane (lane mod DECODE_LANES) - same
+    // loads, same arithmetic, same branches, no stores.  A wave with a few active lanes is the slow case of this
+    // hardware, and several such waves on one CU slow each other further (tools/ubench_share.hip, dependent
+    // v_add_f64: 1.68 ms with 4 active lanes against 1.31 ms with 64, one wave per CU; 3.06 against 1.31 ms with four
+    // waves per CU, 4.60 against 1.31 with eight).  Full waves cost the same however many share the CU, so the
+    // decoders can sit DECODE_WAVES to a workgroup and leave the other CUs to the FFT.
     const int lane = threadIdx.x & 63;
-    if (lane >= DECODE_LANES)
+    const int first = (blockIdx.x * DECODE_WAVES + (int)(threadIdx.x >> 6)) * DECODE_LANES;  // (band, slot) flattened
+    int sub = lane % DECODE_LANES;
+    const bool mine = lane < DECODE_LANES && first + sub < n_total && slots[min(first + sub, n_total - 1)].active;
+    const unsigned long long live = __ballot(mine);  // bit i: signal first+i is decoded by this wave
+    if (!live)
         return;
-    const int idx = (blockIdx.x * DECODE_WAVES + (int)(threadIdx.x >> 6)) * DECODE_LANES + lane;  // (band, slot) flattened
-    if (idx >= n_total)
-        return;
+    if (!((live >> sub) & 1ull))
+        sub = __ffsll((long long)live) - 1;  // nothing of its own to follow: follow the wave's first signal
+    const bool writer = mine;
+    const int idx = first + sub;
     ListenerSlot *slot = &slots[idx];
-    if (!slot->active)
-        return;
     cw::Debouncer deb = slot->deb;
     cw::DecoderState dec = slot->dec;
     TextSink sink{text + (size_t)idx * g.text_cap, text_frames + (size_t)idx * g.text_cap, slot->text_count,
-                  (uint32_t)g.text_cap, slot->text_dropped, g.frame_base, g.frame_base};
+                  (uint32_t)g.text_cap, slot->text_dropped, g.frame_base, g.frame_base, writer};
     sdr_edge *my_edges = edges + (size_t)idx * g.edge_cap;
     const uint64_t *rw = raw_bits + (size_t)idx * g.bit_words;
     uint64_t *dw = deb_bits + (size_t)idx * g.bit_words;
@@ -160,7 +261,8 @@ __global__ __launch_bounds__(64 * DECODE_WAVES) void k_listen_decode(ListenerSlo
         ahead[2] = ahead[3];
         ahead[3] = rw[min((f0 >> 6) + 4, n_words - 1)];
         const uint64_t d = cw::debounce_word(deb, raw, cnt);  // dsp/dsp.go:164-182, a run of equal raw states at a time
-        dw[f0 >> 6] = d;
+        if (writer)
+            dw[f0 >> 6] = d;
         // walk the runs of equal debounced bits
         int pos = 0;
         while (pos < cnt) {
@@ -169,23 +271,41 @@ __global__ __launch_bounds__(64 * DECODE_WAVES) void k_listen_decode(ListenerSlo
             if (cnt - pos < 64)
                 diff &= (1ull << (cnt - pos)) - 1ull;
             const int run = diff ? (__ffsll((long long)diff) - 1) : (cnt - pos);
-            sink.run_base = g.frame_base + (uint32_t)(f0 + pos);
-            cw::decoder_advance(dec, run, morse, sink);
+            Emission em{0u, 0u, false};
+            advance_run(dec, run, g.frame_base + (uint32_t)(f0 + pos), em);
             pos += run;
+            uint32_t edge_frame = 0;
             if (pos < cnt) {  // the edge tick
                 const bool st = !cur;
-                if (n_edges < (uint32_t)g.edge_cap)
-                    my_edges[n_edges] = sdr_edge{(uint32_t)(g.frame_base + f0 + pos), st ? 1u : 0u};
+                edge_frame = g.frame_base + (uint32_t)(f0 + pos);
+                if (writer && n_edges < (uint32_t)g.edge_cap)
+                    my_edges[n_edges] = sdr_edge{edge_frame, st ? 1u : 0u};
                 n_edges++;
-                sink.frame = g.frame_base + (uint32_t)(f0 + pos);
-                cw::decoder_edge(dec, st, morse, sink);
+                edge_tick(dec, st, edge_frame, em);
                 pos++;
             }
+            if (em.key | (uint32_t)em.space) {  // the one place a tick's runes are written
+                if (em.key) {
+                    uint32_t r = kUnknownCharacterRune;
+                    if (em.key != kInvalidChar) {
+                        const uint32_t looked_up = morse[em.key];
+                        r = looked_up ? looked_up : kUnknownCharacterRune;
+                    }
+                    sink.frame = em.frame;
+                    sink.put(r);
+                }
+                if (em.space) {
+                    sink.frame = edge_frame;
+                    sink.put(' ');
+                }
+            }
         }
-        if (g.trace)
+        if (g.trace && writer)
             for (int j = 0; j < cnt; j++)
                 tr_deb[((size_t)band * g.stride + f0 + j) * g.max_listeners + l] = (d >> j) & 1ull;
     }
+    if (!writer)
+        return;
     slot->deb = deb;
     slot->dec = dec;
     slot->text_count = sink.count;
@@ -205,7 +325,7 @@ __global__ void k_listener_stop(ListenerSlot *slot, const uint16_t *morse, uint3
     if (threadIdx.x != 0 || !slot->active)
         return;
     cw::DecoderState dec = slot->dec;
-    TextSink sink{text, text_frames, slot->text_count, (uint32_t)text_cap, slot->text_dropped, frame, frame};
+    TextSink sink{text, text_frames, slot->text_count, (uint32_t)text_cap, slot->text_dropped, frame, frame, true};
     cw::decoder_stop(dec, morse, sink);
     slot->dec = dec;
     slot->text_count = sink.count;
