@@ -515,7 +515,10 @@ __global__ __launch_bounds__(256) void k_thresholds(sdr_frame_rec *__restrict__ 
 hipError_t launch_window_means(const float *psd, double *win_mean, NoiseGeom g, int n_frames, int n_bands, int stride,
                                hipStream_t stream)
 {
-    // a workgroup fills its CU: enough of them to cover the chip, but no more than two rounds
+    // a workgroup fills its CU: enough of them to cover the chip, but no more than two rounds.  (Config 3: 160
+    // workgroups of one window each.  Two windows back to back per workgroup, 80 workgroups: 0.050 instead of
+    // 0.030 ms standalone and 0.226-0.238 instead of 0.222-0.225 ms per pipelined step - the noise stream is as long
+    // as the others by now; four windows: 0.093 ms, 0.253.)
     const int per_band = ((n_frames + TILE - 1) / TILE + WM_GROUPS - 1) / WM_GROUPS;
     int wpb = (per_band * n_bands * g.n_windows) / 512;
     wpb = wpb < 1 ? 1 : (wpb > g.n_windows ? g.n_windows : wpb);
