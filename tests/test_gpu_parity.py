@@ -780,3 +780,39 @@ def test_poll_from_a_consumer_thread(capi):
     for lid in range(tones):
         assert text[lid] == ref.text(lid) and len(text[lid]) > 0
     bank.close()
+
+
+def test_decoder_waves_with_holes_in_the_pool(capi):
+    """The decoder kernel fills every lane of a wave: lanes without a signal of their own follow a live one and store
+    nothing.  A pool with holes - detached slots inside a wave's group of four, a group with a single live slot, whole
+    groups empty, a pool size that is no multiple of the group - must decode exactly like the oracle, slot by slot,
+    and leave the dead slots' state alone."""
+    n, rate, tones, frames = 1024, 96000, 11, 600
+    iq, bins, _ = synth.make_band(frames, rate, n, tones, seed=4711)
+    edge = synth.default_edge_width(n)
+    ref = orc.Receiver(rate, n, edge)
+    bank = capi.Bank(rate, n, edge_width=edge, max_batch_frames=200, max_listeners=19, max_peaks=64)
+    ids, rids = [], []
+    for b in bins:
+        ids.append(bank.attach(0, int(b)))
+        rids.append(ref.attach(int(b)))
+    assert ids == rids == list(range(tones))
+    dead = [1, 2, 4, 5, 6, 9]  # group 0 keeps slots 0 and 3, group 1 keeps 7, group 2 keeps 8 and 10; groups 3, 4 empty
+    state_before = {}
+    ref.process(iq[:200])
+    bank.process_host(iq[:200])
+    for k in dead:
+        state_before[k] = bank.read_decoder_state(0, k).copy()
+        bank.detach(0, k)
+        ref.detach(k)
+    alive = [k for k in range(tones) if k not in dead]
+    for lo in (200, 400):
+        out = ref.process(iq[lo:lo + 200])
+        bank.process_host(iq[lo:lo + 200])
+        for k in alive:
+            assert np.array_equal(bank.read_keying_bits(0, k), out["deb"][:, k]), (lo, k)
+    for k in alive:
+        assert bank.read_text(0, k) == ref.text(k), k
+        assert np.array_equal(bank.read_decoder_state(0, k), ref.decoder_state(k)), k
+    assert any(len(ref.text(k)) > 0 for k in alive)
+    bank.close()
