@@ -82,10 +82,13 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) void k_listen_gather(const float
 // them takes, so fewer signals per wave means a shorter wave - and the decoder is the long pole of the listen stream.
 // Standalone / per pipelined step, four waves per workgroup: 1 signal 0.089 ms / 0.2327, 2: 0.115 / 0.2267,
 // 4: 0.134 / 0.2207, 8: 0.151 / 0.2349 (fewer signals per wave = more workgroups holding CUs the FFT wants).
+// The kernel is compiled for 1, 2 and 4 signals per wave and the launch picks the fewest that keep the decoders
+// within 64 waves (16 workgroups): a small pool - config 2's 16 signals - gets a wave per signal (0.39 instead of
+// 0.59 ms per 4096-frame batch), config 3's 256 signals get four per wave.
 #ifndef SDR_DECODE_LANES
 #define SDR_DECODE_LANES 4
 #endif
-constexpr int DECODE_LANES = SDR_DECODE_LANES;
+constexpr int DECODE_LANES_MAX = SDR_DECODE_LANES;
 
 // The io.Writer of a listener's decoder (cw/decode.go:352): runes and, beside each, the bank frame index of the
 // Tick that wrote it (the host stamps TextProcessor.Write with that frame's time: rx/text_processor.go:208-209,
@@ -201,6 +204,7 @@ __device__ __forceinline__ void edge_tick(cw::DecoderState &d, bool state, uint3
     d.lastState = state;
 }
 
+template <int DECODE_LANES>
 __global__ __launch_bounds__(64 * DECODE_WAVES) void k_listen_decode(ListenerSlot *__restrict__ slots, const uint16_t *morse,
                                                       const uint64_t *__restrict__ raw_bits,
                                                       uint64_t *__restrict__ deb_bits, uint32_t *__restrict__ text,
@@ -356,12 +360,20 @@ hipError_t launch_listen_gather(const float *tap, const sdr_frame_rec *recs, con
 hipError_t launch_listen_decode(ListenerSlot *slots, const uint16_t *morse, const uint64_t *raw_bits,
                                 uint64_t *deb_bits, uint32_t *text, uint32_t *text_frames, sdr_edge *edges,
                                 uint32_t *edge_counts, uint8_t *tr_deb, DropCounters *drops, const BatchCursor *cur, ListenGeom g,
-                                int n_frames, int n_bands, hipStream_t stream)
+                                int n_frames, int n_bands, int live_hint, hipStream_t stream)
 {
+    // live_hint: an upper bound of the signals being decoded (the slots in use)
     const int n_total = n_bands * g.max_listeners;
-    launch_kernel(k_listen_decode, dim3((n_total + DECODE_LANES * DECODE_WAVES - 1) / (DECODE_LANES * DECODE_WAVES)), dim3(64 * DECODE_WAVES), 0,
-                       stream, slots, morse, raw_bits,
-                       deb_bits, text, text_frames, edges, edge_counts, tr_deb, drops, cur, g, n_frames, n_total);
+    const int lanes = (live_hint <= 64 || DECODE_LANES_MAX < 2) ? 1 : (live_hint <= 128 || DECODE_LANES_MAX < 4) ? 2 : DECODE_LANES_MAX;
+    const dim3 grid((n_total + lanes * DECODE_WAVES - 1) / (lanes * DECODE_WAVES)), block(64 * DECODE_WAVES);
+#define SDR_DECODE_ARGS slots, morse, raw_bits, deb_bits, text, text_frames, edges, edge_counts, tr_deb, drops, cur, g, n_frames, n_total
+    if (lanes == 1)
+        launch_kernel(k_listen_decode<1>, grid, block, 0, stream, SDR_DECODE_ARGS);
+    else if (lanes == 2)
+        launch_kernel(k_listen_decode<2>, grid, block, 0, stream, SDR_DECODE_ARGS);
+    else
+        launch_kernel(k_listen_decode<DECODE_LANES_MAX>, grid, block, 0, stream, SDR_DECODE_ARGS);
+#undef SDR_DECODE_ARGS
     return hipGetLastError();
 }
 

@@ -497,9 +497,11 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
                 HIP_TRY(hipStreamWaitEvent(stream_of(sdr::K_FFT), S.done[k], 0));
         }
     }
-    int max_slots = 0;
-    for (int i = 0; i < B; i++)
+    int max_slots = 0, slots_in_use = 0;
+    for (int i = 0; i < B; i++) {
         max_slots = std::max(max_slots, b->n_slots[i]);
+        slots_in_use += b->n_slots[i];
+    }
     if (b->results_on && !cap) {
         const int prc = park_results(b, S);
         if (prc)
@@ -567,7 +569,7 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
             SDR_ARM(sdr::K_LISTEN_DECODE);
         SDR_LAUNCH(sdr::K_LISTEN_DECODE, sdr::launch_listen_decode(b->slots.p, b->morse.p, S.raw_bits.p, S.bits.p, b->text.p,
                                                                    b->text_frames.p, S.edges.p, S.edge_counts.p, S.tr_deb.p, b->drops.p, cur,
-                                                                   lg, n_frames, B, stream_of(sdr::K_LISTEN_DECODE)));
+                                                                   lg, n_frames, B, slots_in_use, stream_of(sdr::K_LISTEN_DECODE)));
     }
     if (b->results_on) {
         // delivery of this batch's edges and runes, behind the decoder on its stream; the decoder's event is
