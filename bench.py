@@ -357,12 +357,23 @@ def main():
     if delivery:
         take(wait=True)
     prof = bank.profile_read()
+    # the same kernel with the machine to itself: one step at a time, drained in between.  (Pipelined, its launches
+    # run back to back and share the CUs with the other stages, so its duration above is the step's.)
+    bank.profile_reset()
+    alone_steps = max(3, min(args.steps, 30))
+    for i in range(alone_steps):
+        step(i)
+        bank.sync()
+    if delivery:
+        take(wait=True)
+    prof_alone = bank.profile_read()
     bank.profile_enable(False)
     if consumer is not None:
         consumer_stop.set()
         consumer.join(timeout=10)
     fft_ms, fft_n = prof["k_fft_psd"]
     fft_avg_ms = fft_ms / max(fft_n, 1)
+    fft_alone_ms = prof_alone["k_fft_psd"][0] / max(prof_alone["k_fft_psd"][1], 1)
     achieved = BYTES_PER_SAMPLE * samples_per_step_rank / (fft_avg_ms * 1e-3) / 1e9
     traffic = measured_traffic(args.workload, frames)
     ops_fft, ops_path = f64_ops_per_sample(n)
@@ -420,6 +431,8 @@ def main():
             "bound": "hbm", "kernel": "k_fft_psd", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "avg_launch_ms": round(fft_avg_ms, 4), "launches_timed": fft_n,
+            "standalone": {"avg_launch_ms": round(fft_alone_ms, 4), "launches_timed": prof_alone["k_fft_psd"][1],
+                           "frac": round(BYTES_PER_SAMPLE * samples_per_step_rank / (fft_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "whole_path_frac": round(value * 1e6 / world * BYTES_PER_SAMPLE / (HBM_PEAK_GBS * 1e9), 4),
         },
     }
