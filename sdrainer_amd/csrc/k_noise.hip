@@ -4,11 +4,11 @@
 // FindNoiseFloor is two SEQUENTIAL float64 accumulations per frame (window sums, then the variance
 // about the winning window's mean): float64 addition is not associative, so to reproduce the
 // reference's bits each chain keeps its order — one lane per chain.  What is parallel is everything
-// around the chain: a workgroup owns 64 chains (64 consecutive frames); fifteen producer waves take
-// turns fetching each chain's next 64 values (one fully coalesced 256-byte load per chain), widen /
-// subtract / square them in float64 and lay them down transposed in a four-slot LDS ring guarded by
-// flags; the consumer wave's lane i then only reads row i and adds — the strictly serial part is one
-// ds_read_b64 + one v_add_f64 per term.
+// around the chain: a chain group owns 64 chains (64 consecutive frames); its producer waves take turns fetching
+// each chain's next 64 values (one fully coalesced 256-byte load per chain) and lay them down transposed in an LDS
+// ring guarded by flags - widened, mean subtracted and squared in float64 for the variance pass, as they are
+// (float32) for the window sums; the consumer wave's lane i then only reads row i and adds - the strictly serial
+// part is one v_add_f64 per term.
 #include <hip/hip_runtime.h>
 
 #include "../../include/sdrainer_hip.h"
@@ -19,34 +19,40 @@ namespace sdr {
 
 constexpr int TILE = 64;
 constexpr int HALF = TILE / 2;
-constexpr int MAX_WAVES = 16;  // a workgroup is 1024 threads: one or two chain groups, each one consumer wave + producers
-// window sums: two chain groups of eight waves (consumer + 7 producers) share a workgroup.  One group of sixteen
-// waves leaves no room for a second workgroup on the CU (102 VGPRs), so 320 groups took two rounds over 256 CUs;
-// half-size workgroups fit two to a CU and are faster standalone, but they spread over every CU and each one keeps
-// an FFT workgroup (which needs a whole CU) off it: 0.2495 ms per pipelined step against 0.2465.
+constexpr int MAX_WAVES = 16;  // a workgroup is 1024 threads: one to four chain groups, each one consumer wave + producers
+// Window sums: FOUR chain groups of four waves (consumer + 3 producers) share a workgroup; their ring tiles hold the
+// psd values as they are (float32), the consumer widens them on its way to the addition (a conversion issues in the
+// shadow of the dependent add before it), so the producers only move data and three of them keep a consumer fed.
+// History: one group of sixteen waves compiled to 102 VGPRs, i.e. one workgroup per CU whatever its LDS says, and the
+// 320 groups of config 3 took two rounds over 256 CUs (0.045 ms); two groups of eight with float64 tiles: 160
+// workgroups, 0.028 ms; half-size workgroups (two to a CU) are as fast standalone but spread over every CU and each
+// keeps an FFT workgroup - which needs a whole CU - off it (0.2495 ms per pipelined step against 0.2465).
 #ifndef SDR_WM_GROUPS
-#define SDR_WM_GROUPS 2
+#define SDR_WM_GROUPS 4
 #endif
 constexpr int WM_GROUPS = SDR_WM_GROUPS;
-#ifndef SDR_NS_GROUPS
-#define SDR_NS_GROUPS 1
-#endif
-constexpr int NS_GROUPS = SDR_NS_GROUPS;  // variance chains
+constexpr int NS_GROUPS = 1;  // variance chains: the producers' float64 work is the limit, all fifteen serve one chain
+                              // (two groups per workgroup: 0.324 ms instead of 0.115)
 constexpr int CHAIN_THREADS = 64 * MAX_WAVES;
-// SLOTS = LDS tiles between producers and consumer: 4 (133 KB, one workgroup per CU) for the long
-// variance chains, 2 (67 KB, two workgroups per CU) for the short window sums.
-template <int SLOTS>
+// SLOTS = LDS tiles between producers and consumer: 4 float64 tiles (133 KB) for the long variance chains, 2 float32
+// tiles per group (4 x 35 KB) for the short window sums.
+template <int SLOTS, class T>
 struct ChainShared {
+    using term_t = T;
     static constexpr int RING_SLOTS = SLOTS;
-    // [slot][chain][column]; row stride 66 doubles = 528 bytes: rows stay 16-byte aligned for the consumer's
-    // ds_read_b128 and consecutive rows shift by one 16-byte unit, so neither side has bank conflicts
-    alignas(16) double term[SLOTS][TILE][TILE + 2];
+    // [slot][chain][column]; rows are 528 bytes apart (float64) / 272 bytes (float32): 16-byte aligned for the
+    // consumer's ds_read_b128, and the sixteen lanes one LDS cycle serves start on sixteen different 16-byte bank
+    // groups, so neither side has bank conflicts
+    static constexpr int PAD = sizeof(T) == 8 ? 2 : 4;
+    alignas(16) T term[SLOTS][TILE][TILE + PAD];
     double mean[TILE];                        // per chain: value subtracted before squaring (variance pass)
     int n_terms[TILE];                        // per chain: number of leading terms that count
     int ready[SLOTS][2];                      // ready[t % SLOTS][h] == t + 1  <=>  rows 32h..32h+31 of tile t are published
     int consumed;                             // tiles the consumer has finished with
-    int simd_of_wave[MAX_WAVES];           // which SIMD each of the group's waves landed on (see chain_run)        // which SIMD each wave landed on (see chain_run)
+    int simd_of_wave[MAX_WAVES];              // which SIMD each of the group's waves landed on (see chain_run)
 };
+using WindowRing = ChainShared<2, float>;
+using VarianceRing = ChainShared<4, double>;
 
 #if defined(SDR_NOISE_TRACE)
 // diagnostic builds (tools/abl): where does the consumer of workgroup 0 spend its time?
@@ -58,16 +64,15 @@ extern "C" __attribute__((visibility("default"))) int sdr_debug_noise_trace(unsi
 #endif
 
 // The rings live at file scope so that the consumer can be a function of its own (see chain_consumer).
-constexpr int NS_SLOTS = NS_GROUPS == 1 ? 4 : 2;
-__shared__ ChainShared<2> g_ring2[WM_GROUPS > NS_GROUPS ? WM_GROUPS : NS_GROUPS];
-__shared__ ChainShared<4> g_ring4[1];
-template <int SLOTS>
-__device__ __forceinline__ ChainShared<SLOTS> &ring(int group)
+__shared__ WindowRing g_ring_wm[WM_GROUPS];
+__shared__ VarianceRing g_ring_ns[NS_GROUPS];
+template <class Shared>
+__device__ __forceinline__ Shared &ring(int group)
 {
-    if constexpr (SLOTS == 2)
-        return g_ring2[group];
+    if constexpr (sizeof(typename Shared::term_t) == 4)
+        return g_ring_wm[group];
     else
-        return g_ring4[group];
+        return g_ring_ns[group];
 }
 
 // Ordering between a wave's LDS accesses and its flag accesses.  A wave's DS instructions execute in issue
@@ -146,7 +151,7 @@ __device__ __forceinline__ void chain_producer(Shared &sh, const float *__restri
                 }
                 if (!full && (int)col >= readlane_i32(terms_of_lane, i))
                     x = 0.0;
-                sh.term[slot][i][lane] = x;
+                sh.term[slot][i][lane] = (typename Shared::term_t)x;
             }
         } else {
 #pragma unroll
@@ -158,7 +163,7 @@ __device__ __forceinline__ void chain_producer(Shared &sh, const float *__restri
                 }
                 if (!full && (int)col >= readlane_i32(terms_of_lane, HALF + i))
                     x = 0.0;
-                sh.term[slot][HALF + i][lane] = x;
+                sh.term[slot][HALF + i][lane] = (typename Shared::term_t)x;
             }
         }
         lds_order();
@@ -181,12 +186,13 @@ __device__ __forceinline__ void chain_producer(Shared &sh, const float *__restri
 // Not inlined on purpose: inside the kernel the register allocator has the producers' half-tile of loads
 // and conversions in the same function and ends up spilling the chain's operands; as a function of its
 // own the consumer gets a clean allocation (about 70 VGPRs, nothing spilled).
-template <int SLOTS>
+template <class Shared>
 __device__ __attribute__((noinline)) double chain_consumer(int n_tiles_any_lane, int lane, int group_any_lane)
 {
+    using T = typename Shared::term_t;
     const int n_tiles = __builtin_amdgcn_readfirstlane(n_tiles_any_lane);  // wave-uniform: scalar loop control
-    ChainShared<SLOTS> &sh = ring<SLOTS>(__builtin_amdgcn_readfirstlane(group_any_lane));
-    constexpr int RING_SLOTS = SLOTS;
+    Shared &sh = ring<Shared>(__builtin_amdgcn_readfirstlane(group_any_lane));
+    constexpr int RING_SLOTS = Shared::RING_SLOTS;
     constexpr int CH = 8;
     double sum = 0;
     if (n_tiles <= 0)
@@ -215,25 +221,29 @@ __device__ __attribute__((noinline)) double chain_consumer(int n_tiles_any_lane,
 #endif
         lds_order();
     };
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    auto load = [&](double (&b)[CH], int t, int c) {
-        const d2 *row = reinterpret_cast<const d2 *>(&sh.term[t % RING_SLOTS][lane][c * CH]);
+    // (the buffers hold the ring's own type: float32 terms are widened when they are added, not when they are read -
+    // a conversion right behind the read would wait for it and undo the read-ahead)
+    typedef T vec16 __attribute__((ext_vector_type(16 / sizeof(T))));
+    constexpr int PER_READ = 16 / (int)sizeof(T);
+    auto load = [&](T (&b)[CH], int t, int c) {
+        const vec16 *row = reinterpret_cast<const vec16 *>(&sh.term[t % RING_SLOTS][lane][c * CH]);
 #pragma unroll
-        for (int j = 0; j < CH / 2; j++) {
-            const d2 v = row[j];  // ds_read_b128
-            b[2 * j] = v.x;
-            b[2 * j + 1] = v.y;
+        for (int j = 0; j < CH / PER_READ; j++) {
+            const vec16 v = row[j];  // ds_read_b128
+#pragma unroll
+            for (int k = 0; k < PER_READ; k++)
+                b[PER_READ * j + k] = v[k];
         }
     };
-    auto add = [&](const double (&b)[CH]) {
+    auto add = [&](const T (&b)[CH]) {
 #pragma unroll
         for (int j = 0; j < CH; j++)
-            sum += b[j];
+            sum += (double)b[j];
     };
     // Four 8-term buffers, each chunk read four chunks (32 terms, > 200 clocks of additions) before it is
     // added: chunk c of a tile lives in buffer c % 4.  Entering tile t, its chunks 0-3 are already on
     // their way (requested during the second half of tile t-1).
-    double q0[CH], q1[CH], q2[CH], q3[CH];
+    T q0[CH], q1[CH], q2[CH], q3[CH];
     wait_tile(0, lds_flag_load(&sh.ready[0][0]), lds_flag_load(&sh.ready[0][1]));
     load(q0, 0, 0);
     load(q1, 0, 1);
@@ -268,7 +278,7 @@ __device__ __attribute__((noinline)) double chain_consumer(int n_tiles_any_lane,
     }
     __builtin_amdgcn_s_setprio(0);
 #if defined(SDR_NOISE_TRACE)
-    if (SLOTS == 4 && blockIdx.x == 7 && lane == 0) {
+    if (sizeof(T) == 8 && blockIdx.x == 7 && lane == 0) {
         g_noise_trace[0] = wall_clock64() - tr_start;
         g_noise_trace[1] = tr_wait;
         g_noise_trace[2] = (unsigned long long)n_tiles;
@@ -332,7 +342,7 @@ __device__ __forceinline__ double chain_run(Shared &sh, int group, int wig, cons
     }
     double sum = 0;
     if (wig == 0)
-        sum = chain_consumer<Shared::RING_SLOTS>(n_tiles, lane, group);
+        sum = chain_consumer<Shared>(n_tiles, lane, group);
     else if (!sits_out)
         chain_producer<VARIANCE>(sh, base, (unsigned)row_stride, rows, n_cols, n_tiles, min_terms, p, np, lane);
     __syncthreads();  // everyone is done with the rings before a caller re-initialises them
@@ -353,7 +363,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_window_means(const float *__r
     // group k's consumer is its wave k, so that the consumers of a workgroup sit on different SIMDs (waves are dealt
     // to SIMDs round-robin; chain_run asks the hardware where each one landed anyway)
     const int wig = (wave - group * WPG - group + WPG) % WPG;
-    ChainShared<2> &sh = ring<2>(group);
+    WindowRing &sh = ring<WindowRing>(group);
     const int f0 = (blockIdx.x * WM_GROUPS + group) * TILE, band = blockIdx.z;
     const int rows = max(0, min(TILE, n_frames - f0));  // (0: the odd group out at the end of a band sums nothing)
     const size_t frame0 = (size_t)band * stride + f0;
@@ -378,7 +388,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_noise_stats(const float *__re
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int group = wave / WPG;
     const int wig = (wave - group * WPG - group + WPG) % WPG;  // (as in k_window_means)
-    ChainShared<NS_SLOTS> &sh = ring<NS_SLOTS>(group);
+    VarianceRing &sh = ring<VarianceRing>(group);
     const bool consumer = wig == 0;
     const int f0 = (blockIdx.x * NS_GROUPS + group) * TILE, band = blockIdx.y;
     const int rows = max(0, min(TILE, n_frames - f0));
