@@ -69,6 +69,10 @@ for src, dst in (("bench_full.json", f"{tag}_bench_{key}.json"), ("bench_serial.
                  ("fft_workgroup_spans.txt", f"{tag}_fft_workgroup_spans.txt"), ("host_input_rate.txt", f"{tag}_host_input_rate.txt"),
                  ("strain_e2e.json", f"{tag}_strain_e2e.json")):
     shutil.copy(os.path.join(G, src), os.path.join(P, dst))
+for src, dst in (("ubench_share.txt", f"{tag}_ubench_share.txt"), ("fft_insitu_spans.txt", f"{tag}_fft_insitu_spans.txt"),
+                 ("skip_matrix.txt", f"{tag}_skip_matrix.txt")):  # (only there if the diagnostic libraries were built)
+    if os.path.exists(os.path.join(G, src)) and os.path.getsize(os.path.join(G, src)) > 0:
+        shutil.copy(os.path.join(G, src), os.path.join(P, dst))
 other = {}
 for name in ("bench_insitu", "bench_nodelivery", "bench_graph_c3", "bench_c5", "bench_graph_c5", "bench_c2"):
     d = json.loads(open(os.path.join(G, name + ".json")).read().strip().splitlines()[-1])

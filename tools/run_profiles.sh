@@ -25,5 +25,9 @@ python tools/host_input_rate.py > $O/host_input_rate.txt 2>&1
 timeout -k 10 300 python tools/strain_e2e.py > $O/strain_e2e.json 2>/dev/null
 SDR_TAP=256 SDR_TRACE_QUIET=1 SDR_FFT_FPW=1 tools/bin/ft_clock1 2048 > $O/fft_workgroup_spans.txt 2>&1
 SDR_FFT_FPW=1 tools/pmc_fft.sh > /dev/null 2>&1 && cp gpurun_out/pmc_fft.txt $O/fft_sq_counters.txt
+# what DESIGN.md section 5 quotes about sharing a CU and about the FFT inside the pipeline
+tools/bin/ubench_share > $O/ubench_share.txt 2>&1 || true
+if [ -f tools/abl/libfftclk.so ]; then SDR_HIP_LIB=$PWD/tools/abl/libfftclk.so python tools/insitu_fft.py > $O/fft_insitu_spans.txt 2>&1 || true; fi
+if [ -f tools/abl/libdiag.so ]; then tools/ab_skip.sh 0 254 128 32 2 64 160 0 > $O/skip_matrix.txt 2>&1 || true; fi
 echo "all done"
 tail -c 600 $O/bench_full.json
