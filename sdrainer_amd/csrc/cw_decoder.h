@@ -366,6 +366,92 @@ SDR_HD inline void decoder_advance(DecoderState &d, int k, const uint16_t *table
     d.ticks = end;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The decoder as k_listen_decode runs it.  Same arithmetic as decoder_advance / decoder_edge above, arranged so that
+// a loop iteration (a run of equal states, then the edge that ends it) has ONE place where a rune is looked up and
+// written.  decodeCurrentChar (cw/decode.go:315-350) is reached from four places in a tick (the abort check, a
+// character gap, a word gap, a ninth symbol).  At most one of them can produce a rune in one iteration - each of them
+// empties the current character - so here they only TAKE the character (a table key, 0 = nothing) and the caller
+// emits it, then the word gap's space.  (tests/emu/emu_decoder.cpp: identical to Decoder.Tick tick by tick.)
+constexpr uint32_t kInvalidChar = 0xFFFFFFFFu;  // a character with an over-long Da in it: decodes to kUnknownCharacter
+
+// the state changes of decodeCurrentChar, without the output: returns the table key of the character taken
+// (kInvalidChar for an invalid one), 0 if there was none
+SDR_HD inline uint32_t take_char(DecoderState &d)
+{
+    const bool has = d.charLen != 0;
+    const uint32_t key = d.currentCharInvalid ? kInvalidChar : ((1u << d.charLen) | d.charBits);
+    d.currentCharInvalid = has ? 0 : d.currentCharInvalid;  // (survives while there is no symbol to report it on)
+    d.charLen = 0;
+    d.charBits = 0;  // (zero already whenever charLen is)
+    return has ? key : 0u;
+}
+
+struct Emission {
+    uint32_t key;    // character to look up and write, 0 = none
+    uint32_t frame;  // the frame of the tick that writes it
+    bool space;      // a word gap: ' ' after the character, stamped with the edge's frame
+};
+
+// decoder_advance: k ticks without an edge, the first of them frame `run_base`
+SDR_HD inline void decoder_run(DecoderState &d, int k, uint32_t run_base, Emission &em)
+{
+    const double end = d.ticks + (double)k;
+    const double start = d.lastState ? d.onStart : d.offStart;
+    const double upperBound = d.offThreshold.threshold * (double)d.abortDecodeAfterDits;
+    if (d.decoding && end - start > upperBound) {  // (rare)
+        const double first_now = ::floor(upperBound) + 1.0 + start;
+        d.decoding = 0;
+        const uint32_t key = take_char(d);
+        if (key) {
+            em.key = key;
+            em.frame = run_base + (uint32_t)((int)(first_now - d.ticks) - 1);
+        }
+    }
+    d.ticks = end;
+}
+
+// decoder_edge: the tick (frame `frame`) at which the debounced state changes to `state`
+SDR_HD inline void decoder_edge_deferred(DecoderState &d, bool state, uint32_t frame, Emission &em)
+{
+    d.ticks += 1;
+    const double now = d.ticks;
+    const double duration = now - (state ? d.offStart : d.onStart);
+    d.onStart = state ? now : d.onStart;
+    d.offStart = state ? d.offStart : now;
+    if (duration >= kMinDitTime) {
+        AdaptiveThreshold t = state ? d.offThreshold : d.onThreshold;
+        at_put(t, duration);
+        if (state)
+            d.offThreshold = t;
+        else
+            d.onThreshold = t;
+        uint32_t key = 0;
+        if (state) {  // onRisingEdge
+            const bool word_gap = duration >= 4.5 * t.low;
+            if (word_gap || duration >= t.threshold)
+                key = take_char(d);
+            em.space = word_gap;
+        } else if (duration >= 2 * t.high) {  // onFallingEdge
+            d.currentCharInvalid = 1;
+        } else {
+            const bool da = duration >= t.threshold;
+            if (d.charLen == kMaxSymbolCount)  // (rare)
+                key = take_char(d);
+            d.charBits = (d.charBits << 1) | (da ? 1u : 0u);
+            d.charLen++;
+            if (da)
+                d.wpm = (d.wpm + dit_to_wpm(d, t.low)) / 2.0;
+        }
+        if (key) {  // (if the abort check of this iteration's run took the character, there is none left here)
+            em.key = key;
+            em.frame = frame;
+        }
+    }
+    d.decoding = 1;
+    d.lastState = state;
+}
+
 template <class Sink>
 SDR_HD inline void decoder_stop(DecoderState &d, const uint16_t *table, Sink &out)  // stop :352-354
 {

@@ -115,94 +115,10 @@ struct TextSink {
     }
 };
 
-// ---------------------------------------------------------------------------------------------------------------
-// The decoder as the kernel runs it.  Same arithmetic as cw_decoder.h's decoder_advance / decoder_edge (which stay
-// the definition: the audio path and the CPU checks use them), arranged so that the loop body has ONE place where a
-// rune is looked up and written.  decodeCurrentChar (cw/decode.go:315-350) is reached from four places in a tick
-// (the abort check, a character gap, a word gap, a ninth symbol); inlined four times, each with its table lookup
-// and its two stores behind a divergent branch, it was most of the loop's branches - and a wave's taken branches
-// are what its neighbours on the CU feel: the decoder ran 0.137 ms alone on its CU and 0.234 ms with three more
-// decoder waves on the CU's other SIMDs.  At most one of the four can produce a rune in one tick (each of them empties
-// the current character), so they only TAKE the character here (a key, 0 = nothing) and the loop emits it at its end.
-constexpr uint32_t kUnknownCharacterRune = cw::kUnknownCharacter;
-constexpr uint32_t kInvalidChar = 0xFFFFFFFFu;  // a character with an over-long Da in it: decodes to kUnknownCharacter
-
-// the state changes of decodeCurrentChar, without the output: returns the table key of the character taken
-// (kInvalidChar for an invalid one), 0 if there was none
-__device__ __forceinline__ uint32_t take_char(cw::DecoderState &d)
-{
-    const bool has = d.charLen != 0;
-    const uint32_t key = d.currentCharInvalid ? kInvalidChar : ((1u << d.charLen) | d.charBits);
-    d.currentCharInvalid = has ? 0 : d.currentCharInvalid;  // (survives while there is no symbol to report it on)
-    d.charLen = 0;
-    d.charBits = 0;  // (zero already whenever charLen is)
-    return has ? key : 0u;
-}
-
-struct Emission {
-    uint32_t key;    // character to look up and write, 0 = none
-    uint32_t frame;  // the frame of the tick that writes it
-    bool space;      // a word gap: ' ' after the character, stamped with the edge's frame
-};
-
-// decoder_advance: k ticks without an edge
-__device__ __forceinline__ void advance_run(cw::DecoderState &d, int k, uint32_t run_base, Emission &em)
-{
-    const double end = d.ticks + (double)k;
-    const double start = d.lastState ? d.onStart : d.offStart;
-    const double upperBound = d.offThreshold.threshold * (double)d.abortDecodeAfterDits;
-    if (__builtin_expect(d.decoding && end - start > upperBound, 0)) {
-        const double first_now = ::floor(upperBound) + 1.0 + start;
-        d.decoding = 0;
-        const uint32_t key = take_char(d);
-        if (key) {
-            em.key = key;
-            em.frame = run_base + (uint32_t)((int)(first_now - d.ticks) - 1);
-        }
-    }
-    d.ticks = end;
-}
-
-// decoder_edge: the tick at which the debounced state changes to `state`
-__device__ __forceinline__ void edge_tick(cw::DecoderState &d, bool state, uint32_t frame, Emission &em)
-{
-    d.ticks += 1;
-    const double now = d.ticks;
-    const double duration = now - (state ? d.offStart : d.onStart);
-    d.onStart = state ? now : d.onStart;
-    d.offStart = state ? d.offStart : now;
-    if (duration >= cw::kMinDitTime) {
-        cw::AdaptiveThreshold t = state ? d.offThreshold : d.onThreshold;
-        cw::at_put(t, duration);
-        if (state)
-            d.offThreshold = t;
-        else
-            d.onThreshold = t;
-        uint32_t key = 0;
-        if (state) {  // onRisingEdge
-            const bool word_gap = duration >= 4.5 * t.low;
-            if (word_gap || duration >= t.threshold)
-                key = take_char(d);
-            em.space = word_gap;
-        } else if (duration >= 2 * t.high) {  // onFallingEdge
-            d.currentCharInvalid = 1;
-        } else {
-            const bool da = duration >= t.threshold;
-            if (__builtin_expect(d.charLen == cw::kMaxSymbolCount, 0))
-                key = take_char(d);
-            d.charBits = (d.charBits << 1) | (da ? 1u : 0u);
-            d.charLen++;
-            if (da)
-                d.wpm = (d.wpm + cw::dit_to_wpm(d, t.low)) / 2.0;
-        }
-        if (key) {  // (if the abort check of this iteration's run took the character, there is none left here)
-            em.key = key;
-            em.frame = frame;
-        }
-    }
-    d.decoding = 1;
-    d.lastState = state;
-}
+// (the decoder as the kernel runs it - one place per loop iteration that writes runes - is cw_decoder.h's
+// decoder_run / decoder_edge_deferred, checked tick by tick against Decoder.Tick on the CPU: tests/emu/emu_decoder.cpp)
+using cw::Emission;
+using cw::kInvalidChar;
 
 template <int DECODE_LANES>
 __global__ __launch_bounds__(64 * DECODE_WAVES) void k_listen_decode(ListenerSlot *__restrict__ slots, const uint16_t *morse,
@@ -276,7 +192,7 @@ __global__ __launch_bounds__(64 * DECODE_WAVES) void k_listen_decode(ListenerSlo
                 diff &= (1ull << (cnt - pos)) - 1ull;
             const int run = diff ? (__ffsll((long long)diff) - 1) : (cnt - pos);
             Emission em{0u, 0u, false};
-            advance_run(dec, run, g.frame_base + (uint32_t)(f0 + pos), em);
+            cw::decoder_run(dec, run, g.frame_base + (uint32_t)(f0 + pos), em);
             pos += run;
             uint32_t edge_frame = 0;
             if (pos < cnt) {  // the edge tick
@@ -285,15 +201,15 @@ __global__ __launch_bounds__(64 * DECODE_WAVES) void k_listen_decode(ListenerSlo
                 if (writer && n_edges < (uint32_t)g.edge_cap)
                     my_edges[n_edges] = sdr_edge{edge_frame, st ? 1u : 0u};
                 n_edges++;
-                edge_tick(dec, st, edge_frame, em);
+                cw::decoder_edge_deferred(dec, st, edge_frame, em);
                 pos++;
             }
             if (em.key | (uint32_t)em.space) {  // the one place a tick's runes are written
                 if (em.key) {
-                    uint32_t r = kUnknownCharacterRune;
+                    uint32_t r = cw::kUnknownCharacter;
                     if (em.key != kInvalidChar) {
                         const uint32_t looked_up = morse[em.key];
-                        r = looked_up ? looked_up : kUnknownCharacterRune;
+                        r = looked_up ? looked_up : cw::kUnknownCharacter;
                     }
                     sink.frame = em.frame;
                     sink.put(r);

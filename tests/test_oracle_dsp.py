@@ -338,6 +338,22 @@ def test_debounce_word_matches_the_literal_debouncer(tmp_path):
     assert "mismatches 0" in out.stdout
 
 
+def test_kernel_decoder_loop_matches_literal_ticks(tmp_path):
+    """The decoder loop of k_listen_decode - closed form over a run of equal states, the edge tick, one place per
+    iteration that writes runes (cw_decoder.h decoder_run / decoder_edge_deferred) - against literal Decoder.Tick calls
+    on the CPU: same runes, same frames, same state after every 64-tick word, over 400 keyed streams with glitches,
+    over-long marks, long silences and over-long characters."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "emu_decoder")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-o", exe,
+                           os.path.join(root, "tests", "emu", "emu_decoder.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "mismatches 0" in out.stdout and " 0 runes" not in out.stdout
+
+
 def test_fft_phase_functions_match_oracle_bit_for_bit(tmp_path):
     """The register/LDS index math and per-pass twiddle layout of the FFT kernel (fft_f64.h), emulated
     thread by thread on the CPU, against the oracle's stage-by-stage radix-2 FFT for every block size."""
