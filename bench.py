@@ -5,7 +5,8 @@ per-peak envelope / Morse decode, at 1/2/4/8 GPUs; % of the HBM roofline).
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One process per GPU.  A *step* is one pass of the whole hot path (all seven kernels) over one batch of
+One process per GPU.  Without a launcher (`WORLD_SIZE` unset) `--gpus N` with N > 1 starts its own N rank processes
+before anything touches the GPU (spawn_ranks) and relays rank 0's line.  A *step* is one pass of the whole hot path (all seven kernels) over one batch of
 synthetic IQ that is already resident in HBM.  Workload at every N: BASELINE config 3 — one 2 MS/s
 band, 16384-point FFT, 256 tracked CW signals — per GPU (config 4 = 8 x config 3, one band per GPU):
 bands are independent receivers, so the job shards by band with no data-path collective (weak
@@ -168,8 +169,40 @@ def cpu_baseline(rate, n, tones, free_last, seconds):
     }
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this same script (one per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, as torch.distributed.run would set them), BEFORE
+    this process has touched the GPU - it never does.  Rank 0's stdout (the one JSON line) is relayed; the exit code
+    is non-zero if any rank failed."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), SDR_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))
     if args.serial:
         os.environ["SDR_NO_OVERLAP"] = "1"
     import torch
@@ -177,7 +210,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:  # never report an n_gpus that is not what was asked for
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # rehearsal knobs (a one-GPU box cannot host two RCCL ranks): SDR_DIST_BACKEND=gloo runs the
     # collectives on the CPU, SDR_FORCE_DEVICE pins every rank to one GPU
@@ -196,6 +229,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == world
 
     from sdrainer_amd import capi, sharding, synth
 
@@ -416,6 +450,11 @@ def main():
             "bands_per_gpu": bands_per_gpu, "frames_per_step_per_band": frames,
             "samples_per_step_per_gpu": samples_per_step_rank, "input": "complex64 IQ resident in HBM",
             "sharding": f"{bands_per_gpu * world} independent bands, {bands_per_gpu} per GPU, no data-path collective",
+            "distributed": ({"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                             "collectives": "broadcast of the shared configuration struct from rank 0 before the timed "
+                                            "region; barrier + max-over-ranks of the elapsed time around it",
+                             "launched_by": "bench.py itself" if os.environ.get("SDR_BENCH_SPAWNED") else "external launcher"}
+                            if dist is not None else {"world_size": 1, "backend": None}),
             "clock_settle_ms": args.settle_ms,
             "launch": (f"hipGraph: {bank.graph_batches} batches per replay (sdr_graph_launch)" if args.graph
                        else "eager: every kernel launched per step over the bank's four streams"),

@@ -73,6 +73,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    # the link step leaves its offload-bundler temporaries beside the output (libsdrainer_hip.so.N.hipv4-... /
+    # .host-...): they are not part of the product
+    import glob
+
+    for tmp in glob.glob(LIB + ".*.hipv4-*") + glob.glob(LIB + ".*.host-*"):
+        os.remove(tmp)
     with open(STAMP, "w") as f:
         f.write(source_hash() + "\n")
     return LIB

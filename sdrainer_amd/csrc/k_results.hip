@@ -28,14 +28,16 @@ __global__ __launch_bounds__(64 * PACK_WAVES) void k_pack_listen(ListenerSlot *_
                                                     int n_slots, unsigned char *__restrict__ host)
 {
     const int l = blockIdx.x * PACK_WAVES + (int)(threadIdx.x >> 6), band = blockIdx.y, lane = threadIdx.x & 63;
-    if (l > 0 && l >= n_slots)
+    // the bank's drop counters travel with every batch, also one without a single listener slot (a bank created
+    // with max_listeners == 0 has no slot array at all: nothing below may be touched then)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        *reinterpret_cast<DropCounters *>(host + lay.off_drops) = *drops;  // (the decoder of this batch has finished)
+    if (l >= n_slots)
         return;
     const size_t idx = (size_t)band * lay.max_listeners + l;
     ListenerSlot *slot = &slots[idx];
     uint32_t *h_edge_counts = reinterpret_cast<uint32_t *>(host + lay.off_edge_counts);
     uint32_t *h_text_counts = reinterpret_cast<uint32_t *>(host + lay.off_text_counts);
-    if (idx == 0 && lane == 0)
-        *reinterpret_cast<DropCounters *>(host + lay.off_drops) = *drops;  // (the decoder of this batch has finished)
     if (!slot->active) {
         if (lane == 0) {
             h_edge_counts[idx] = 0;

@@ -115,6 +115,7 @@ struct BatchSet {
     int64_t res_batch = -1;  // batch whose results sit in res_host, not delivered yet (-1: none)
     int64_t res_first_frame = 0;
     int res_frames = 0, res_chunks = 0, res_count0 = 0, res_slots = 0;
+    std::vector<int64_t> res_center;  // the bands' centre frequencies when the batch was enqueued (peak frequencies)
     void release()
     {
         if (res_host)
@@ -192,6 +193,7 @@ struct sdr_bank {
     hipGraphExec_t graph_exec = nullptr;
     hipGraphNode_t graph_cursor_node = nullptr;
     int graph_frames = 0, graph_slots = 0;
+    uint64_t attach_gen = 0, graph_attach_gen = 0;  // sdr_attach / sdr_detach calls so far; as of the capture
     std::vector<hipEvent_t> graph_join;
     // bulk delivery
     bool results_on = false;
@@ -200,6 +202,7 @@ struct sdr_bank {
     struct Parked {            // a finished batch moved off its ring set before delivery
         int64_t batch, first_frame;
         int frames, chunks, count0, slots;
+        std::vector<int64_t> center;
         std::vector<unsigned char> block;
     };
     std::deque<Parked> parked;
@@ -390,6 +393,7 @@ int park_results(sdr_bank *b, BatchSet &S)
     p.chunks = S.res_chunks;
     p.count0 = S.res_count0;
     p.slots = S.res_slots;
+    p.center = S.res_center;
     // (a full copy keeps one decoding routine; batches are parked only when the caller polls too rarely)
     p.block.assign(S.res_host, S.res_host + b->res_layout.bytes);
     b->parked.push_back(std::move(p));
@@ -416,6 +420,11 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     const sdr_config &c = b->cfg;
     if (n_frames <= 0)
         return SDR_OK;
+    // an armed stage event must never outlive this call (an error return between SDR_ARM and the launch would
+    // otherwise hand it to the next kernel this thread launches, possibly on another bank)
+    struct DisarmOnExit {
+        ~DisarmOnExit() { sdr::t_done_event = nullptr; }
+    } disarm_on_exit;
     if (n_frames > c.max_batch_frames)
         return fail(SDR_ERR_BAD_ARG, "n_frames exceeds max_batch_frames");
     HIP_TRY(hipSetDevice(b->device));
@@ -554,19 +563,21 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     lg.frame_base = (uint32_t)b->total_frames;
     SDR_AFTER(sdr::K_LISTEN_GATHER, sdr::K_THRESHOLDS);
     SDR_AFTER(sdr::K_LISTEN_GATHER, sdr::K_FFT);
+    // (armed whether or not the stage launches: SDR_DONE records a stage event nobody took the ordinary way, and a
+    // stage left out must still publish its event - the set-reuse wait reads the last stage of each stream)
+    SDR_ARM(sdr::K_LISTEN_GATHER);
     if (max_slots > 0) {
         ProfScope ps(b, sdr::K_LISTEN_GATHER, stream_of(sdr::K_LISTEN_GATHER));
-        SDR_ARM(sdr::K_LISTEN_GATHER);
         SDR_LAUNCH(sdr::K_LISTEN_GATHER, sdr::launch_listen_gather(S.tap.p, S.recs.p, b->slots.p, S.raw_bits.p, S.tr_values.p,
                                                                    S.tr_raw.p, lg, n_frames, max_slots, B,
                                                                    stream_of(sdr::K_LISTEN_GATHER)));
     }
     SDR_DONE(sdr::K_LISTEN_GATHER);
     SDR_AFTER(sdr::K_LISTEN_DECODE, sdr::K_LISTEN_GATHER);
+    if (!b->results_on)
+        SDR_ARM(sdr::K_LISTEN_DECODE);
     if (max_slots > 0) {
         ProfScope ps(b, sdr::K_LISTEN_DECODE, stream_of(sdr::K_LISTEN_DECODE));
-        if (!b->results_on)
-            SDR_ARM(sdr::K_LISTEN_DECODE);
         SDR_LAUNCH(sdr::K_LISTEN_DECODE, sdr::launch_listen_decode(b->slots.p, b->morse.p, S.raw_bits.p, S.bits.p, b->text.p,
                                                                    b->text_frames.p, S.edges.p, S.edge_counts.p, S.tr_deb.p, b->drops.p, cur,
                                                                    lg, n_frames, B, slots_in_use, stream_of(sdr::K_LISTEN_DECODE)));
@@ -605,11 +616,11 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     SDR_DONE(sdr::K_CUMULATE);
     const int new_count = (count0 + n_frames) % SDR_CUMULATION_SIZE;
     SDR_AFTER(sdr::K_FIND_PEAKS, sdr::K_CUMULATE);
+    if (!b->results_on)
+        SDR_ARM(sdr::K_FIND_PEAKS);
     if (b->find_peaks && n_chunks > 0) {
         SDR_AFTER(sdr::K_FIND_PEAKS, sdr::K_THRESHOLDS);  // needs the completing frame's peak threshold
         ProfScope ps(b, sdr::K_FIND_PEAKS, stream_of(sdr::K_FIND_PEAKS));
-        if (!b->results_on)
-            SDR_ARM(sdr::K_FIND_PEAKS);
         sdr::PeakGeom pg{N, stride, count0, b->max_chunks, c.max_peaks};
         SDR_LAUNCH(sdr::K_FIND_PEAKS, sdr::launch_find_peaks(S.cum_out.p, S.recs.p, S.dev_peaks.p, S.peak_counts.p, cur, pg, n_frames,
                                                              n_chunks, B, stream_of(sdr::K_FIND_PEAKS)));
@@ -627,6 +638,7 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
             S.res_chunks = n_chunks;
             S.res_count0 = count0;
             S.res_slots = max_slots;
+            S.res_center = b->center_frequency;
             b->batches_enqueued = b->batch_index + 1;
         }
     }
@@ -1132,6 +1144,7 @@ int sdr_attach(sdr_bank *b, int band, int bin, int *listener_id)
     HIP_TRY(hipMemcpy(b->slots.p + (size_t)band * c.max_listeners + lid, &s, sizeof s, hipMemcpyHostToDevice));
     const int32_t tap_bin = bin;
     HIP_TRY(hipMemcpy(b->tap_bins.p + (size_t)band * c.max_listeners + lid, &tap_bin, sizeof tap_bin, hipMemcpyHostToDevice));
+    b->attach_gen++;
     if (listener_id)
         *listener_id = lid;
     return SDR_OK;
@@ -1154,6 +1167,7 @@ int sdr_detach(sdr_bank *b, int band, int lid)
     const int32_t free_bin = -1;
     HIP_TRY(hipMemcpy(b->tap_bins.p + (size_t)band * b->cfg.max_listeners + lid, &free_bin, sizeof free_bin,
                       hipMemcpyHostToDevice));
+    b->attach_gen++;
     return SDR_OK;
 }
 
@@ -1222,6 +1236,7 @@ int sdr_set_center_frequency(sdr_bank *b, int band, int64_t frequency)
     int rc = check_band(b, band);
     if (rc)
         return rc;
+    std::lock_guard<std::mutex> guard(b->res_mu);  // (sdr_poll's thread reads the batches' snapshots under it)
     b->center_frequency[band] = frequency;
     return SDR_OK;
 }
@@ -1581,6 +1596,7 @@ int sdr_graph_capture(sdr_bank *b, int n_frames)
     b->graph_cursor_node = cursor_node;
     b->graph_frames = n_frames;
     b->graph_slots = max_slots;
+    b->graph_attach_gen = b->attach_gen;
     return SDR_OK;
 }
 
@@ -1595,8 +1611,8 @@ int sdr_graph_launch(sdr_bank *b, const float *const *iq_dev)
     int max_slots = 0;
     for (int i = 0; i < b->cfg.n_bands; i++)
         max_slots = std::max(max_slots, b->n_slots[i]);
-    if (max_slots != b->graph_slots)
-        return fail(SDR_ERR_STATE, "listeners were attached since the capture: capture again");
+    if (max_slots != b->graph_slots || b->attach_gen != b->graph_attach_gen)
+        return fail(SDR_ERR_STATE, "listeners were attached or detached since the capture: capture again");
     HIP_TRY(hipSetDevice(b->device));
     const int n_frames = b->graph_frames;
     CursorBlock blk{};
@@ -1653,6 +1669,7 @@ int sdr_graph_launch(sdr_bank *b, const float *const *iq_dev)
             S.res_chunks = meta[k].chunks;
             S.res_count0 = meta[k].count0;
             S.res_slots = max_slots;
+            S.res_center = b->center_frequency;
         }
         b->last_set = k;
         b->last_frames = n_frames;
@@ -1786,6 +1803,7 @@ namespace {
 struct BatchMeta {
     int64_t batch, first_frame;
     int frames, chunks, count0, slots;
+    const std::vector<int64_t> *center;  // centre frequencies as of the batch, not as of the poll
 };
 
 // block (pinned set or parked copy) -> the caller's buffers
@@ -1796,7 +1814,7 @@ static int sdr_poll_parked(sdr_bank *b, sdr_results *r)
     if (b->parked.empty() || b->parked.front().batch != b->deliver_next)
         return fail(SDR_ERR_STATE, "results of the next batch are not where they should be");
     const sdr_bank::Parked &p = b->parked.front();
-    const BatchMeta m{p.batch, p.first_frame, p.frames, p.chunks, p.count0, p.slots};
+    const BatchMeta m{p.batch, p.first_frame, p.frames, p.chunks, p.count0, p.slots, &p.center};
     const int rc = deliver_block(b, p.block.data(), m, r);
     if (rc == SDR_OK) {
         b->parked.pop_front();
@@ -1851,7 +1869,7 @@ static int deliver_block(sdr_bank *b, const unsigned char *blk, const BatchMeta 
         return fail(SDR_ERR_BAD_SIZE, "sdr_poll: a result buffer is too small (the n_* fields say what is needed)");
     int ci = 0, pi = 0, li = 0, ei = 0, ri = 0;
     for (int band = 0; band < B; band++) {
-        host::FrequencyMapping fm(c.sample_rate, c.block_size, b->center_frequency[band]);
+        host::FrequencyMapping fm(c.sample_rate, c.block_size, (*m.center)[band]);
         for (int ch = 0; ch < m.chunks; ch++) {
             const size_t cidx = (size_t)band * lay.max_chunks + ch;
             const int n = peak_counts[2 * cidx];
@@ -1935,7 +1953,7 @@ int sdr_poll(sdr_bank *b, sdr_results *r, int wait)
             HIP_TRY(q);
         }
     }
-    const BatchMeta m{S.res_batch, S.res_first_frame, S.res_frames, S.res_chunks, S.res_count0, S.res_slots};
+    const BatchMeta m{S.res_batch, S.res_first_frame, S.res_frames, S.res_chunks, S.res_count0, S.res_slots, &S.res_center};
     const int rc = deliver_block(b, S.res_host, m, r);
     if (rc == SDR_OK) {
         S.res_batch = -1;

@@ -46,3 +46,26 @@ def test_two_rank_bench_on_one_gpu(tmp_path):
     assert reports[0]["bands"] != reports[1]["bands"] and sorted(reports[0]["bands"] + reports[1]["bands"]) == [0, 1]
     assert reports[0]["shared_config"] == reports[1]["shared_config"]
     assert all(r["decoded_runes"] > 0 for r in reports)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: bench.py starts its two ranks itself (before it
+    touches the GPU), relays rank 0's single line and reports the world it really ran in."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(SDR_DIST_BACKEND="gloo", SDR_FORCE_DEVICE="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--frames", "256", "--settle-ms", "0", "--no-cpu-baseline"], env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 5
+    d = res["config"]["distributed"]
+    assert d["world_size"] == 2 and d["backend"] == "gloo" and d["launched_by"] == "bench.py itself"
+    # a world that is not the one asked for is refused, never reported under another n_gpus
+    env1 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline"], env=env1, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=600)
+    assert q.returncode != 0 and "WORLD_SIZE=1" in (q.stderr + q.stdout)

@@ -816,3 +816,85 @@ def test_decoder_waves_with_holes_in_the_pool(capi):
         assert np.array_equal(bank.read_decoder_state(0, k), ref.decoder_state(k)), k
     assert any(len(ref.text(k)) > 0 for k in alive)
     bank.close()
+
+
+@pytest.mark.parametrize("find_peaks", [False, True])
+def test_short_batches_without_sync_keep_the_ring_sets_safe(capi, find_peaks):
+    """Batches shorter than a cumulation, no listeners, results off - stages that launch nothing (find_peaks on a batch
+    that completes no cumulation, gather / decode without listener slots) must still publish their stage events, or
+    the FFT of batch i + RING overwrites psd while k_cumulate(i) reads it.  More batches than ring sets are enqueued
+    without a sync; the cumulation that the LAST batch completes carries every earlier batch's contribution."""
+    import torch
+
+    n, rate, per, batches = 4096, 192000, 60, 25
+    frames = per * batches
+    iq, _, _ = synth.make_band(frames, rate, n, 6, seed=321)
+    edge = synth.default_edge_width(n)
+    ref = orc.Receiver(rate, n, edge)
+    out = ref.process(iq)
+    bank = capi.Bank(rate, n, edge_width=edge, max_batch_frames=per, max_listeners=0, max_peaks=128, find_peaks=find_peaks)
+    bank.set_stream(torch.cuda.current_stream().cuda_stream)
+    dev = torch.from_numpy(iq).cuda()
+    torch.cuda.synchronize()
+    for k in range(batches):
+        bank.process_device(dev[k * per].data_ptr(), per)
+    bank.sync()
+    assert bank.last_batch_chunks == 1  # frames 1440..1499 complete the cumulation that ends at frame 1499
+    last = len(out["cumulation"]) - 1
+    assert out["peak_frames"][last] == frames - 1
+    assert _bits_equal(bank.read_cumulation(0, 0), out["cumulation"][last])
+    _assert_records_equal(bank.read_frame_records(0), out["frames"][frames - per:])
+    if find_peaks:
+        assert bank.read_peaks(0, 0)[0] == out["peaks"][last]
+    bank.close()
+
+
+def test_results_with_an_empty_listener_pool(capi):
+    """A bank created with max_listeners == 0 has no slot array; with bulk delivery on, k_pack_listen must touch none
+    (it still delivers the drop counters) and sdr_poll hands out peaks only."""
+    n, rate, frames = 1024, 96000, 250
+    iq, _, _ = synth.make_band(frames, rate, n, 5, seed=55)
+    edge = synth.default_edge_width(n)
+    ref = orc.Receiver(rate, n, edge)
+    out = ref.process(iq)
+    bank = capi.Bank(rate, n, edge_width=edge, max_batch_frames=256, max_listeners=0, max_peaks=128)
+    bank.enable_results(True)
+    assert bank.process_host(iq) == frames
+    res = bank.poll(wait=True)
+    assert res["n_frames"] == frames and len(res["listeners"]) == 0 and len(res["edges"]) == 0
+    assert res["runes_dropped"] == 0 and res["edges_dropped"] == 0
+    assert len(res["chunks"]) == 2
+    for ch in res["chunks"]:
+        gc = list(out["peak_frames"]).index(int(ch["frame"]))
+        got = [tuple(int(p[k]) if k != "signal_value" else float(p[k]) for k in
+                     ("from", "to", "from_frequency", "to_frequency", "signal_frequency", "signal_value", "signal_bin"))
+               for p in res["peaks"][ch["first_peak"]:ch["first_peak"] + ch["n_peaks"]]]
+        assert got == out["peaks"][gc] and len(got) >= 5
+    bank.close()
+
+
+def test_peak_frequencies_follow_the_batch_not_the_poll(capi):
+    """sdr_set_center_frequency between a batch and its delivery: the batch's peaks keep the frequencies of ITS time
+    (rx/receiver.go applies setters between frames; dsp/fft.go:95-135 maps bins with the mapping of that frame)."""
+    n, rate, frames = 1024, 96000, 200
+    iq, bins, _ = synth.make_band(frames, rate, n, 4, seed=91)
+    edge = synth.default_edge_width(n)
+    bank = capi.Bank(rate, n, edge_width=edge, max_batch_frames=128, max_listeners=4, max_peaks=64)
+    bank.enable_results(True)
+    refs = []
+    for k, cf in enumerate((7000000, 14000000)):
+        bank.set_center_frequency(0, cf)
+        bank.process_host(iq[k * 100:(k + 1) * 100])
+        r = orc.Receiver(rate, n, edge, 15.0, 1, center_frequency=cf)
+        if k:
+            r.process(iq[:100])
+        refs.append(r.process(iq[k * 100:(k + 1) * 100])["peaks"][0])
+    bank.set_center_frequency(0, 21000000)  # after both batches, before either is polled
+    for k in range(2):
+        res = bank.poll(wait=True)
+        ch = res["chunks"][0]
+        got = [tuple(int(p[f]) if f != "signal_value" else float(p[f]) for f in
+                     ("from", "to", "from_frequency", "to_frequency", "signal_frequency", "signal_value", "signal_bin"))
+               for p in res["peaks"][ch["first_peak"]:ch["first_peak"] + ch["n_peaks"]]]
+        assert got == refs[k] and len(got) >= 1
+    bank.close()
