@@ -24,10 +24,13 @@
 
 namespace sdr {
 
-// Development aid (tools/fft_trace.hip).  SDR_FFT_TRACE: per-wave time stamps of one workgroup's phases.  The
-// stamps cost a third of the kernel's speed (every one waits for the scalar-memory counter LDS shares), so they
-// show the order of things, not their durations; durations come from SDR_FFT_CLOCK (per-workgroup spans, two
-// scalar loads per workgroup) and the SDR_ABLATE timing-only builds.
+// Development aids (tools/fft_bench.hip; none of this is compiled into the library).
+//  SDR_FFT_PHASES=<workgroup>: every wave of that one workgroup reads the shader clock (s_memtime) at each phase
+//    boundary into SGPRs - no wait, no store until the wave's last instruction - and writes the stamps out at the end;
+//    the other workgroups pay a scalar compare per stamp.  (Round 2 stamped through memory at every boundary, which
+//    cost a third of the kernel's speed; this costs under 1 %.)
+//  SDR_FFT_CLOCK: per-workgroup spans (first wave's start, last wave's end, where it ran) + the in-kernel clock.
+//  SDR_ABLATE=n: timing-only builds with one ingredient removed (results are wrong by construction).
 #if defined(SDR_FFT_CLOCK_LIB)
 // diagnostic LIBRARY build (tools/build_abl.sh fftclk "-DSDR_FFT_CLOCK -DSDR_FFT_CLOCK_LIB", tools/insitu_fft.py):
 // the per-workgroup spans of the FFT launches inside the running pipeline
@@ -38,16 +41,24 @@ extern "C" __attribute__((visibility("default"))) int sdr_debug_fft_wg(unsigned 
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fft_wg), sizeof(g_fft_wg));
 }
 #endif
-#if defined(SDR_FFT_TRACE)
-__shared__ int s_fft_trace_frame;  // which of the workgroup's frames is being stamped
-#define SDR_STAMP(k)                                                                                  \
-    do {                                                                                              \
-        if (blockIdx.x == SDR_FFT_TRACE && (threadIdx.x & 63) == 0)                                   \
-            g_fft_trace[s_fft_trace_frame & 1][threadIdx.x >> 6][k] = wall_clock64();                 \
+constexpr int kStampCount = 16;
+enum StampId { ST_START = 0, ST_LOADED = 1, ST_PASS0 = 2, ST_EX0 = 3, ST_PASS1 = 4, ST_EX1 = 5, ST_PASS2 = 6, ST_EX2 = 7,
+               ST_PASS3 = 8, ST_STORED = 10, ST_END = 11, ST_LANDED = 12, ST_ALL_LANDED = 13 };
+#if defined(SDR_FFT_PHASES)
+struct Stamps {
+    unsigned long long v[kStampCount];
+    bool on;
+};
+#define SDR_STAMP(st, k)                                \
+    do {                                                \
+        if ((st).on)                                    \
+            (st).v[k] = __builtin_amdgcn_s_memtime();   \
     } while (0)
 #else
-#define SDR_STAMP(k) \
-    do {             \
+struct Stamps {
+};
+#define SDR_STAMP(st, k) \
+    do {                 \
     } while (0)
 #endif
 
@@ -103,24 +114,71 @@ constexpr bool last_lds_exchange_is_cross()
     return last >= 0 && fft64::Plan<LOGN>::cross_wave(last);
 }
 
+// Twiddles of a pass's first stages are requested BEFORE the exchange in front of the pass (SDR_FFT_TWPRE rows of the
+// pass's twiddle block: 1 = stage 0, 3 = stages 0-1, 7 = stages 0-2): behind an exchange every wave of the
+// workgroup starts its pass at the same moment, and without this each of them sat out an L2 round trip there - the
+// fences of the exchange keep the compiler from hoisting the loads itself.  During the exchange only the 64 data
+// registers are live, so the rows cost no register the pass does not have anyway.
+#if !defined(SDR_FFT_TWPRE)
+#define SDR_FFT_TWPRE 1
+#endif
+template <int LOGN, int P>
+constexpr int tw_pre_rows()
+{
+    using PL = fft64::Plan<LOGN>;
+    // (a short last pass has several groups per thread with different twiddles each, and nothing but register swaps
+    // or nothing at all in front of it: left to the compiler)
+    if (P <= 0 || P >= PL::NPASS || PL::pass_log(P) != PL::LOGR)
+        return 0;
+    constexpr int rows = (1 << PL::LOGR) - 1;
+    return SDR_FFT_TWPRE < rows ? SDR_FFT_TWPRE : rows;
+}
+constexpr int kTwPreMax = 15;
+
+__device__ __forceinline__ fft64::cplx load_tw(rsrc_t tw, int lo, int c)
+{
+    const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(tw, (unsigned)lo * 16u, c * 16, 0);
+    fft64::cplx r;
+    r.x = __hiloint2double((int)w.y, (int)w.x);
+    r.y = __hiloint2double((int)w.w, (int)w.z);
+    return r;
+}
+
+template <int LOGN, int P>
+__device__ __forceinline__ void prefetch_tw(fft64::cplx (&pre)[kTwPreMax], int t, rsrc_t tw)
+{
+    using PL = fft64::Plan<LOGN>;
+    constexpr int NPRE = tw_pre_rows<LOGN, P>();
+    if constexpr (NPRE > 0) {
+        constexpr int S = 1 << (P * PL::LOGR);
+        const int lo = fft64::elem_index<LOGN, P>(t, 0, 0) & (S - 1);
+#pragma unroll
+        for (int r = 0; r < NPRE; r++)
+            pre[r] = load_tw(tw, lo, PL::tw_offset(P) + r * S);
+    }
+}
+
 template <int LOGN, int P, bool FRAME_FOLLOWS, class LdsFree>
 __device__ __forceinline__ void run_passes(double (&xr)[fft64::Plan<LOGN>::R], double (&xi)[fft64::Plan<LOGN>::R],
                                            int t, rsrc_t tw, const fft64::cplx *__restrict__ tw_ptr, double *lds,
-                                           LdsFree lds_free)
+                                           LdsFree lds_free, const fft64::cplx (&pre)[kTwPreMax], Stamps &st)
 {
     using PL = fft64::Plan<LOGN>;
 #if !(defined(SDR_ABLATE) && (SDR_ABLATE == 5))
-    fft64::butterfly_pass<LOGN, P>(xr, xi, t, [tw, tw_ptr](int c, int lo) {
+    fft64::butterfly_pass<LOGN, P>(xr, xi, t, [tw, tw_ptr, &pre](int c, int lo) {
         if constexpr (P == 0)
             return tw_ptr[c];  // pass 0: the same entry for every thread, a scalar load
-        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(tw, (unsigned)lo * 16u, c * 16, 0);
-        fft64::cplx r;
-        r.x = __hiloint2double((int)w.y, (int)w.x);
-        r.y = __hiloint2double((int)w.w, (int)w.z);
-        return r;
+        constexpr int S = 1 << (P * PL::LOGR);
+        const int row = (c - PL::tw_offset(P)) / S;  // (a constant once the pass is unrolled)
+        if (row < tw_pre_rows<LOGN, P>())
+            return pre[row];
+        return load_tw(tw, lo, c);
     });
 #endif
-    SDR_STAMP(2 + 2 * P);
+    fft64::cplx pre_next[kTwPreMax];
+    if constexpr (P < PL::NPASS - 1)
+        prefetch_tw<LOGN, P + 1>(pre_next, t, tw);
+    SDR_STAMP(st, 2 + 2 * P);
     if constexpr (P < PL::NPASS - 1) {
         if constexpr (fft64::make_swap_plan<LOGN>(P).ok) {
             // slot bits <-> lane bits 4/5 only: done in registers (fft_f64.h exchange_swap), no LDS
@@ -188,8 +246,8 @@ __device__ __forceinline__ void run_passes(double (&xr)[fft64::Plan<LOGN>::R], d
             if constexpr (!later_lds_exchange<LOGN>(P))
                 lds_free();
         }
-        SDR_STAMP(3 + 2 * P);
-        run_passes<LOGN, P + 1, FRAME_FOLLOWS>(xr, xi, t, tw, tw_ptr, lds, lds_free);
+        SDR_STAMP(st, 3 + 2 * P);
+        run_passes<LOGN, P + 1, FRAME_FOLLOWS>(xr, xi, t, tw, tw_ptr, lds, lds_free, pre_next, st);
     }
 }
 
@@ -212,7 +270,7 @@ __device__ __forceinline__ void store_psd(const double (&xr)[fft64::Plan<LOGN>::
     for (int s = 0; s < PL::R; s++) {
         const int sk = fft64::slot_part<LOGN, PL::NPASS - 1>(s) ^ (H & SLOT_MASK);
         const float p = (float)(xr[s] * xr[s] + xi[s] * xi[s]);
-#if defined(SDR_ABLATE) && (SDR_ABLATE == 6 || SDR_ABLATE == 7)
+#if defined(SDR_ABLATE) && (SDR_ABLATE == 6 || SDR_ABLATE == 7 || SDR_ABLATE == 16)
         if (p == 1234.5f)  // timing-only build: (almost) no stores
             pd[tk | sk] = p;
 #else
@@ -265,9 +323,12 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
     using PL = fft64::Plan<LOGN>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *lds = reinterpret_cast<double *>(smem);
-#if defined(SDR_FFT_TRACE)
-    if ((threadIdx.x & 63) == 0)
-        s_fft_trace_frame = 0;
+    Stamps st;
+#if defined(SDR_FFT_PHASES)
+    st.on = blockIdx.x == SDR_FFT_PHASES && blockIdx.y == 0;
+#pragma unroll
+    for (int k = 0; k < kStampCount; k++)
+        st.v[k] = 0;
 #endif
 #if defined(SDR_FFT_CLOCK)
     unsigned long long ck0 = 0, rt0 = 0;
@@ -275,7 +336,7 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
         ck0 = __builtin_amdgcn_s_memtime();
     rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    SDR_STAMP(0);
+    SDR_STAMP(st, ST_START);
     const float *__restrict__ iq = cur ? cur->iq : iq_arg;  // graph replay: the batch's input pointer lives in device memory
     const int frame0 = MULTI ? blockIdx.x * fpw : blockIdx.x;
     const int frame_end = MULTI ? min(frame0 + fpw, n_frames) : frame0 + 1;
@@ -284,7 +345,11 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
 
     // Frame -> LDS by LDS-DMA, one contiguous 1 KB row per wave instruction, shaped through the source address
     // (fft_f64.h "Input staging").  The staging image lives in the exchange area.
-    auto stage_frame = [&](int frame, int tid) {
+    auto stage_frame = [&](int frame, int tid, int part = 0) {
+#if defined(SDR_ABLATE) && (SDR_ABLATE == 15 || SDR_ABLATE == 16)
+        if (frame >= 0)  // timing-only build: no input DMA at all - what a perfectly hidden input would leave
+            return;
+#endif
         constexpr int ROWS_PER_WAVE = PL::R / 2;
         const int lane = tid & 63;
 #if defined(SDR_ABLATE) && (SDR_ABLATE == 8)
@@ -296,6 +361,8 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
         const rsrc_t xrs = make_rsrc(iq + fr * PL::N * 2, PL::N * 8u);
 #pragma unroll
         for (int j = 0; j < ROWS_PER_WAVE; j++) {
+            if ((part == 1 && j >= ROWS_PER_WAVE / 2) || (part == 2 && j < ROWS_PER_WAVE / 2))
+                continue;
             const int r = wave * ROWS_PER_WAVE + j;
             const int g = fft64::in_granule<LOGN>(lane, r);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void *)(smem + r * 1024), 16,
@@ -322,10 +389,6 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
 
 #pragma nounroll
     for (int frame = frame0; frame < frame_end; frame++) {
-#if defined(SDR_FFT_TRACE)
-        if ((threadIdx.x & 63) == 0)
-            s_fft_trace_frame = frame - frame0;  // (every wave writes the same value; its own lane 0 reads it back)
-#endif
         // (with more than one frame per workgroup everything derived from the thread id is loop-invariant and the
         // compiler would hoist - and spill - it: make the thread id opaque per frame)
         int t = threadIdx.x;
@@ -339,9 +402,9 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PL::R) : "memory");
-        SDR_STAMP(12);  // this wave's rows have landed
+        SDR_STAMP(st, ST_LANDED);  // this wave's rows have landed
         __syncthreads();
-        SDR_STAMP(13);  // everybody's have
+        SDR_STAMP(st, ST_ALL_LANDED);  // everybody's have
 
         double xr[PL::R], xi[PL::R];
         const int n_thread = fft64::input_sample<LOGN>(t, 0);
@@ -360,20 +423,21 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
             xi[m] = (double)v.y;
         }
         __syncthreads();  // everyone has its samples: the exchange area may be written again
-        SDR_STAMP(1);
+        SDR_STAMP(st, ST_LOADED);
         const bool more = MULTI && frame + 1 < frame_end;
         // (no scheduling pin around the DMA: the compiler keeps it behind the exchanges' LDS accesses and behind the
         // twiddle loads already issued, which it waits for with counted vmcnt; a "memory" pin cost 46 spills)
         // (LDS is written again after the last exchange in both variants - the next frame's staging or the tap's
         // copy of the psd row - so the exchange ends with its fence: a barrier when it crossed waves)
+        const fft64::cplx no_pre[kTwPreMax] = {};
         run_passes<LOGN, 0, true>(xr, xi, t, make_rsrc(tw, (unsigned)(PL::TW_TOTAL * sizeof(fft64::cplx))), tw, lds, [&] {
-            if constexpr (MULTI && SDR_FFT_DMA_AT == 0)
+            if constexpr (MULTI && (SDR_FFT_DMA_AT == 0 || SDR_FFT_DMA_AT == 2))
                 if (more)
-                    stage_frame(frame + 1, t);
-        });
-        if constexpr (MULTI && SDR_FFT_DMA_AT == 1)
+                    stage_frame(frame + 1, t, SDR_FFT_DMA_AT == 2 ? 1 : 0);
+        }, no_pre, st);
+        if constexpr (MULTI && (SDR_FFT_DMA_AT == 1 || SDR_FFT_DMA_AT == 2))
             if (more)
-                stage_frame(frame + 1, t);
+                stage_frame(frame + 1, t, SDR_FFT_DMA_AT == 2 ? 2 : 0);
         if constexpr (!MULTI && !last_lds_exchange_is_cross<LOGN>())
             if (lds_tap)
                 __syncthreads();  // a wave-local last exchange fences only its own wave; the row goes everywhere
@@ -385,7 +449,7 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
             if (n_tap > 0 && frame > frame0)
                 tap_frame(frame - 1);
         }
-        SDR_STAMP(10);
+        SDR_STAMP(st, ST_STORED);
     }
     if (lds_tap) {
         __syncthreads();  // the row is in LDS (and lds_bins has been for a long time)
@@ -400,10 +464,14 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
         __syncthreads();
         tap_frame(frame_end - 1);
     }
-#if defined(SDR_FFT_TRACE)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SDR_STAMP(st, ST_END);
+#if defined(SDR_FFT_PHASES)
+    if (st.on && (threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < kStampCount; k++)
+            g_fft_phases[threadIdx.x >> 6][k] = st.v[k];
+    }
 #endif
-    SDR_STAMP(11);
 #if defined(SDR_FFT_CLOCK)
     if (blockIdx.x == 100 && threadIdx.x == 0) {
         g_fft_clock[0] = __builtin_amdgcn_s_memtime() - ck0;

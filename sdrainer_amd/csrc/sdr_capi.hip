@@ -588,7 +588,10 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         SDR_ARM(sdr::K_LISTEN_DECODE);
         HIP_TRY(sdr::launch_pack_listen(b->slots.p, S.edges.p, S.edge_counts.p, b->text.p, b->text_frames.p, b->drops.p, b->res_layout, max_slots, B,
                                         S.res_host, stream_of(sdr::K_LISTEN_DECODE)));
-        HIP_TRY(hipEventRecord(S.res_listen, stream_of(sdr::K_LISTEN_DECODE)));
+        // (an event recorded inside a capture is an edge of the graph, not something the host can wait for: a
+        // replay's delivery events are recorded behind the launch, sdr_graph_launch)
+        if (!cap)
+            HIP_TRY(hipEventRecord(S.res_listen, stream_of(sdr::K_LISTEN_DECODE)));
     }
     SDR_DONE(sdr::K_LISTEN_DECODE);
 
@@ -629,7 +632,8 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         SDR_ARM(sdr::K_FIND_PEAKS);
         HIP_TRY(sdr::launch_pack_peaks(S.dev_peaks.p, S.peak_counts.p, cur, b->res_layout, b->find_peaks, n_frames, n_chunks, B,
                                        S.res_host, stream_of(sdr::K_FIND_PEAKS)));
-        HIP_TRY(hipEventRecord(S.res_peaks, stream_of(sdr::K_FIND_PEAKS)));
+        if (!cap)
+            HIP_TRY(hipEventRecord(S.res_peaks, stream_of(sdr::K_FIND_PEAKS)));
         if (!cap) {
             std::lock_guard<std::mutex> guard(b->res_mu);
             S.res_batch = b->batch_index;
@@ -1658,6 +1662,19 @@ int sdr_graph_launch(sdr_bank *b, const float *const *iq_dev)
         b->failed = true;
         return fail(SDR_ERR_HIP, std::string("hipGraphLaunch: ") + hipGetErrorString(e));
     }
+    // the replay's results are in the host blocks when the replay has finished on its stream: these are the events
+    // sdr_poll waits for (GPUTEST r03 caught polls returning the previous replay's blocks: the events recorded while
+    // capturing are graph edges, the host saw them as complete)
+    if (b->results_on)
+        for (int k = 0; k < RING; k++) {
+            e = hipEventRecord(b->set[k].res_listen, b->stream[S_FFT]);
+            if (e == hipSuccess)
+                e = hipEventRecord(b->set[k].res_peaks, b->stream[S_FFT]);
+            if (e != hipSuccess) {
+                b->failed = true;
+                return fail(SDR_ERR_HIP, std::string("hipEventRecord behind the replay: ") + hipGetErrorString(e));
+            }
+        }
     // the host's view of the carried state, batch by batch, as the eager path commits it
     std::lock_guard<std::mutex> guard(b->res_mu);
     for (int k = 0; k < RING; k++) {

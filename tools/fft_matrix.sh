@@ -1,16 +1,16 @@
 #!/bin/bash
-# Development aid: standalone k_fft_psd timings (binaries from tools/build_fft_tools.sh).
+# Development aid: standalone k_fft_psd runs of the binaries tools/build_tools.sh made (all of them, or those named).
+#   tools/fft_matrix.sh [out-file] [binary ...]     env FPWS="1 8" = SDR_FFT_FPW values to run each binary with
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-out=gpurun_out/fft_matrix.txt
+out=${1:-gpurun_out/fft_matrix.txt}; shift
+mkdir -p $(dirname $out)
 : > $out
-run() { # bin fpw frames [tap]
-  echo "== $1 FPW=$2 frames=$3 tap=${4:-256}" >> $out
-  SDR_TAP=${4:-256} SDR_TRACE_QUIET=${QUIET:-1} SDR_FFT_FPW=$2 timeout -k 5 60 tools/bin/$1 $3 >> $out 2>&1 || exit 1
-}
-for fpw in 1 2 4 8 16; do run ft_time1 $fpw 2048; done
-run ft_time1 8 2048 0
-run ft_time1 1 2048 0
-run ft_clock1 8 2048
-run ft_clock1 1 2048
-grep -E "^==|single|launches" $out | paste - - - - | awk '{print $2,$3,$4,$5,"| single",$11,"| 1str",$19,"| 2str",$27}'
-grep -A8 "ft_clock1" $out | grep -E "==|clock|span|lifetime|gap|XCC"
+bins="$@"
+[ -z "$bins" ] && bins=$(ls tools/bin | grep '^fb_')
+for b in $bins; do
+  for fpw in ${FPWS:-1}; do
+    echo "== $b FPW=$fpw" >> $out
+    SDR_FFT_FPW=$fpw timeout -k 5 90 tools/bin/$b ${FRAMES:-2048} ${LOGN:-14} ${BANDS:-1} >> $out 2>&1 || { echo "FAILED $b" >> $out; exit 1; }
+  done
+done
+grep -E "^==|psd hash|single launch|back to back" $out | paste - - - - | awk '{print $2, $3, "|", $6, "|", $12, $13, $14, $15, "| b2b", $23}'
