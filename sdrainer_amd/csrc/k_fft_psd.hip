@@ -96,7 +96,7 @@ template <int LOGN>
 constexpr bool later_lds_exchange(int e)
 {
     for (int k = e + 1; k < fft64::Plan<LOGN>::NPASS - 1; k++)
-        if (!fft64::make_swap_plan<LOGN>(k).ok)
+        if (fft64::make_reg_plan<LOGN>(k).n == 0)
             return true;
     return false;
 }
@@ -109,7 +109,7 @@ constexpr bool last_lds_exchange_is_cross()
 {
     int last = -1;
     for (int e = 0; e < fft64::Plan<LOGN>::NPASS - 1; e++)
-        if (!fft64::make_swap_plan<LOGN>(e).ok)
+        if (fft64::make_reg_plan<LOGN>(e).n == 0)
             last = e;
     return last >= 0 && fft64::Plan<LOGN>::cross_wave(last);
 }
@@ -122,6 +122,15 @@ constexpr bool last_lds_exchange_is_cross()
 #if !defined(SDR_FFT_TWPRE)
 #define SDR_FFT_TWPRE 1
 #endif
+#if !defined(SDR_FFT_TW_CHUNK)
+#define SDR_FFT_TW_CHUNK 0  // layout B: at most this many twiddle rows requested at a time (0: the compiler decides)
+#endif
+#if !defined(SDR_FFT_SCALAR_CHUNK)
+#define SDR_FFT_SCALAR_CHUNK 4
+#endif
+#if !defined(SDR_FFT_TWPRE_B)
+#define SDR_FFT_TWPRE_B 7  // layout B: rows of pass 2 requested before the next frame's LDS-DMA goes out (see k_fft_psd_b)
+#endif
 template <int LOGN, int P>
 constexpr int tw_pre_rows()
 {
@@ -130,6 +139,10 @@ constexpr int tw_pre_rows()
     // or nothing at all in front of it: left to the compiler)
     if (P <= 0 || P >= PL::NPASS || PL::pass_log(P) != PL::LOGR)
         return 0;
+    if (PL::LB && P == 1)
+        return 0;  // layout B: pass 1's twiddles depend on the wave only - scalar loads, nothing to pre-issue
+    if (PL::LB && P == 2)
+        return SDR_FFT_TWPRE_B < 15 ? SDR_FFT_TWPRE_B : 15;
     constexpr int rows = (1 << PL::LOGR) - 1;
     return SDR_FFT_TWPRE < rows ? SDR_FFT_TWPRE : rows;
 }
@@ -151,23 +164,40 @@ __device__ __forceinline__ void prefetch_tw(fft64::cplx (&pre)[kTwPreMax], int t
     constexpr int NPRE = tw_pre_rows<LOGN, P>();
     if constexpr (NPRE > 0) {
         constexpr int S = 1 << (P * PL::LOGR);
-        const int lo = fft64::elem_index<LOGN, P>(t, 0, 0) & (S - 1);
+        const int lo = fft64::tw_pos<LOGN, P>(t, 0);
 #pragma unroll
         for (int r = 0; r < NPRE; r++)
             pre[r] = load_tw(tw, lo, PL::tw_offset(P) + r * S);
     }
 }
 
-template <int LOGN, int P, bool FRAME_FOLLOWS, class LdsFree>
+// `hooks(E, after)` is called right before (after == false) and right after (after == true) exchange E: the
+// register-staged kernel hangs its tap and its store fence there.
+struct NoHooks {
+    __device__ __forceinline__ void operator()(int, bool) const {}
+};
+
+template <int LOGN, int P, bool FRAME_FOLLOWS, class LdsFree, class Hooks = NoHooks>
 __device__ __forceinline__ void run_passes(double (&xr)[fft64::Plan<LOGN>::R], double (&xi)[fft64::Plan<LOGN>::R],
                                            int t, rsrc_t tw, const fft64::cplx *__restrict__ tw_ptr, double *lds,
-                                           LdsFree lds_free, const fft64::cplx (&pre)[kTwPreMax], Stamps &st)
+                                           LdsFree lds_free, const fft64::cplx (&pre)[kTwPreMax], Stamps &st,
+                                           Hooks hooks = Hooks{})
 {
     using PL = fft64::Plan<LOGN>;
 #if !(defined(SDR_ABLATE) && (SDR_ABLATE == 5))
-    fft64::butterfly_pass<LOGN, P>(xr, xi, t, [tw, tw_ptr, &pre](int c, int lo) {
+    // (layout B, pass 1: the twiddle depends on the wave only - wave w owns the sub-problem "index bits 0-3 = w")
+    const int wave_u = __builtin_amdgcn_readfirstlane(t >> 6);
+    // (layout B keeps the next frame's samples in 32 registers: twiddle rows come four at a time, fft_f64.h)
+    // (scalar passes: a fence behind every few rows keeps the scalar loads from all being hoisted to the top of the
+    // pass, where their 60 SGPRs do not fit)
+    constexpr int CHUNK = !PL::LB ? 0 : (P <= 1 ? SDR_FFT_SCALAR_CHUNK : SDR_FFT_TW_CHUNK);
+    fft64::butterfly_pass<LOGN, P, CHUNK>(xr, xi, t, [tw, tw_ptr, &pre, wave_u](int c, int lo) {
         if constexpr (P == 0)
             return tw_ptr[c];  // pass 0: the same entry for every thread, a scalar load
+#if !defined(SDR_FFT_P1_VECTOR)
+        if constexpr (PL::LB && P == 1)
+            return tw_ptr[c + wave_u];  // scalar load (fft_f64.h tw_pos(t, 0) == wave here, checked by tests/emu)
+#endif
         constexpr int S = 1 << (P * PL::LOGR);
         const int row = (c - PL::tw_offset(P)) / S;  // (a constant once the pass is unrolled)
         if (row < tw_pre_rows<LOGN, P>())
@@ -175,16 +205,25 @@ __device__ __forceinline__ void run_passes(double (&xr)[fft64::Plan<LOGN>::R], d
         return load_tw(tw, lo, c);
     });
 #endif
+    // Layout B: pass 2's rows are requested two passes ahead - behind exchange 0, BEFORE lds_free() sends the next
+    // frame's LDS-DMA out (a vector load issued behind the DMA returns behind it, 5 us later) - and ride through pass 1,
+    // whose own twiddles are scalar: they arrive in `pre` at pass 1 and are handed on.
     fft64::cplx pre_next[kTwPreMax];
-    if constexpr (P < PL::NPASS - 1)
+    if constexpr (P < PL::NPASS - 1 && !(PL::LB && P <= 1))
         prefetch_tw<LOGN, P + 1>(pre_next, t, tw);
+    if constexpr (PL::LB && P == 1) {
+#pragma unroll
+        for (int r = 0; r < kTwPreMax; r++)
+            pre_next[r] = pre[r];
+    }
     SDR_STAMP(st, 2 + 2 * P);
     if constexpr (P < PL::NPASS - 1) {
-        if constexpr (fft64::make_swap_plan<LOGN>(P).ok) {
-            // slot bits <-> lane bits 4/5 only: done in registers (fft_f64.h exchange_swap), no LDS
+        hooks(P, false);
+        if constexpr (fft64::make_reg_plan<LOGN>(P).n > 0) {
+            // done in registers (fft_f64.h exchange_regs: v_permlane16/32_swap, ds_bpermute), no LDS memory
 #if !(defined(SDR_ABLATE) && (SDR_ABLATE == 14))
-            fft64::exchange_swap<LOGN, P>(xr);
-            fft64::exchange_swap<LOGN, P>(xi);
+            fft64::exchange_regs<LOGN, P>(xr);
+            fft64::exchange_regs<LOGN, P>(xi);
 #endif
         } else {
             // A wave-local exchange (fft_f64.h make_layout) only touches LDS words of the wave's own
@@ -234,20 +273,23 @@ __device__ __forceinline__ void run_passes(double (&xr)[fft64::Plan<LOGN>::R], d
                 rd(xi, lds);
             } else {
                 wr(xr, lds);
-                wr(xi, lds + PL::N);
+                wr(xi, lds + fft64::kExchangeWords<LOGN>);
                 sync();
                 rd(xr, lds);
-                rd(xi, lds + PL::N);
+                rd(xi, lds + fft64::kExchangeWords<LOGN>);
             }
             // reads done before a later exchange writes LDS again (other waves' words if CROSS)
             // ... or the next frame's staging does
             if constexpr (later_lds_exchange<LOGN>(P) || FRAME_FOLLOWS)
                 sync();
+            if constexpr (PL::LB && P == 0)
+                prefetch_tw<LOGN, 2>(pre_next, t, tw);
             if constexpr (!later_lds_exchange<LOGN>(P))
                 lds_free();
         }
         SDR_STAMP(st, 3 + 2 * P);
-        run_passes<LOGN, P + 1, FRAME_FOLLOWS>(xr, xi, t, tw, tw_ptr, lds, lds_free, pre_next, st);
+        hooks(P, true);
+        run_passes<LOGN, P + 1, FRAME_FOLLOWS>(xr, xi, t, tw, tw_ptr, lds, lds_free, pre_next, st, hooks);
     }
 }
 
@@ -381,7 +423,7 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
     };
     stage_frame(frame0, threadIdx.x);
     // one-frame workgroup: its listeners' bins into LDS (behind the exchange area) while the frame is on its way
-    int *lds_bins = reinterpret_cast<int *>(smem + PL::LDS_BYTES);
+    int *lds_bins = reinterpret_cast<int *>(smem + fft64::kLdsBytes<LOGN>);
     const bool lds_tap = !MULTI && n_tap > 0 && n_tap <= kMaxLdsTap;
     if (lds_tap)
         for (int l = threadIdx.x; l < n_tap; l += PL::T)
@@ -492,6 +534,187 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_fft_psd_b - layout B (N = 16384).  What it is built around: a CU takes in about 25 GB/s, so a frame's 128 KB need
+// 5 us to arrive, a third of the 15 us the frame's arithmetic and exchanges take - and in layout A that third is
+// spent waiting (tools/fft_bench, SDR_ABLATE=15: 0.115 ms per 2048 frames with the input wait removed, 0.168 with
+// it).  Two things keep layout A from fetching the next frame under the current one: its 128 KB of LDS are busy until
+// the last exchange, and a twiddle load issued behind an LDS-DMA returns behind it (vector memory operations retire
+// in order), so a DMA sent out in the second half of a frame stalls that half's twiddles.  Here
+//   * the cross-wave exchange comes first, right behind pass 0, and everything behind it stays in registers
+//     (v_permlane swaps and ds_bpermute lane rotations, fft_f64.h make_reg_plan): LDS is free for the next frame from a
+//     third of the way into the current one;
+//   * pass 1, which follows, loads its twiddles through the scalar cache (wave w owns the sub-problem "index bits 0-3
+//     = w"), and the first eleven rows of pass 2's twiddles are requested BEFORE the DMA goes out and ride through
+//     pass 1 in the registers scalar twiddles leave free: the first vector load behind the DMA is issued 5.5 us
+//     after it.
+// The staging image is wave-private: wave w fetches exactly the 1024 samples it will read (16 slots x 64 consecutive
+// samples: 512 contiguous bytes each), so no barrier stands between the DMA and the reads - only the wave's own
+// counted vmcnt.  A workgroup takes `fpw` consecutive frames.  Tap: frame f-1's bins are read back from its psd row
+// around the register exchange behind pass 1 of frame f (loads before it, stores behind it); the row is complete by
+// then: every wave waited for its own psd stores of frame f-1 (vmcnt at the top of frame f covers everything older
+// than them; the hook in front of the cross-wave exchange waits for the stores themselves) before the barriers of
+// frame f's cross-wave exchange, which lie in between.  The workgroup's last frame is tapped after a drain.
+// ---------------------------------------------------------------------------------------------
+template <int LOGN>
+__global__ __launch_bounds__(fft64::Plan<LOGN>::T, 4) void k_fft_psd_b(const float *__restrict__ iq_arg, const BatchCursor *__restrict__ cur,
+                                                                        const fft64::cplx *__restrict__ tw, float *__restrict__ psd,
+                                                                        int in_stride, int out_stride, int n_frames, int fpw,
+                                                                        const int *__restrict__ tap_bins, float *__restrict__ tap_out,
+                                                                        int n_tap, int tap_stride)
+{
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass needs the kernel's signature only; something in this body made it drop the
+                                     // stub without a diagnostic)
+    using PL = fft64::Plan<LOGN>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *lds = reinterpret_cast<double *>(smem);
+    Stamps st;
+#if defined(SDR_FFT_PHASES)
+    st.on = blockIdx.x == SDR_FFT_PHASES && blockIdx.y == 0;
+#pragma unroll
+    for (int k = 0; k < kStampCount; k++)
+        st.v[k] = 0;
+#endif
+#if defined(SDR_FFT_CLOCK)
+    unsigned long long ck0 = 0, rt0 = 0;
+    if (blockIdx.x == 100)
+        ck0 = __builtin_amdgcn_s_memtime();
+    rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    SDR_STAMP(st, ST_START);
+    const float *__restrict__ iq = cur ? cur->iq : iq_arg;
+    const int frame0 = blockIdx.x * fpw;
+    const int frame_end = min(frame0 + fpw, n_frames);
+    const size_t in_band = (size_t)blockIdx.y * in_stride, out_band = (size_t)blockIdx.y * out_stride;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int kBlock = PL::R * 64 * 8;  // bytes of staging per wave: its 16 slots x 64 samples
+    // Frame -> this wave's staging block by LDS-DMA.  Instruction j fills slots 2j (lanes 0-31) and 2j+1 (lanes
+    // 32-63), 16 bytes = two consecutive samples per lane; block layout [slot][lane], 8 bytes each.
+    auto stage_frame = [&](int frame) {
+#if defined(SDR_ABLATE) && (SDR_ABLATE == 15 || SDR_ABLATE == 16)
+        if (frame >= 0)  // timing-only build: no input DMA at all
+            return;
+#endif
+#if defined(SDR_ABLATE) && (SDR_ABLATE == 8)
+        const size_t fr = (in_band + frame) & 15;  // timing-only: 16 frames, L2-resident
+#else
+        const size_t fr = in_band + frame;
+#endif
+        const rsrc_t xrs = make_rsrc(iq + fr * PL::N * 2, PL::N * 8u);
+        const int lane = tid & 63;
+        // sample of (lane 2g, this wave, slot h): the slot's odd bit h = lane >> 5 selects sample bit 13
+        const unsigned voff = (unsigned)(fft64::input_sample<LOGN>((tid & ~63) | (2 * (lane & 31)), 0) + ((lane >> 5) ? fft64::input_slot_sample<LOGN>(1) : 0)) * 8u;
+#pragma unroll
+        for (int j = 0; j < PL::R / 2; j++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void *)(smem + wave * kBlock + j * 1024), 16,
+                                                     voff, fft64::input_slot_sample<LOGN>(2 * j) * 8, 0, SDR_FFT_DMA_AUX);
+    };
+    const rsrc_t twr = make_rsrc(tw, (unsigned)(PL::TW_TOTAL * sizeof(fft64::cplx)));
+    const int *bins = tap_bins + (size_t)blockIdx.y * tap_stride;
+    const bool reg_tap = n_tap > 0 && n_tap <= PL::T;  // one listener per thread in registers; more take the plain loop
+    const int my_bin = (reg_tap && tid < n_tap) ? bins[tid] : -1;
+    float tap_val = 0.f;
+    auto tap_frame_slow = [&](int frame) {
+        const float *row = psd + (out_band + frame) * PL::N;
+        float *out = tap_out + (out_band + frame) * (size_t)tap_stride;
+        for (int l = tid; l < n_tap; l += PL::T) {
+            const int bin = bins[l];
+            out[l] = bin >= 0 ? row[bin] : 0.0f;
+        }
+    };
+    if (frame0 < frame_end)
+        stage_frame(frame0);
+#pragma nounroll
+    for (int frame = frame0; frame < frame_end; frame++) {
+        // (everything derived from the thread id - twiddle positions, store offsets - is loop-invariant and the
+        // compiler would hoist it out of the frame loop into registers it does not have: opaque per frame)
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        // this wave's DMA: the first frame's is its only traffic; a later one is older than the previous frame's R psd
+        // stores, and vector memory operations retire in order
+        if (frame == frame0)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PL::R) : "memory");
+        SDR_STAMP(st, ST_LANDED);
+        double xr[PL::R], xi[PL::R];
+        {
+            const unsigned char *blk = smem + wave * kBlock + (t & 63) * 8;
+#pragma unroll
+            for (int m = 0; m < PL::R; m++) {  // dsp/fft.go:59-69 setSamplesFromIQ
+#if defined(SDR_ABLATE) && (SDR_ABLATE == 1 || SDR_ABLATE == 7)
+                const float2 v = make_float2(1e-3f * (float)(t + m), 0.5f);  // timing-only build: no input
+#else
+                const float2 v = *reinterpret_cast<const float2 *>(blk + m * 512);
+#endif
+                xr[m] = (double)v.x;
+                xi[m] = (double)v.y;
+            }
+        }
+        SDR_STAMP(st, ST_LOADED);
+        const bool more = frame + 1 < frame_end;
+        const bool tap_prev = n_tap > 0 && frame > frame0;
+        const fft64::cplx no_pre[kTwPreMax] = {};
+        run_passes<LOGN, 0, true>(
+            xr, xi, t, twr, tw, lds,
+            [&] {  // the cross-wave exchange is over (its last barrier passed): LDS belongs to the next frame
+                if (more)
+                    stage_frame(frame + 1);
+            },
+            no_pre, st,
+            [&](int e, bool after) {
+                if (e == 0 && !after) {
+                    // this wave's psd stores of the previous frame have completed before the barrier that follows
+                    if (frame > frame0)
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if (e == 1 && tap_prev && reg_tap) {
+                    if (!after) {
+                        const float *row = psd + (out_band + frame - 1) * PL::N;
+                        tap_val = my_bin >= 0 ? __builtin_nontemporal_load(row + my_bin) : 0.0f;
+                    } else if (tid < n_tap) {
+                        tap_out[(out_band + frame - 1) * (size_t)tap_stride + tid] = tap_val;
+                    }
+                }
+            });
+        store_psd<LOGN, false>(xr, xi, t, psd + (out_band + frame) * PL::N, smem, false);
+        if (tap_prev && !reg_tap)
+            tap_frame_slow(frame - 1);
+        SDR_STAMP(st, ST_STORED);
+    }
+    if (n_tap > 0 && frame_end > frame0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        tap_frame_slow(frame_end - 1);
+    }
+    SDR_STAMP(st, ST_END);
+#if defined(SDR_FFT_PHASES)
+    if (st.on && (threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < kStampCount; k++)
+            g_fft_phases[threadIdx.x >> 6][k] = st.v[k];
+    }
+#endif
+#if defined(SDR_FFT_CLOCK)
+    if (blockIdx.x == 100 && threadIdx.x == 0) {
+        g_fft_clock[0] = __builtin_amdgcn_s_memtime() - ck0;
+        g_fft_clock[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) {
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0) {
+            g_fft_wg[blockIdx.x][0] = rt0;
+            g_fft_wg[blockIdx.x][1] = now;
+            g_fft_wg[blockIdx.x][3] = __builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11)) |
+                                      ((unsigned long long)__builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (3 << 11)) << 32);
+        }
+        atomicMax(&g_fft_wg[blockIdx.x][2], now);
+    }
+#endif
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
 // Tuning knob, read once per process: SDR_FFT_FPW = frames per workgroup.
 // (LDS behind the exchange area: the one-frame workgroup's copy of its listeners' bins)
 constexpr int kDefaultFpw = 1;  // in the pipeline short-lived workgroups win: 0.250 (1) / 0.253 (2) / 0.291 (4) / 0.294 ms (8) per step, standalone the other way round (0.174 / 0.166 / 0.165 / 0.164 ms)
@@ -506,11 +729,49 @@ static int fft_fpw()
     return v;
 }
 
+// frames per workgroup of the layout B kernel: SDR_FFT_FPW overrides
+constexpr int kDefaultFpwB = 8;
+static int fft_fpw_b()
+{
+    static const int v = [] {
+        if (const char *e = getenv("SDR_FFT_FPW"))
+            return std::max(1, std::min(atoi(e), 64));
+        return kDefaultFpwB;
+    }();
+    return v;
+}
+
 template <int LOGN>
 static hipError_t launch_fft_t(const float *iq, const BatchCursor *cur, const fft64::cplx *tw, float *psd, int n_frames,
                                int n_bands, int in_stride, int out_stride, FftTap tap, hipStream_t stream)
 {
     using PL = fft64::Plan<LOGN>;
+    if constexpr (PL::LB) {
+        static std::once_flag b_attr_once[kMaxDevices];
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess)
+            return e;
+        if (dev < 0 || dev >= kMaxDevices)
+            return hipErrorInvalidDevice;
+        hipError_t attr_err = hipSuccess;
+        std::call_once(b_attr_once[dev], [&] {
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_psd_b<LOGN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           fft64::kLdsBytes<LOGN>);
+        });
+        if (attr_err != hipSuccess)
+            return attr_err;
+        if (n_frames <= 0 || n_bands <= 0)
+            return hipSuccess;
+        // a workgroup's frames are consecutive (the next one is prefetched under the current one's first passes);
+        // never fewer workgroups than the chip has CUs
+        int fpw = fft_fpw_b();
+        while (fpw > 1 && (long)((n_frames + fpw - 1) / fpw) * n_bands < 256)
+            fpw /= 2;
+        launch_kernel((k_fft_psd_b<LOGN>), dim3((n_frames + fpw - 1) / fpw, n_bands), dim3(PL::T), fft64::kLdsBytes<LOGN>, stream, iq, cur, tw, psd,
+                      in_stride, out_stride, n_frames, fpw, tap.bins, tap.out, tap.n, tap.stride);
+        return hipGetLastError();
+    } else {
     // the > 64 KB dynamic LDS attribute is per device: set it once on each device a bank launches on
     static std::once_flag attr_once[kMaxDevices];
     int dev = 0;
@@ -523,7 +784,7 @@ static hipError_t launch_fft_t(const float *iq, const BatchCursor *cur, const ff
     std::call_once(attr_once[dev], [&] {
         for (const void *k : {reinterpret_cast<const void *>(&k_fft_psd<LOGN, false>),
                               reinterpret_cast<const void *>(&k_fft_psd<LOGN, true>)}) {
-            const hipError_t ae = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, PL::LDS_BYTES + kMaxLdsTap * 4);
+            const hipError_t ae = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, fft64::kLdsBytes<LOGN> + kMaxLdsTap * 4);
             if (ae != hipSuccess)
                 attr_err = ae;
         }
@@ -538,13 +799,14 @@ static hipError_t launch_fft_t(const float *iq, const BatchCursor *cur, const ff
     while (fpw > 1 && (long)((n_frames + fpw - 1) / fpw) * n_bands < 256)
         fpw /= 2;
     if (fpw > 1)
-        launch_kernel((k_fft_psd<LOGN, true>), dim3((n_frames + fpw - 1) / fpw, n_bands), dim3(PL::T), PL::LDS_BYTES, stream,
+        launch_kernel((k_fft_psd<LOGN, true>), dim3((n_frames + fpw - 1) / fpw, n_bands), dim3(PL::T), fft64::kLdsBytes<LOGN>, stream,
                            iq, cur, tw, psd, in_stride, out_stride, n_frames, fpw, tap.bins, tap.out, tap.n, tap.stride);
     else
         launch_kernel((k_fft_psd<LOGN, false>), dim3(n_frames, n_bands), dim3(PL::T),
-                           PL::LDS_BYTES + (tap.n > 0 && tap.n <= kMaxLdsTap ? tap.n * 4 : 0), stream, iq, cur, tw, psd, in_stride,
+                           fft64::kLdsBytes<LOGN> + (tap.n > 0 && tap.n <= kMaxLdsTap ? tap.n * 4 : 0), stream, iq, cur, tw, psd, in_stride,
                            out_stride, n_frames, 1, tap.bins, tap.out, tap.n, tap.stride);
     return hipGetLastError();
+    }
 }
 
 hipError_t launch_fft(int logn, const float *iq, const BatchCursor *cur, const fft64::cplx *tw, float *psd, int n_frames,

@@ -33,11 +33,11 @@ struct Passes {
                                     [tw](int c, int lo) { return tw[c + lo]; });
         if (P < PL::NPASS - 1) {
             constexpr int E = (P < PL::NPASS - 1 ? P : 0);
-            if constexpr (make_swap_plan<LOGN>(E).ok) {
-                // register exchange (v_permlane16/32_swap on the GPU): modelled wave by wave
+            if constexpr (make_reg_plan<LOGN>(E).n > 0) {
+                // register exchange (v_permlane16/32_swap and ds_bpermute on the GPU): modelled wave by wave
                 for (int t0 = 0; t0 < PL::T; t0 += 64) {
-                    exchange_swap_wave<LOGN, E>(reinterpret_cast<double (*)[PL::R]>(&xr[(size_t)t0 * PL::R]));
-                    exchange_swap_wave<LOGN, E>(reinterpret_cast<double (*)[PL::R]>(&xi[(size_t)t0 * PL::R]));
+                    exchange_regs_wave<LOGN, E>(reinterpret_cast<double (*)[PL::R]>(&xr[(size_t)t0 * PL::R]));
+                    exchange_regs_wave<LOGN, E>(reinterpret_cast<double (*)[PL::R]>(&xi[(size_t)t0 * PL::R]));
                 }
             } else {
             // LDS starts each exchange poisoned, so a read of a word nobody wrote yet cannot pass
@@ -54,8 +54,8 @@ struct Passes {
                     // a wave-local exchange stays inside the wave's own block of words
                     if (!PL::cross_wave(E))
                         for (int s = 0; s < PL::R; s++) {
-                            const int a = lds_addr<LOGN, E>(thread_part<LOGN, E>(t)) ^ lds_addr<LOGN, E>(slot_part<LOGN, E>(s));
-                            if (a / (PL::N / (PL::T / 64)) != t / 64) {
+                            const int a = lds_addr<LOGN, E>(thread_part<LOGN, E>(t)) + lds_addr<LOGN, E>(slot_part<LOGN, E>(s));
+                            if (a / make_addr<LOGN>(E).block != t / 64) {
                                 printf("LOGN=%d exchange %d: thread %d writes outside its wave's block\n", LOGN, E, t);
                                 exit(1);
                             }
@@ -90,7 +90,7 @@ static void audit(int *worst_write, int *worst_read)
         for (int t0 = 0; t0 < PL::T; t0 += 16) {
             int cnt[16] = {};
             for (int t = t0; t < t0 + 16; t++) {
-                const int a = lds_addr<LOGN, E>(thread_part<LOGN, E>(t)) ^ lds_addr<LOGN, E>(slot_part<LOGN, E>(s));
+                const int a = lds_addr<LOGN, E>(thread_part<LOGN, E>(t)) + lds_addr<LOGN, E>(slot_part<LOGN, E>(s));
                 *worst_write = std::max(*worst_write, ++cnt[a % 16]);
             }
         }
@@ -98,7 +98,7 @@ static void audit(int *worst_write, int *worst_read)
         for (int t0 = 0; t0 < PL::T; t0 += 32) {
             int cnt[32] = {};
             for (int t = t0; t < t0 + 32; t++) {
-                const int a = lds_addr<LOGN, E>(thread_part<LOGN, E + 1>(t)) ^ lds_addr<LOGN, E>(slot_part<LOGN, E + 1>(s));
+                const int a = lds_addr<LOGN, E>(thread_part<LOGN, E + 1>(t)) + lds_addr<LOGN, E>(slot_part<LOGN, E + 1>(s));
                 *worst_read = std::max(*worst_read, ++cnt[a % 32]);
             }
         }
@@ -110,9 +110,18 @@ struct Audit {
     {
         int w, r, rc = 0;
         audit<LOGN, E>(&w, &r);
-        if (make_swap_plan<LOGN>(E).ok) {
-            printf("LOGN=%d exchange %d: in registers (lane bit 4 <-> slot bit %d, lane bit 5 <-> slot bit %d)\n", LOGN, E,
-                   make_swap_plan<LOGN>(E).slot_bit_lane4, make_swap_plan<LOGN>(E).slot_bit_lane5);
+        if (make_reg_plan<LOGN>(E).n > 0) {
+            printf("LOGN=%d exchange %d: in registers:", LOGN, E);
+            for (int i = 0; i < make_reg_plan<LOGN>(E).n; i++) {
+                const RegStep st = make_reg_plan<LOGN>(E).st[i];
+                if (st.rot)
+                    printf(" rotate lane bits (%d,%d)<->(4,5);", st.a, st.a + 1);
+                else
+                    printf(" swap slot bit %d<->lane bit 4, slot bit %d<->lane bit 5;", st.a, st.b);
+            }
+            printf(" plan %s\n", reg_plan_valid<LOGN>(E) ? "valid" : "INVALID");
+            if (!reg_plan_valid<LOGN>(E))
+                rc = 1;
         } else {
             printf("LOGN=%d exchange %d (%s): worst write %d-way, worst read %d-way\n", LOGN, E,
                    Plan<LOGN>::cross_wave(E) ? "cross-wave" : "wave-local", w, r);
@@ -130,6 +139,19 @@ template <int LOGN>
 static int audit_loads()
 {
     using PL = Plan<LOGN>;
+    if (PL::LB) {
+        // layout B loads the frame straight from memory: the 64 lanes of a wave must read 64 consecutive samples
+        // (512 contiguous bytes per wave instruction) for every register slot
+        for (int m = 0; m < PL::R; m++)
+            for (int t0 = 0; t0 < PL::T; t0 += 64)
+                for (int t = t0; t < t0 + 64; t++)
+                    if (input_sample<LOGN>(t, m) != input_sample<LOGN>(t0, m) + (t - t0)) {
+                        printf("LOGN=%d (layout B): wave %d slot %d does not load 64 consecutive samples\n", LOGN, t0 / 64, m);
+                        return 1;
+                    }
+        printf("LOGN=%d (layout B): every wave loads 512 contiguous bytes per slot\n", LOGN);
+        return 0;
+    }
     for (int m = 0; m < PL::R; m++)
         for (int t0 = 0; t0 < PL::T; t0 += 4)
             for (int t = t0; t < t0 + 4; t++)
@@ -184,6 +206,38 @@ static int audit_staging()
     return worst > 1;
 }
 
+// Twiddle rows (fft_f64.h make_tw_perm): tw_pos_of_lo is a bijection of [0, S), the position a thread computes from
+// its id agrees with it, and the lanes 0-15 of a wave read consecutive entries wherever index bits sit in lanes.
+template <int LOGN, int P>
+static int audit_tw_rows()
+{
+    using PL = Plan<LOGN>;
+    if constexpr (P < PL::NPASS) {
+        constexpr int S = 1 << (P * PL::LOGR);
+        constexpr int G = PL::R >> PL::pass_log(P);
+        std::vector<char> seen((size_t)S, 0);
+        for (int lo = 0; lo < S; lo++) {
+            const int p = tw_pos_of_lo<LOGN, P>(lo);
+            if (p < 0 || p >= S || seen[p]) {
+                printf("LOGN=%d pass %d: tw_pos_of_lo is not a bijection\n", LOGN, P);
+                return 1;
+            }
+            seen[p] = 1;
+        }
+        for (int t = 0; t < PL::T; t++)
+            for (int u = 0; u < G; u++) {
+                const int lo = elem_index<LOGN, P>(t, u, 0) & (S - 1);
+                if (tw_pos<LOGN, P>(t, u) != tw_pos_of_lo<LOGN, P>(lo)) {
+                    printf("LOGN=%d pass %d: thread %d group %d computes position %d, the table has it at %d\n", LOGN, P, t, u,
+                           tw_pos<LOGN, P>(t, u), tw_pos_of_lo<LOGN, P>(lo));
+                    return 1;
+                }
+            }
+        return audit_tw_rows<LOGN, P + 1>();
+    }
+    return 0;
+}
+
 template <int LOGN>
 static int check(orc_iq_fft_t orc_fft, orc_factors_t orc_fac, unsigned seed)
 {
@@ -210,7 +264,7 @@ static int check(orc_iq_fft_t orc_fft, orc_factors_t orc_fac, unsigned seed)
     std::vector<cplx> tw((size_t)PL::TW_TOTAL);
     build_pass_twiddles<LOGN>(wre.data(), wim.data(), tw.data());
 
-    std::vector<double> xr((size_t)N), xi((size_t)N), lre((size_t)N), lim((size_t)N);
+    std::vector<double> xr((size_t)N), xi((size_t)N), lre((size_t)exchange_words<LOGN>()), lim((size_t)exchange_words<LOGN>());
     for (int t = 0; t < PL::T; t++)
         load_input<LOGN>(iq.data(), t, &xr[(size_t)t * PL::R], &xi[(size_t)t * PL::R]);
     Passes<LOGN, 0>::run(xr, xi, tw.data(), lre, lim);
@@ -245,7 +299,10 @@ static int check(orc_iq_fft_t orc_fft, orc_factors_t orc_fac, unsigned seed)
     int rc = bad != 0;
     rc |= Audit<LOGN, 0>::run();
     rc |= audit_loads<LOGN>();
-    rc |= audit_staging<LOGN>();
+    if (!PL::LB)
+        rc |= audit_staging<LOGN>();
+    // twiddle rows: the positions the threads of a pass read must be a permutation of the row
+    rc |= audit_tw_rows<LOGN, 1>();
     return rc;
 }
 
