@@ -35,8 +35,16 @@ struct cplx {
 //     Pass 0's lanes are the six lowest sample-number bits, so a wave loads 512 contiguous bytes per register slot
 //     straight from memory - no LDS staging, the next frame is prefetched into registers - and pass 1's twiddles depend
 //     on the wave only (scalar loads).  Needs the wave id to cover a whole pass's worth of bits (WB == LOGR): N = 16384.
+//     MEASURED (round 3, tools/fft_bench, 2048 frames of 16384): bit-identical, but no faster - 0.168 ms per launch
+//     against layout A's 0.165.  What it gains (the next frame's LDS-DMA under passes 1-2: A loses 0.050 ms to the input
+//     wait, B 0.032) it pays back: the register-only exchanges (+128 v_permlane, 128 ds_bpermute per wave), a
+//     transposed epilogue through LDS (wave w holds the bins = w mod 16; stored from registers they cost 0.087 ms)
+//     and waves that drift apart over the long barrier-free stretch.  And its workgroups must take several frames
+//     each, which starves the tail stages of CUs inside the pipeline (0.273 ms per step against 0.216).  So it is
+//     OFF by default (SDR_FFT_LAYOUT_B_FROM = 15 selects no size); -DSDR_FFT_LAYOUT_B_FROM=14 builds it, tests/emu
+//     checks both layouts on the CPU.
 #if !defined(SDR_FFT_LAYOUT_B_FROM)
-#define SDR_FFT_LAYOUT_B_FROM 14
+#define SDR_FFT_LAYOUT_B_FROM 15
 #endif
 SDR_HD constexpr bool layout_b(int logn) { return logn >= SDR_FFT_LAYOUT_B_FROM; }
 

@@ -534,6 +534,61 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
 #endif
 }
 
+// Epilogue of layout B (dsp/fft.go:54-57 fftshift, :71-73 PSD[float32]).  Wave w holds the bins = w (mod 16): stored
+// from the registers, a wave instruction would put 64 four-byte words into 64 different 64-byte segments of the row
+// (measured: 0.087 of the kernel's 0.21 ms).  So the row goes through a 32 KB tile of LDS - the part the next frame's
+// staging image leaves free - half a row at a time: every thread drops its eight values of the half (ds_write_b32, the
+// slot part of the address in the offset field; an XOR swizzle of address bits 0-3 with bits 5-8 keeps both sides
+// free of bank conflicts), and behind a barrier picks up two runs of four consecutive bins (ds_read_b128; the swizzle
+// permutes the four words by a per-thread constant, undone with v_cndmask) and stores them 16 bytes per lane, 1 KB
+// contiguous per wave instruction.
+template <int LOGN>
+__device__ __forceinline__ void store_psd_b(const double (&xr)[fft64::Plan<LOGN>::R], const double (&xi)[fft64::Plan<LOGN>::R], int t,
+                                            float *__restrict__ pd, unsigned char *tile)
+{
+    using PL = fft64::Plan<LOGN>;
+    constexpr int H = PL::N / 2;
+    constexpr int LAST = PL::NPASS - 1;
+    static_assert(PL::T * 8 == PL::N / 2 && PL::N * 2 == 32768, "tile = half a row = 32 KB, eight bins per thread");
+    const int tp = fft64::thread_part<LOGN, LAST>(t);  // (bits 0..9 here: wave and lanes)
+    const unsigned x = ((unsigned)tp >> 5) & 15u;
+    const unsigned wbase = (((unsigned)tp & (unsigned)(H - 1)) ^ x) * 4u;
+    const rsrc_t pdr = make_rsrc(pd, PL::N * 4u);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        if (h)
+            __syncthreads();  // everybody has read the first half out of the tile
+#pragma unroll
+        for (int s = 0; s < PL::R; s++) {
+            const int sp = fft64::slot_part<LOGN, LAST>(s);
+            const int k_hi = ((sp ^ H) >> (LOGN - 1)) & 1;  // which half of the shifted row this slot's bin lands in
+            if (k_hi != h)
+                continue;
+            const float p = (float)(xr[s] * xr[s] + xi[s] * xi[s]);
+            *reinterpret_cast<float *>(tile + wbase + (unsigned)((sp & (H - 1)) * 4)) = p;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int part = 0; part < 2; part++) {
+            const unsigned a0 = 4u * (unsigned)t + (unsigned)(part * (H / 2));  // first of this thread's four bins (within the half)
+            const unsigned xr4 = (a0 >> 5) & 15u;
+            const float4 u = *reinterpret_cast<const float4 *>(tile + (((a0 ^ xr4) & ~3u) * 4u));
+            // word i of the read holds bin a0 + (i ^ (xr4 & 3))
+            const bool s1 = xr4 & 1u, s2 = xr4 & 2u;
+            const float a = s1 ? u.y : u.x, b = s1 ? u.x : u.y, c = s1 ? u.w : u.z, d = s1 ? u.z : u.w;
+            u32x4 v;
+            v.x = __float_as_uint(s2 ? c : a);
+            v.y = __float_as_uint(s2 ? d : b);
+            v.z = __float_as_uint(s2 ? a : c);
+            v.w = __float_as_uint(s2 ? b : d);
+#if defined(SDR_ABLATE) && (SDR_ABLATE == 6 || SDR_ABLATE == 7 || SDR_ABLATE == 16)
+            if (v.x == 0x449a5000u)  // timing-only build: (almost) no stores
+#endif
+            __builtin_amdgcn_raw_buffer_store_b128(v, pdr, a0 * 4u, h * (H * 4), SDR_FFT_PSD_AUX);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_fft_psd_b - layout B (N = 16384).  What it is built around: a CU takes in about 25 GB/s, so a frame's 128 KB need
 // 5 us to arrive, a third of the 15 us the frame's arithmetic and exchanges take - and in layout A that third is
@@ -589,6 +644,7 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, 4) void k_fft_psd_b(const flo
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int kBlock = PL::R * 64 * 8;  // bytes of staging per wave: its 16 slots x 64 samples
+    constexpr int kStageBytes = PL::N * 8;  // the staging image; the epilogue's 32 KB tile sits behind it
     // Frame -> this wave's staging block by LDS-DMA.  Instruction j fills slots 2j (lanes 0-31) and 2j+1 (lanes
     // 32-63), 16 bytes = two consecutive samples per lane; block layout [slot][lane], 8 bytes each.
     auto stage_frame = [&](int frame) {
@@ -678,7 +734,7 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, 4) void k_fft_psd_b(const flo
                     }
                 }
             });
-        store_psd<LOGN, false>(xr, xi, t, psd + (out_band + frame) * PL::N, smem, false);
+        store_psd_b<LOGN>(xr, xi, t, psd + (out_band + frame) * PL::N, smem + kStageBytes);
         if (tap_prev && !reg_tap)
             tap_frame_slow(frame - 1);
         SDR_STAMP(st, ST_STORED);
@@ -729,6 +785,12 @@ static int fft_fpw()
     return v;
 }
 
+// LDS of the layout B kernel: the cross-wave exchange's (padded) area, or the staging image plus the epilogue's tile
+template <int LOGN>
+inline constexpr int kLdsBytesB = fft64::kLdsBytes<LOGN> > fft64::Plan<LOGN>::N * 8 + fft64::Plan<LOGN>::N * 2
+                                      ? fft64::kLdsBytes<LOGN>
+                                      : fft64::Plan<LOGN>::N * 8 + fft64::Plan<LOGN>::N * 2;
+
 // frames per workgroup of the layout B kernel: SDR_FFT_FPW overrides
 constexpr int kDefaultFpwB = 8;
 static int fft_fpw_b()
@@ -757,7 +819,7 @@ static hipError_t launch_fft_t(const float *iq, const BatchCursor *cur, const ff
         hipError_t attr_err = hipSuccess;
         std::call_once(b_attr_once[dev], [&] {
             attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_psd_b<LOGN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           fft64::kLdsBytes<LOGN>);
+                                           kLdsBytesB<LOGN>);
         });
         if (attr_err != hipSuccess)
             return attr_err;
@@ -768,7 +830,7 @@ static hipError_t launch_fft_t(const float *iq, const BatchCursor *cur, const ff
         int fpw = fft_fpw_b();
         while (fpw > 1 && (long)((n_frames + fpw - 1) / fpw) * n_bands < 256)
             fpw /= 2;
-        launch_kernel((k_fft_psd_b<LOGN>), dim3((n_frames + fpw - 1) / fpw, n_bands), dim3(PL::T), fft64::kLdsBytes<LOGN>, stream, iq, cur, tw, psd,
+        launch_kernel((k_fft_psd_b<LOGN>), dim3((n_frames + fpw - 1) / fpw, n_bands), dim3(PL::T), kLdsBytesB<LOGN>, stream, iq, cur, tw, psd,
                       in_stride, out_stride, n_frames, fpw, tap.bins, tap.out, tap.n, tap.stride);
         return hipGetLastError();
     } else {

@@ -354,18 +354,23 @@ def test_kernel_decoder_loop_matches_literal_ticks(tmp_path):
     assert "mismatches 0" in out.stdout and " 0 runes" not in out.stdout
 
 
-def test_fft_phase_functions_match_oracle_bit_for_bit(tmp_path):
+@pytest.mark.parametrize("layout_b_from", [15, 14])
+def test_fft_phase_functions_match_oracle_bit_for_bit(tmp_path, layout_b_from):
     """The register/LDS index math and per-pass twiddle layout of the FFT kernel (fft_f64.h), emulated
-    thread by thread on the CPU, against the oracle's stage-by-stage radix-2 FFT for every block size."""
+    thread by thread on the CPU, against the oracle's stage-by-stage radix-2 FFT for every block size: LDS exchanges
+    (padded additive address maps, bank-conflict audit), register exchanges (permlane swaps, lane rotations), twiddle
+    rows in thread order, input staging.  Both layouts: A (shipped, all sizes) and B (experimental, N = 16384:
+    cross-wave exchange first, registers only behind it)."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path / "emu_fft")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-o", exe,
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", f"-DSDR_FFT_LAYOUT_B_FROM={layout_b_from}", "-o", exe,
                            os.path.join(root, "tests", "emu", "emu_fft.cpp"), "-ldl"])
     out = subprocess.run([exe, orc.build()], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count(": 0 mismatches") == 6
+    assert ("layout B" in out.stdout) == (layout_b_from <= 14)
 
 
 def test_kiwi_iq_bytes_decode():
