@@ -22,15 +22,17 @@ namespace sdr {
 
 // One lane per listener slot, one wave per 64 frames: lane l reads tap[f][l] for the wave's frames (the FFT kernel
 // wrote the psd value of the slot's bin there, k_fft_psd.hip "The tap"; neighbouring lanes read neighbouring
-// words), projects it to dB with the literal Go algorithm (0.5 M values per batch: no shortcut needed) and
-// collects its own 64 comparison results into one word.
+// words), projects it to dB - the certified table shortcut of gomath.h, the literal Go algorithm where its
+// certificate fails - and collects its own 64 comparison results into one word.  Sixteen waves to a workgroup: round
+// 2's one-wave workgroups with the literal logarithm (0.031 ms) went to 128 different CUs and kept an FFT workgroup,
+// which needs a whole CU, off each of them for that long; these are 8 workgroups for a few microseconds.
 // Waves per workgroup.  Four decoder waves (one per SIMD) share a workgroup: with every lane of a wave working
 // (k_listen_decode) they run as fast together as alone - 0.134 against 0.130 ms - and 16 workgroups keep 16 CUs from
 // the FFT instead of 64: 0.221 against 0.234 ms per pipelined step (eight waves: 0.159 ms / 0.247, sixteen: 0.240 /
 // 0.32; before the lanes were filled, four waves of four active lanes took 0.234 ms against 0.137 alone).  The gather
 // waves stay one to a workgroup (two, four, eight: no difference beyond the noise).
 #ifndef SDR_GATHER_WAVES
-#define SDR_GATHER_WAVES 1
+#define SDR_GATHER_WAVES 16
 #endif
 #ifndef SDR_DECODE_WAVES
 #define SDR_DECODE_WAVES 4
@@ -38,12 +40,25 @@ namespace sdr {
 constexpr int GATHER_WAVES = SDR_GATHER_WAVES;  // 64-frame words per workgroup, one per wave
 constexpr int DECODE_WAVES = SDR_DECODE_WAVES;  // signal groups per workgroup, one per wave
 
+// the literal Go algorithm, out of line: it is rare (about three values in 10^5 fail the shortcut's certificate)
+__device__ __attribute__((noinline)) float gather_db_slow(float psd, double inv_n2) { return gomath::psd_value_in_db(psd, inv_n2); }
+
 __global__ __launch_bounds__(64 * GATHER_WAVES) void k_listen_gather(const float *__restrict__ tap, const sdr_frame_rec *__restrict__ recs,
-                                                      const ListenerSlot *__restrict__ slots,
+                                                      const ListenerSlot *__restrict__ slots, const void *__restrict__ db_tab,
                                                       uint64_t *__restrict__ raw_bits, float *__restrict__ tr_values,
                                                       uint8_t *__restrict__ tr_raw, ListenGeom g, int n_frames,
                                                       int n_slots, double inv_n2)
 {
+    // the tables of the certified dB shortcut (gomath.h; k_cumulate uses the same ones)
+    __shared__ __attribute__((aligned(16))) unsigned char s_tab[gomath::kDbTabBytes];
+    {
+        const uint4 *src = static_cast<const uint4 *>(db_tab);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_tab);
+        for (int i = threadIdx.x; i < gomath::kDbTabBytes / 16; i += blockDim.x)
+            dst[i] = src[i];
+    }
+    __syncthreads();
+    const gomath::DbTables tab = gomath::db_tables(s_tab);
     const int word = blockIdx.x * GATHER_WAVES + (int)(threadIdx.x >> 6), band = blockIdx.z;
     const int l = blockIdx.y * 64 + (int)(threadIdx.x & 63);
     if (l >= n_slots || word * 64 >= n_frames)
@@ -56,16 +71,21 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) void k_listen_gather(const float
     const size_t frame0 = (size_t)band * g.stride + f0;
     uint64_t mask = 0;
     for (int j0 = 0; j0 < cnt; j0 += 8) {
-        float p[8];
+        float p[8], thr[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++)
+        for (int k = 0; k < 8; k++) {
             p[k] = tap[(frame0 + min(j0 + k, cnt - 1)) * g.max_listeners + l];
+            thr[k] = recs[frame0 + min(j0 + k, cnt - 1)].listen_thr;
+        }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int j = j0 + k;
             if (j < cnt) {
-                const float v = gomath::psd_value_in_db(p[k], inv_n2) + (float)SDR_DBM_SHIFT;  // spectrum[SignalBin]
-                const bool raw = v > recs[frame0 + j].listen_thr;                              // cw/spectral.go:49
+                float db;
+                if (!gomath::psd_value_in_db_fast(p[k], tab, &db))
+                    db = gather_db_slow(p[k], inv_n2);
+                const float v = db + (float)SDR_DBM_SHIFT;  // spectrum[SignalBin]
+                const bool raw = v > thr[k];                // cw/spectral.go:49
                 mask |= (uint64_t)raw << j;
                 if (g.trace) {
                     const size_t ti = (frame0 + j) * g.max_listeners + l;
@@ -262,14 +282,14 @@ __global__ void k_set_debounce(ListenerSlot *slots, int n, int threshold)
         slots[i].deb.threshold = threshold;
 }
 
-hipError_t launch_listen_gather(const float *tap, const sdr_frame_rec *recs, const ListenerSlot *slots, uint64_t *raw_bits,
-                                float *tr_values, uint8_t *tr_raw, ListenGeom g, int n_frames, int n_slots, int n_bands,
-                                hipStream_t stream)
+hipError_t launch_listen_gather(const float *tap, const sdr_frame_rec *recs, const ListenerSlot *slots, const void *db_tab,
+                                uint64_t *raw_bits, float *tr_values, uint8_t *tr_raw, ListenGeom g, int n_frames, int n_slots,
+                                int n_bands, hipStream_t stream)
 {
     const double inv_n2 = 1.0 / ((double)g.n * (double)g.n);
     launch_kernel(k_listen_gather, dim3(((n_frames + 63) / 64 + GATHER_WAVES - 1) / GATHER_WAVES, (n_slots + 63) / 64, n_bands),
                        dim3(64 * GATHER_WAVES), 0, stream, tap, recs,
-                       slots, raw_bits, tr_values, tr_raw, g, n_frames, n_slots, inv_n2);
+                       slots, db_tab, raw_bits, tr_values, tr_raw, g, n_frames, n_slots, inv_n2);
     return hipGetLastError();
 }
 

@@ -36,23 +36,26 @@ constexpr int NS_GROUPS = 1;  // variance chains: the producers' float64 work is
 constexpr int CHAIN_THREADS = 64 * MAX_WAVES;
 // SLOTS = LDS tiles between producers and consumer: 4 float64 tiles (133 KB) for the long variance chains, 2 float32
 // tiles per group (4 x 35 KB) for the short window sums.
-template <int SLOTS, class T>
+template <int SLOTS, class T, int PAD_ = (sizeof(T) == 8 ? 2 : 4)>
 struct ChainShared {
     using term_t = T;
     static constexpr int RING_SLOTS = SLOTS;
     // [slot][chain][column]; rows are 528 bytes apart (float64) / 272 bytes (float32): 16-byte aligned for the
     // consumer's ds_read_b128, and the sixteen lanes one LDS cycle serves start on sixteen different 16-byte bank
-    // groups, so neither side has bank conflicts
-    static constexpr int PAD = sizeof(T) == 8 ? 2 : 4;
+    // groups, so neither side has bank conflicts.  (The variance ring's rows are 264 bytes apart: its consumers read
+    // single words, sixteen rows x two columns per 32-lane group - word 66 c + k: all 32 banks.)
+    static constexpr int PAD = PAD_;
     alignas(16) T term[SLOTS][TILE][TILE + PAD];
     double mean[TILE];                        // per chain: value subtracted before squaring (variance pass)
     int n_terms[TILE];                        // per chain: number of leading terms that count
     int ready[SLOTS][2];                      // ready[t % SLOTS][h] == t + 1  <=>  rows 32h..32h+31 of tile t are published
     int consumed;                             // tiles the consumer has finished with
     int simd_of_wave[MAX_WAVES];              // which SIMD each of the group's waves landed on (see chain_run)
+    int consumed_by[4];                       // variance chains on the matrix pipe: tiles each of the four consumer waves is done with
+    double chain_sum[TILE];                   // ... and where they leave their chains' sums
 };
 using WindowRing = ChainShared<2, float>;
-using VarianceRing = ChainShared<4, double>;
+using VarianceRing = ChainShared<6, float, 2>;
 
 #if defined(SDR_NOISE_TRACE)
 // diagnostic builds (tools/abl): where does the consumer of workgroup 0 spend its time?
@@ -69,7 +72,7 @@ __shared__ VarianceRing g_ring_ns[NS_GROUPS];
 template <class Shared>
 __device__ __forceinline__ Shared &ring(int group)
 {
-    if constexpr (sizeof(typename Shared::term_t) == 4)
+    if constexpr (Shared::RING_SLOTS == WindowRing::RING_SLOTS)
         return g_ring_wm[group];
     else
         return g_ring_ns[group];
@@ -349,6 +352,159 @@ __device__ __forceinline__ double chain_run(Shared &sh, int group, int wig, cons
     return sum;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The variance chains on the MATRIX pipe.  A dependent v_add_f64 costs 10 clocks, so a chain of up to 16384 ordered
+// additions cannot take less than 68 us on the vector ALU whatever feeds it (round 2: 108 us).  v_mfma_f64_4x4x4_4b
+// computes D = C + A x B as a strictly sequential chain of float64 fused multiply-adds in k order - measured, every bit
+// (tools/ubench_mfma_f64.hip: 64 000 outputs on wide-range random data equal fma(a3,1, fma(a2,1, fma(a1,1, fma(a0,1,c))))
+// and no other association) - and with B = 1 an fma IS the rounded addition the reference performs (dsp/fft.go:246-248:
+// sum += term, term already rounded).  One instruction therefore adds FOUR consecutive terms to each of sixteen
+// chains, in order, in 21.5 clocks: 5.4 per term.  Operand layout (probed): lane L supplies term k = L >> 4 of chain
+// L & 15; the sum of chain c sits in lanes 16 (c & 3) + 4 (c >> 2) + j, j = 0..3.
+// Four consumer waves (one per SIMD: the matrix pipe is per SIMD) take sixteen of the workgroup's 64 chains each and
+// read what the twelve producers laid down (the psd values as they are, rows 264 bytes apart: conflict-free for this
+// read pattern) and widen, subtract and square them in the shadow of the matrix instruction before; each reports the
+// tiles it is done with on its own, the producers wait for the slowest.
+// ---------------------------------------------------------------------------------------------
+constexpr int NV_CONSUMERS = 4;
+constexpr int NV_PRODUCERS = MAX_WAVES - NV_CONSUMERS;
+
+__device__ __attribute__((noinline)) void variance_consumer_mfma(int n_tiles_any_lane, int lane, int consumer_any_lane, int min_terms_any_lane)
+{
+    const int n_tiles = __builtin_amdgcn_readfirstlane(n_tiles_any_lane);
+    const int g = __builtin_amdgcn_readfirstlane(consumer_any_lane);
+    const int min_terms = __builtin_amdgcn_readfirstlane(min_terms_any_lane);
+    VarianceRing &sh = g_ring_ns[0];
+    constexpr int RING_SLOTS = VarianceRing::RING_SLOTS;
+    const int row = 16 * g + (lane & 15), k = lane >> 4;
+    const double mean = sh.mean[row];     // this lane's chain: the value subtracted before squaring
+    const int n_terms = sh.n_terms[row];  // ... and how many leading terms count
+    double acc = 0.0;
+    __builtin_amdgcn_s_setprio(3);
+    for (int t = 0; t < n_tiles; t++) {
+        const int slot = t % RING_SLOTS;
+        while (lds_flag_load(&sh.ready[slot][0]) != t + 1 || lds_flag_load(&sh.ready[slot][1]) != t + 1)
+            __builtin_amdgcn_s_sleep(1);
+        lds_order();
+        float x[TILE / 4];
+#pragma unroll
+        for (int q = 0; q < TILE / 4; q++)
+            x[q] = sh.term[slot][row][4 * q + k];  // ds_read_b32: terms 4q .. 4q+3 of sixteen chains per instruction
+        // term = (psd - mean)^2, math.Pow(d, 2) (dsp/fft.go:247), widened, subtracted and squared in float64 here, in
+        // the shadow of the previous instruction on the matrix pipe; terms past the chain's end count as +0 (only in
+        // the tiles where some chain of the workgroup ends: a scalar branch)
+        if ((t + 1) * TILE <= min_terms) {
+            double p_next = ((double)x[0] - mean) * ((double)x[0] - mean);
+#pragma unroll
+            for (int q = 0; q < TILE / 4; q++) {
+                const double p = p_next;
+                acc = __builtin_amdgcn_mfma_f64_4x4x4f64(p, 1.0, acc, 0, 0, 0);
+                if (q + 1 < TILE / 4) {
+                    const double d = (double)x[q + 1] - mean;
+                    p_next = d * d;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < TILE / 4; q++) {
+                const double d = (double)x[q] - mean;
+                double p = d * d;
+                if (t * TILE + 4 * q + k >= n_terms)
+                    p = 0.0;
+                acc = __builtin_amdgcn_mfma_f64_4x4x4f64(p, 1.0, acc, 0, 0, 0);
+            }
+        }
+        asm volatile("" : "+v"(acc)::"memory");
+        lds_order();
+        if (lane == 0)
+            lds_flag_store(&sh.consumed_by[g], t + 1);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    // chain c of this consumer: lanes 16 (c & 3) + 4 (c >> 2) + j hold its sum; j = 0 writes it
+    if ((lane & 3) == 0) {
+        const int c = 4 * ((lane >> 2) & 3) + (lane >> 4);
+        sh.chain_sum[16 * g + c] = acc;
+    }
+}
+
+// producers of the matrix-pipe variance chains: they only move data - each unit is 32 chains' next 64 psd values (one
+// coalesced 256-byte read per chain), laid down as they are (float32); the next unit's reads are in flight while this
+// one is written.  They wait for the slowest of the four consumers before reusing a ring slot.
+__device__ __forceinline__ void variance_producer(VarianceRing &sh, const float *__restrict__ base, unsigned row_stride, int rows,
+                                                  int n_cols, int n_tiles, int p, int np, int lane)
+{
+    const int n_units = 2 * n_tiles;
+    constexpr int RING_SLOTS = VarianceRing::RING_SLOTS;
+    auto fetch = [&](float (&v)[HALF], int u) {
+        u = min(u, n_units - 1);
+        const int t = u >> 1, h = u & 1;
+        const unsigned ccol = min((unsigned)(t * TILE + lane), (unsigned)(n_cols - 1));
+#pragma unroll
+        for (int i = 0; i < HALF; i++)
+            v[i] = base[(unsigned)min(h * HALF + i, rows - 1) * row_stride + ccol];
+    };
+    float v[HALF], nv[HALF];
+    if (p < n_units)
+        fetch(nv, p);
+    for (int u = p; u < n_units; u += np) {
+#pragma unroll
+        for (int i = 0; i < HALF; i++)
+            v[i] = nv[i];
+        if (u + np < n_units)
+            fetch(nv, u + np);
+        const int t = u >> 1, h = u & 1;
+        const int slot = t % RING_SLOTS;
+        if (t >= RING_SLOTS) {
+            const int need = t - RING_SLOTS + 1;
+            while (lds_flag_load(&sh.consumed_by[0]) < need || lds_flag_load(&sh.consumed_by[1]) < need ||
+                   lds_flag_load(&sh.consumed_by[2]) < need || lds_flag_load(&sh.consumed_by[3]) < need)
+                __builtin_amdgcn_s_sleep(1);
+        }
+        lds_order();
+#pragma unroll
+        for (int i = 0; i < HALF; i++)
+            sh.term[slot][h * HALF + i][lane] = v[i];
+        lds_order();
+        if (lane == 0)
+            lds_flag_store(&sh.ready[slot][h], t + 1);
+    }
+}
+
+// Runs the workgroup's 64 variance chains; `my_terms` / `my_mean`: chain (frame) `lane`'s length and mean, valid in
+// wave 0.  Returns chain `lane`'s sum in every wave (read back from LDS behind the closing barrier).
+__device__ __forceinline__ double variance_run(int wave, const float *__restrict__ base, size_t row_stride, int rows, int n_cols,
+                                               int my_terms, double my_mean)
+{
+    VarianceRing &sh = g_ring_ns[0];
+    const int lane = threadIdx.x & 63;
+    if (wave == 0) {
+        sh.n_terms[lane] = my_terms;
+        sh.mean[lane] = my_mean;
+        sh.chain_sum[lane] = 0.0;
+        if (lane < VarianceRing::RING_SLOTS) {
+            sh.ready[lane][0] = 0;
+            sh.ready[lane][1] = 0;
+        }
+        if (lane < NV_CONSUMERS)
+            sh.consumed_by[lane] = 0;
+    }
+    __syncthreads();
+    int max_terms = sh.n_terms[lane], min_terms = max_terms;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        max_terms = max(max_terms, __shfl_xor(max_terms, o));
+        min_terms = min(min_terms, __shfl_xor(min_terms, o));
+    }
+    const int n_tiles = __builtin_amdgcn_readfirstlane((max_terms + TILE - 1) / TILE);
+    min_terms = __builtin_amdgcn_readfirstlane(min_terms);
+    if (wave < NV_CONSUMERS)
+        variance_consumer_mfma(n_tiles, lane, wave, min_terms);
+    else
+        variance_producer(sh, base, (unsigned)row_stride, rows, n_cols, n_tiles, wave - NV_CONSUMERS, NV_PRODUCERS, lane);
+    __syncthreads();
+    return sh.chain_sum[lane];
+}
+
 // pass 1: mean of window w of frame f = sequential float64 sum of psd[edge + w*W .. +W) / W (:239-241,:230).
 // A workgroup walks `windows_per_block` windows of its 64 frames back to back: with many bands there are
 // thousands of (frame group, window) chains, and one long-lived workgroup per CU beats ten short ones.
@@ -388,7 +544,6 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_noise_stats(const float *__re
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int group = wave / WPG;
     const int wig = (wave - group * WPG - group + WPG) % WPG;  // (as in k_window_means)
-    VarianceRing &sh = ring<VarianceRing>(group);
     const bool consumer = wig == 0;
     const int f0 = (blockIdx.x * NS_GROUPS + group) * TILE, band = blockIdx.y;
     const int rows = max(0, min(TILE, n_frames - f0));
@@ -416,7 +571,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_noise_stats(const float *__re
     }
     // sdr_create guarantees n_windows >= 9, so every chain starts at `edge`
     const float *base = psd + frame0 * g.n + g.edge;
-    const double sum = chain_run<true, NS_GROUPS>(sh, group, wig, base, g.n, rows, g.n - g.edge, n_terms, resultMean);
+    const double sum = variance_run(wave, base, g.n, rows, g.n - g.edge, n_terms, resultMean);
     if (!valid)
         return;
     const double variance = sum / (double)g.window;
@@ -439,7 +594,10 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_noise_stats(const float *__re
 // carried over from the previous batch), so only the two float32 running sums form a serial chain:
 // lanes 0 and 1 of wave 0 run them side by side, everything else is data-parallel.
 // ---------------------------------------------------------------------------------------------
-constexpr int THR_CHUNK = 1024;
+#ifndef SDR_THR_CHUNK
+#define SDR_THR_CHUNK 1024
+#endif
+constexpr int THR_CHUNK = SDR_THR_CHUNK;
 
 __global__ __launch_bounds__(256) void k_thresholds(sdr_frame_rec *__restrict__ recs, BandState *__restrict__ st,
                                                     int n_frames, int stride)

@@ -568,7 +568,7 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     SDR_ARM(sdr::K_LISTEN_GATHER);
     if (max_slots > 0) {
         ProfScope ps(b, sdr::K_LISTEN_GATHER, stream_of(sdr::K_LISTEN_GATHER));
-        SDR_LAUNCH(sdr::K_LISTEN_GATHER, sdr::launch_listen_gather(S.tap.p, S.recs.p, b->slots.p, S.raw_bits.p, S.tr_values.p,
+        SDR_LAUNCH(sdr::K_LISTEN_GATHER, sdr::launch_listen_gather(S.tap.p, S.recs.p, b->slots.p, b->db_tab.p, S.raw_bits.p, S.tr_values.p,
                                                                    S.tr_raw.p, lg, n_frames, max_slots, B,
                                                                    stream_of(sdr::K_LISTEN_GATHER)));
     }

@@ -129,9 +129,9 @@ hipError_t launch_noise_stats(const float *psd, const double *win_mean, sdr_fram
                               int n_bands, int stride, hipStream_t stream);
 hipError_t launch_thresholds(sdr_frame_rec *recs, BandState *st, int n_frames, int n_bands, int stride,
                              hipStream_t stream);
-hipError_t launch_listen_gather(const float *tap, const sdr_frame_rec *recs, const ListenerSlot *slots, uint64_t *raw_bits,
-                                float *tr_values, uint8_t *tr_raw, ListenGeom g, int n_frames, int n_slots, int n_bands,
-                                hipStream_t stream);
+hipError_t launch_listen_gather(const float *tap, const sdr_frame_rec *recs, const ListenerSlot *slots, const void *db_tab,
+                                uint64_t *raw_bits, float *tr_values, uint8_t *tr_raw, ListenGeom g, int n_frames, int n_slots,
+                                int n_bands, hipStream_t stream);
 hipError_t launch_listen_decode(ListenerSlot *slots, const uint16_t *morse, const uint64_t *raw_bits,
                                 uint64_t *deb_bits, uint32_t *text, uint32_t *text_frames, sdr_edge *edges,
                                 uint32_t *edge_counts, uint8_t *tr_deb, DropCounters *drops, const BatchCursor *cur, ListenGeom g,

@@ -127,6 +127,12 @@ static void probe(const char *name, int n_out, Launch run)
     for (int l : src[1])
         printf(" %d", l);
     printf("\n");
+    if (n_out == 64) {
+        printf("%s: first source lane of every output lane:", name);
+        for (int o = 0; o < n_out; o++)
+            printf(" %d", src[o].empty() ? -1 : src[o][0]);
+        printf("\n");
+    }
     if (!four)
         return;
     // evaluation order: random data with a wide exponent range, so that every association rounds differently
