@@ -187,14 +187,14 @@ struct sdr_bank {
     int find_peaks = 1;
     bool failed = false;  // a HIP call failed in the middle of a launch sequence: device state is unknown
     DevBuf<sdr::DropCounters> drops;
-    // graph mode (sdr_graph_*): RING consecutive batches captured as one hipGraph
+    // graph mode (sdr_graph_*): RING consecutive batches captured as one linear hipGraph PER STREAM
     DevBuf<sdr::BatchCursor> cursors;  // [RING]
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    hipGraphNode_t graph_cursor_node = nullptr;
+    hipGraph_t graph[N_STAGES] = {};
+    hipGraphExec_t graph_exec[N_STAGES] = {};
+    hipGraphNode_t graph_cursor_node[RING] = {};  // the FFT stream's graph: the node that writes batch k's cursor
+    bool graph_ready = false;
     int graph_frames = 0, graph_slots = 0;
     uint64_t attach_gen = 0, graph_attach_gen = 0;  // sdr_attach / sdr_detach calls so far; as of the capture
-    std::vector<hipEvent_t> graph_join;
     // bulk delivery
     bool results_on = false;
     sdr::ResultsLayout res_layout{};
@@ -332,7 +332,59 @@ size_t utf8_encode(uint32_t r, char *out)
     return 3;
 }
 
-int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_stride, int capture_k = -1);
+// An external event wait inside an open stream capture.  hipStreamWaitEvent(..., hipEventWaitExternal) behind a kernel
+// node throws std::bad_alloc inside the runtime (ROCm 7.2; tools/experiments/probe_graph_ext.hip, scenario 3), so the
+// wait node is added to the capture's graph by hand, behind the stream's current dependency set, and made the
+// dependency of whatever the stream captures next.
+hipError_t capture_wait_external(hipStream_t stream, hipEvent_t event)
+{
+    hipStreamCaptureStatus status;
+    unsigned long long id = 0;
+    hipGraph_t graph = nullptr;
+    const hipGraphNode_t *deps = nullptr;
+    size_t n_deps = 0;
+    hipError_t e = hipStreamGetCaptureInfo_v2(stream, &status, &id, &graph, &deps, &n_deps);
+    if (e != hipSuccess)
+        return e;
+    if (status != hipStreamCaptureStatusActive || !graph)
+        return hipErrorStreamCaptureInvalidated;
+    hipGraphNode_t wait_node = nullptr;
+    e = hipGraphAddEventWaitNode(&wait_node, graph, deps, n_deps, event);
+    if (e != hipSuccess)
+        return e;
+    return hipStreamUpdateCaptureDependencies(stream, &wait_node, 1, hipStreamSetCaptureDependencies);
+}
+
+// ... and the record side the same way (hipEventRecordWithFlags(..., hipEventRecordExternal) is refused with "invalid
+// argument" by the HIP runtime PyTorch brings along, which is the one a Python process ends up with)
+hipError_t capture_record_external(hipStream_t stream, hipEvent_t event)
+{
+    hipStreamCaptureStatus status;
+    unsigned long long id = 0;
+    hipGraph_t graph = nullptr;
+    const hipGraphNode_t *deps = nullptr;
+    size_t n_deps = 0;
+    hipError_t e = hipStreamGetCaptureInfo_v2(stream, &status, &id, &graph, &deps, &n_deps);
+    if (e != hipSuccess)
+        return e;
+    if (status != hipStreamCaptureStatusActive || !graph)
+        return hipErrorStreamCaptureInvalidated;
+    hipGraphNode_t node = nullptr;
+    e = hipGraphAddEventRecordNode(&node, graph, deps, n_deps, event);
+    if (e != hipSuccess)
+        return e;
+    return hipStreamUpdateCaptureDependencies(stream, &node, 1, hipStreamSetCaptureDependencies);
+}
+
+// graph mode: what differs between the batches of a replay lives in device-side cursors; batch k's is written by a node
+// of the FFT stream's graph right in front of that batch's FFT
+__global__ void k_set_cursor(sdr::BatchCursor *dst, sdr::BatchCursor v)
+{
+    if (threadIdx.x == 0)
+        *dst = v;
+}
+
+int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_stride, int capture_k = -1, int capture_stage = -1);
 
 // A failure after the first launch leaves the pipeline half enqueued (some stages of this batch ran, the
 // carried state of others did not advance): no later batch can be trusted, so the bank refuses further work.
@@ -340,7 +392,7 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
 {
     if (b->failed)
         return fail(SDR_ERR_STATE, "an earlier process call failed half way; destroy the bank");
-    if (b->graph_exec)
+    if (b->graph_ready)
         return fail(SDR_ERR_STATE, "a graph is captured: process through sdr_graph_launch, or sdr_graph_release first");
     const int rc = process_device_body(b, iq_dev, n_frames, in_stride);
     if (rc == SDR_ERR_HIP)
@@ -409,13 +461,18 @@ constexpr int kDefaultPlan[sdr::K_COUNT] = {
     /* fft */ S_FFT, /* window means */ S_NOISE, /* noise stats */ S_NOISE, /* thresholds */ S_PEAKS,
     /* gather */ S_LISTEN, /* cumulate */ S_PEAKS, /* find peaks */ S_PEAKS, /* decode */ S_LISTEN};
 
+// capture_stage: while capturing, ONE stream records at a time (sdr_graph_capture walks the batches once per stream):
+// only what is enqueued on that stream - its kernels, its event records, its waits - is issued, everything else of the
+// batch is skipped in that walk.
 // capture_k >= 0: the call is being recorded into a graph as its batch number capture_k (sdr_graph_capture).  Then
 // the batch uses buffer set capture_k, everything that differs from batch to batch comes from the device-side
 // cursor of that number instead of the launch parameters, grids cover the most chunks a batch of this length can
 // complete, nothing is asked of the host (no event queries, no profiling, no parking) and no host state changes.
-int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_stride, int capture_k)
+int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_stride, int capture_k, int capture_stage)
 {
     const bool cap = capture_k >= 0;
+    static const bool pdbg = getenv("SDR_GRAPH_DEBUG") != nullptr;
+#define PDBG(msg) do { if (pdbg && cap) { hipStreamCaptureStatus cs_ = hipStreamCaptureStatusNone; (void)hipStreamIsCapturing(b->stream[capture_stage], &cs_); fprintf(stderr, "[graph body %d stage %d] %s (capture status %d)\n", capture_k, capture_stage, msg, (int)cs_); fflush(stderr); } } while (0)
     const sdr::BatchCursor *cur = cap ? b->cursors.p + capture_k : nullptr;
     const sdr_config &c = b->cfg;
     if (n_frames <= 0)
@@ -435,6 +492,8 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     int plan[sdr::K_COUNT];
     for (int k = 0; k < sdr::K_COUNT; k++)
         plan[k] = kDefaultPlan[k];
+    // is kernel k's stream the one that is recording (always, outside a capture)?
+#define SDR_ON(k) (!cap || plan[k] == capture_stage)
 #if defined(SDR_DIAG)
     // diagnostic builds only (tools/abl): SDR_DIAG_SKIP = bit mask of kernel ids not to launch, to see
     // which stage holds the pipelined step up (results are wrong by construction); SDR_DIAG_PLAN = stream plan.
@@ -444,17 +503,27 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
             plan[k] = e[k] - '0';
 #define SDR_LAUNCH(id, call) \
     do {                     \
-        if (!(diag_skip >> (id) & 1)) \
+        if (!(diag_skip >> (id) & 1) && SDR_ON(id)) \
             HIP_TRY(call);   \
     } while (0)
 #else
-#define SDR_LAUNCH(id, call) HIP_TRY(call)
+#define SDR_LAUNCH(id, call)  \
+    do {                      \
+        if (SDR_ON(id))       \
+            HIP_TRY(call);    \
+    } while (0)
 #endif
     auto stream_of = [&](int k) { return b->stream[plan[k]]; };
     // kernel k of this batch may start once kernel `dep` of this batch is done (nothing to do on the same stream)
+    // (while capturing, every stream records a graph of its own: an event that crosses streams is an EXTERNAL event
+    // node - it is recorded and waited for at replay time like the eager path's events, it does not merge the captures)
     auto after = [&](int k, int dep) -> int {
-        if (stream_of(k) != stream_of(dep))
-            HIP_TRY(hipStreamWaitEvent(stream_of(k), S.done[dep], 0));
+        if (stream_of(k) != stream_of(dep) && SDR_ON(k)) {
+            if (cap)
+                HIP_TRY(capture_wait_external(stream_of(k), S.done[dep]));
+            else
+                HIP_TRY(hipStreamWaitEvent(stream_of(k), S.done[dep], 0));
+        }
         return SDR_OK;
     };
 #define SDR_AFTER(k, dep)          \
@@ -468,12 +537,12 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     static const bool stop_events = !(getenv("SDR_STOP_EVENTS") && atoi(getenv("SDR_STOP_EVENTS")) == 0);
     const bool ride = stop_events && !cap;
 #define SDR_ARM(k) (sdr::t_done_event = ride ? S.done[k] : nullptr)
-#define SDR_DONE(k)                                              \
-    do {                                                         \
-        if (!ride || sdr::t_done_event) {                        \
-            sdr::t_done_event = nullptr;                         \
-            HIP_TRY(hipEventRecord(S.done[k], stream_of(k)));    \
-        }                                                        \
+#define SDR_DONE(k)                                                                                   \
+    do {                                                                                              \
+        if ((!ride || sdr::t_done_event) && SDR_ON(k)) {                                              \
+            sdr::t_done_event = nullptr;                                                              \
+            HIP_TRY(cap ? capture_record_external(stream_of(k), S.done[k]) : hipEventRecord(S.done[k], stream_of(k))); \
+        }                                                                                             \
     } while (0)
 
     // FFT + PSD + tap, once every reader of this set (batch i - RING) is done with it (with RING sets the
@@ -487,7 +556,7 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     // set is free, the FFT queue holds kernels only): 0.161 ms with nothing else running, but 0.237 against 0.234
     // with the whole pipeline, where the FFT launches are spaced by the CUs the tail holds, not by their queue.
     static const bool host_waits = getenv("SDR_HOST_THROTTLE") && atoi(getenv("SDR_HOST_THROTTLE")) != 0;
-    if (!cap) {
+    {
         // the last stage launched on a stream stands for all of that stream's
         static const int launch_order[] = {sdr::K_WINDOW_MEANS, sdr::K_NOISE_STATS, sdr::K_THRESHOLDS, sdr::K_LISTEN_GATHER,
                                            sdr::K_LISTEN_DECODE, sdr::K_CUMULATE,   sdr::K_FIND_PEAKS};
@@ -498,7 +567,16 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
             last_on[plan[k]] = k;
         for (int st = 0; st < N_STAGES; st++) {
             const int k = last_on[st];
-            if (k < 0 || st == plan[sdr::K_FFT] || hipEventQuery(S.done[k]) == hipSuccess)
+            if (k < 0 || st == plan[sdr::K_FFT])
+                continue;
+            if (cap) {
+                // a replay's FFT of set k waits for the PREVIOUS replay's readers of set k (the streams replay
+                // graphs of their own and run ahead of each other exactly as the eager pipeline does)
+                if (SDR_ON(sdr::K_FFT))
+                    HIP_TRY(capture_wait_external(stream_of(sdr::K_FFT), S.done[k]));
+                continue;
+            }
+            if (hipEventQuery(S.done[k]) == hipSuccess)
                 continue;
             if (host_waits)
                 HIP_TRY(hipEventSynchronize(S.done[k]));
@@ -506,6 +584,9 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
                 HIP_TRY(hipStreamWaitEvent(stream_of(sdr::K_FFT), S.done[k], 0));
         }
     }
+    PDBG("reuse waits done");
+    if (cap && SDR_ON(sdr::K_FFT))  // this batch's cursor: behind the waits above, so no kernel of the previous replay still reads it
+        hipLaunchKernelGGL(k_set_cursor, dim3(1), dim3(64), 0, stream_of(sdr::K_FFT), b->cursors.p + capture_k, sdr::BatchCursor{});
     int max_slots = 0, slots_in_use = 0;
     for (int i = 0; i < B; i++) {
         max_slots = std::max(max_slots, b->n_slots[i]);
@@ -516,6 +597,7 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         if (prc)
             return prc;
     }
+    PDBG("cursor kernel launched");
     {
         ProfScope ps(b, sdr::K_FFT, stream_of(sdr::K_FFT));
         SDR_ARM(sdr::K_FFT);
@@ -523,7 +605,9 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         SDR_LAUNCH(sdr::K_FFT, sdr::launch_fft(b->logn, iq_dev, cur, b->tw.p, S.psd.p, n_frames, B, in_stride, stride, tap,
                                                stream_of(sdr::K_FFT)));
     }
+    PDBG("fft launched");
     SDR_DONE(sdr::K_FFT);
+    PDBG("fft event");
 
     // noise floor (stateless per batch), then the rolling means -> thresholds, in batch order
     SDR_AFTER(sdr::K_WINDOW_MEANS, sdr::K_FFT);
@@ -550,6 +634,7 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
                                                              stream_of(sdr::K_THRESHOLDS)));
     }
     SDR_DONE(sdr::K_THRESHOLDS);
+    PDBG("noise + thresholds");
 
     // per-signal envelope + decoder
     sdr::ListenGeom lg;
@@ -582,18 +667,19 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
                                                                    b->text_frames.p, S.edges.p, S.edge_counts.p, S.tr_deb.p, b->drops.p, cur,
                                                                    lg, n_frames, B, slots_in_use, stream_of(sdr::K_LISTEN_DECODE)));
     }
-    if (b->results_on) {
+    if (b->results_on && SDR_ON(sdr::K_LISTEN_DECODE)) {
         // delivery of this batch's edges and runes, behind the decoder on its stream; the decoder's event is
         // recorded behind it so that the set is not reused before the copy to the host has happened
         SDR_ARM(sdr::K_LISTEN_DECODE);
         HIP_TRY(sdr::launch_pack_listen(b->slots.p, S.edges.p, S.edge_counts.p, b->text.p, b->text_frames.p, b->drops.p, b->res_layout, max_slots, B,
                                         S.res_host, stream_of(sdr::K_LISTEN_DECODE)));
-        // (an event recorded inside a capture is an edge of the graph, not something the host can wait for: a
-        // replay's delivery events are recorded behind the launch, sdr_graph_launch)
-        if (!cap)
-            HIP_TRY(hipEventRecord(S.res_listen, stream_of(sdr::K_LISTEN_DECODE)));
+        // (inside a capture: an external event node, recorded at replay time - sdr_poll waits for it like for the
+        // eager path's)
+        HIP_TRY(cap ? capture_record_external(stream_of(sdr::K_LISTEN_DECODE), S.res_listen)
+                    : hipEventRecord(S.res_listen, stream_of(sdr::K_LISTEN_DECODE)));
     }
     SDR_DONE(sdr::K_LISTEN_DECODE);
+    PDBG("listen");
 
     // dB projection + cumulation, peak scan (rx/receiver.go:404-409,459-460)
     const int count0 = b->cum_count;
@@ -628,12 +714,11 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         SDR_LAUNCH(sdr::K_FIND_PEAKS, sdr::launch_find_peaks(S.cum_out.p, S.recs.p, S.dev_peaks.p, S.peak_counts.p, cur, pg, n_frames,
                                                              n_chunks, B, stream_of(sdr::K_FIND_PEAKS)));
     }
-    if (b->results_on) {
+    if (b->results_on && SDR_ON(sdr::K_FIND_PEAKS)) {
         SDR_ARM(sdr::K_FIND_PEAKS);
         HIP_TRY(sdr::launch_pack_peaks(S.dev_peaks.p, S.peak_counts.p, cur, b->res_layout, b->find_peaks, n_frames, n_chunks, B,
                                        S.res_host, stream_of(sdr::K_FIND_PEAKS)));
-        if (!cap)
-            HIP_TRY(hipEventRecord(S.res_peaks, stream_of(sdr::K_FIND_PEAKS)));
+        HIP_TRY(cap ? capture_record_external(stream_of(sdr::K_FIND_PEAKS), S.res_peaks) : hipEventRecord(S.res_peaks, stream_of(sdr::K_FIND_PEAKS)));
         if (!cap) {
             std::lock_guard<std::mutex> guard(b->res_mu);
             S.res_batch = b->batch_index;
@@ -647,10 +732,12 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         }
     }
     SDR_DONE(sdr::K_FIND_PEAKS);
+    PDBG("peaks");
 #undef SDR_AFTER
 #undef SDR_DONE
 #undef SDR_ARM
 #undef SDR_LAUNCH
+#undef SDR_ON
 
     if (cap)
         return SDR_OK;
@@ -675,14 +762,7 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
 
 // graph mode: the values that differ between the batches of a replay, written to the device-side cursors by the
 // graph's first node from its kernel arguments
-struct CursorBlock {
-    sdr::BatchCursor c[RING];
-};
-__global__ void k_set_cursors(sdr::BatchCursor *dst, CursorBlock v)
-{
-    if (threadIdx.x < RING)
-        dst[threadIdx.x] = v.c[threadIdx.x];
-}
+// (one node per batch; its kernel argument is what a replay updates)
 
 }  // namespace
 
@@ -842,12 +922,12 @@ int sdr_destroy(sdr_bank *b)
     for (int s = 0; s < N_STAGES; s++)
         (void)hipStreamSynchronize(b->stream[s]);
     resolve_profile(b);
-    if (b->graph_exec)
-        (void)hipGraphExecDestroy(b->graph_exec);
-    if (b->graph)
-        (void)hipGraphDestroy(b->graph);
-    for (auto e : b->graph_join)
-        (void)hipEventDestroy(e);
+    for (int st = 0; st < N_STAGES; st++) {
+        if (b->graph_exec[st])
+            (void)hipGraphExecDestroy(b->graph_exec[st]);
+        if (b->graph[st])
+            (void)hipGraphDestroy(b->graph[st]);
+    }
     b->tw.release();
     b->drops.release();
     b->cursors.release();
@@ -1486,11 +1566,18 @@ int sdr_read_decoder_state(sdr_bank *b, int band, int lid, double *out12)
 }
 
 // ---- graph mode ------------------------------------------------------------------------------------------------
-// RING consecutive batches - every launch of process_device_body with its fork / join over the bank's four
-// streams - recorded once as a hipGraph and replayed with one hipGraphLaunch.  What differs between batches
-// (input pointer, frame numbering, cumulation phase, carry buffer) is read by the kernels from device-side
-// cursors; the graph's first node writes them from its kernel arguments, which are the only thing a replay
-// updates (hipGraphExecKernelNodeSetParams), so no host memory is read while a replay runs.
+// RING consecutive batches recorded once and replayed: ONE LINEAR GRAPH PER STREAM of the bank (the FFT stream's, the
+// noise, peaks and listen streams'), each holding its stream's kernels of the six batches in order, with the events
+// that cross streams as external event record / wait nodes - the same events, in the same places, as the eager path.
+// A replay is four hipGraphLaunch calls, each on the stream it was recorded on: every stage keeps its own hardware
+// queue, consecutive replays overlap like consecutive eager batches do, and the host enqueues four commands per six
+// batches instead of sixty.  (Round 2 captured one graph with fork / join over the four streams: the runtime put its
+// branches on queues of its own choosing - 7-10 % slower than eager and, one process in three, three times slower - and
+// a replay, being one stream operation, could not overlap the next one.)
+// What differs between batches (input pointer, frame numbering, cumulation phase, carry buffer) is read by the kernels
+// from device-side cursors; batch k's cursor is written by a node of the FFT stream's graph right in front of that
+// batch's FFT, behind the waits for the previous replay's readers of set k; its kernel argument is the only thing a
+// replay updates (hipGraphExecKernelNodeSetParams), so no host memory is read while a replay runs.
 int sdr_graph_batches(sdr_bank *b) { return b ? RING : 0; }
 
 int sdr_graph_release(sdr_bank *b)
@@ -1500,13 +1587,17 @@ int sdr_graph_release(sdr_bank *b)
     int rc = sync_bank(b);
     if (rc)
         return rc;
-    if (b->graph_exec)
-        (void)hipGraphExecDestroy(b->graph_exec);
-    if (b->graph)
-        (void)hipGraphDestroy(b->graph);
-    b->graph_exec = nullptr;
-    b->graph = nullptr;
-    b->graph_cursor_node = nullptr;
+    for (int st = 0; st < N_STAGES; st++) {
+        if (b->graph_exec[st])
+            (void)hipGraphExecDestroy(b->graph_exec[st]);
+        if (b->graph[st])
+            (void)hipGraphDestroy(b->graph[st]);
+        b->graph_exec[st] = nullptr;
+        b->graph[st] = nullptr;
+    }
+    for (auto &n : b->graph_cursor_node)
+        n = nullptr;
+    b->graph_ready = false;
     return SDR_OK;
 }
 
@@ -1529,75 +1620,103 @@ int sdr_graph_capture(sdr_bank *b, int n_frames)
         for (auto &S : b->set)
             if ((rc = park_results(b, S)))
                 return rc;
+    static const bool dbg = getenv("SDR_GRAPH_DEBUG") != nullptr;
+#define GDBG(msg) do { if (dbg) { fprintf(stderr, "[graph] %s\n", msg); fflush(stderr); } } while (0)
+    GDBG("enter");
     HIP_TRY(hipSetDevice(b->device));
+    // every event a graph will wait for has been recorded at least once (the first replay waits for "the previous
+    // replay's" stage events: a wait node must find a completed record, not an event that was never recorded)
+    for (auto &S : b->set) {
+        for (int k = 0; k < sdr::K_COUNT; k++)
+            HIP_TRY(hipEventRecord(S.done[k], b->stream[kDefaultPlan[k]]));
+        if (S.res_listen) {
+            HIP_TRY(hipEventRecord(S.res_listen, b->stream[S_LISTEN]));
+            HIP_TRY(hipEventRecord(S.res_peaks, b->stream[S_PEAKS]));
+        }
+    }
+    for (int st = 0; st < N_STAGES; st++)
+        HIP_TRY(hipStreamSynchronize(b->stream[st]));
+    GDBG("events recorded");
     const bool was_profiling = b->profiling;
     b->profiling = false;
-    hipStream_t s0 = b->stream[S_FFT];
-    // (legacy default stream cannot be captured: the bank must have been given a stream, sdr_set_stream)
-    hipError_t e = hipStreamBeginCapture(s0, hipStreamCaptureModeRelaxed);
-    if (e != hipSuccess) {
-        b->profiling = was_profiling;
-        return fail(SDR_ERR_HIP, std::string("hipStreamBeginCapture (the bank's stream must not be the null stream): ") + hipGetErrorString(e));
-    }
-    CursorBlock zero{};
-    hipLaunchKernelGGL(k_set_cursors, dim3(1), dim3(64), 0, s0, b->cursors.p, zero);
+    // one stream records at a time (the legacy default stream cannot be captured: the bank must have been given a
+    // stream, sdr_set_stream); what crosses streams are external event nodes, so the four captures share nothing.
+    // (Four captures open at once corrupted the runtime's memory - bad_alloc / segfault inside the second stream's
+    // first wait, ROCm 7.2 - although two did not: tools/experiments/probe_graph_ext.hip.)
     int max_slots = 0;
     for (int i = 0; i < b->cfg.n_bands; i++)
         max_slots = std::max(max_slots, b->n_slots[i]);
+    hipGraph_t g[N_STAGES] = {};
+    hipError_t e = hipSuccess;
     rc = SDR_OK;
-    for (int k = 0; k < RING && rc == SDR_OK; k++)
-        rc = process_device_body(b, nullptr, n_frames, n_frames, k);
-    // join: the capture ends on the origin stream with every forked stream merged back
-    if (b->graph_join.empty())
-        for (int st = 1; st < N_STAGES; st++) {
-            hipEvent_t ev;
-            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess)
-                b->graph_join.push_back(ev);
-        }
-    for (int st = 1; st < N_STAGES && rc == SDR_OK; st++) {
-        if (hipEventRecord(b->graph_join[st - 1], b->stream[st]) != hipSuccess ||
-            hipStreamWaitEvent(s0, b->graph_join[st - 1], 0) != hipSuccess)
-            rc = fail(SDR_ERR_HIP, "joining the captured streams failed");
-    }
-    hipGraph_t g = nullptr;
-    e = hipStreamEndCapture(s0, &g);
-    b->profiling = was_profiling;
-    if (rc != SDR_OK) {
-        if (g)
-            (void)hipGraphDestroy(g);
-        return rc;
-    }
-    if (e != hipSuccess || !g)
-        return fail(SDR_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-    // the cursor node: the kernel node that runs k_set_cursors
-    size_t n_nodes = 0;
-    HIP_TRY(hipGraphGetNodes(g, nullptr, &n_nodes));
-    std::vector<hipGraphNode_t> nodes(n_nodes);
-    HIP_TRY(hipGraphGetNodes(g, nodes.data(), &n_nodes));
-    hipGraphNode_t cursor_node = nullptr;
-    for (hipGraphNode_t nd : nodes) {
-        hipGraphNodeType t;
-        if (hipGraphNodeGetType(nd, &t) != hipSuccess || t != hipGraphNodeTypeKernel)
-            continue;
-        hipKernelNodeParams kp{};
-        if (hipGraphKernelNodeGetParams(nd, &kp) == hipSuccess && kp.func == reinterpret_cast<void *>(&k_set_cursors)) {
-            cursor_node = nd;
+    for (int st = 0; st < N_STAGES && rc == SDR_OK; st++) {
+        e = hipStreamBeginCapture(b->stream[st], hipStreamCaptureModeRelaxed);
+        if (e != hipSuccess) {
+            rc = fail(SDR_ERR_HIP, std::string("hipStreamBeginCapture (the bank's stream must not be the null stream): ") + hipGetErrorString(e));
             break;
         }
+        for (int k = 0; k < RING && rc == SDR_OK; k++)
+            rc = process_device_body(b, nullptr, n_frames, n_frames, k, st);
+        e = hipStreamEndCapture(b->stream[st], &g[st]);
+        if ((e != hipSuccess || !g[st]) && rc == SDR_OK)
+            rc = fail(SDR_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
     }
-    if (!cursor_node) {
-        (void)hipGraphDestroy(g);
-        return fail(SDR_ERR_HIP, "captured graph has no cursor node");
+    GDBG("captures ended");
+    b->profiling = was_profiling;
+    auto drop = [&] {
+        for (auto &gg : g)
+            if (gg)
+                (void)hipGraphDestroy(gg);
+    };
+    if (rc != SDR_OK) {
+        drop();
+        return rc;
     }
-    hipGraphExec_t ex = nullptr;
-    e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-    if (e != hipSuccess) {
-        (void)hipGraphDestroy(g);
-        return fail(SDR_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    // the cursor nodes: the kernel nodes of the FFT stream's graph that run k_set_cursor, told apart by their target
+    {
+        size_t n_nodes = 0;
+        HIP_TRY(hipGraphGetNodes(g[S_FFT], nullptr, &n_nodes));
+        std::vector<hipGraphNode_t> nodes(n_nodes);
+        HIP_TRY(hipGraphGetNodes(g[S_FFT], nodes.data(), &n_nodes));
+        int found = 0;
+        for (hipGraphNode_t nd : nodes) {
+            hipGraphNodeType t;
+            if (hipGraphNodeGetType(nd, &t) != hipSuccess || t != hipGraphNodeTypeKernel)
+                continue;
+            hipKernelNodeParams kp{};
+            if (hipGraphKernelNodeGetParams(nd, &kp) != hipSuccess || kp.func != reinterpret_cast<void *>(&k_set_cursor) || !kp.kernelParams)
+                continue;
+            const sdr::BatchCursor *dst = *static_cast<sdr::BatchCursor *const *>(kp.kernelParams[0]);
+            const ptrdiff_t k = dst - b->cursors.p;
+            if (k >= 0 && k < RING && !b->graph_cursor_node[k]) {
+                b->graph_cursor_node[k] = nd;
+                found++;
+            }
+        }
+        if (found != RING) {
+            drop();
+            for (auto &n : b->graph_cursor_node)
+                n = nullptr;
+            return fail(SDR_ERR_HIP, "captured graph does not hold one cursor node per batch");
+        }
     }
-    b->graph = g;
-    b->graph_exec = ex;
-    b->graph_cursor_node = cursor_node;
+    GDBG("cursor nodes found");
+    for (int st = 0; st < N_STAGES; st++) {
+        if (dbg) { size_t nn = 0; (void)hipGraphGetNodes(g[st], nullptr, &nn); fprintf(stderr, "[graph] stream %d: %zu nodes\n", st, nn); fflush(stderr); }
+        e = hipGraphInstantiate(&b->graph_exec[st], g[st], nullptr, nullptr, 0);
+        if (e != hipSuccess) {
+            for (int j = 0; j < st; j++) {
+                (void)hipGraphExecDestroy(b->graph_exec[j]);
+                b->graph_exec[j] = nullptr;
+            }
+            drop();
+            return fail(SDR_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+        }
+    }
+    GDBG("instantiated");
+    for (int st = 0; st < N_STAGES; st++)
+        b->graph[st] = g[st];
+    b->graph_ready = true;
     b->graph_frames = n_frames;
     b->graph_slots = max_slots;
     b->graph_attach_gen = b->attach_gen;
@@ -1608,7 +1727,7 @@ int sdr_graph_launch(sdr_bank *b, const float *const *iq_dev)
 {
     if (!b || !iq_dev)
         return fail(SDR_ERR_BAD_ARG, "null argument");
-    if (!b->graph_exec)
+    if (!b->graph_ready)
         return fail(SDR_ERR_STATE, "no graph captured (sdr_graph_capture)");
     if (b->failed)
         return fail(SDR_ERR_STATE, "an earlier process call failed half way; destroy the bank");
@@ -1619,7 +1738,7 @@ int sdr_graph_launch(sdr_bank *b, const float *const *iq_dev)
         return fail(SDR_ERR_STATE, "listeners were attached or detached since the capture: capture again");
     HIP_TRY(hipSetDevice(b->device));
     const int n_frames = b->graph_frames;
-    CursorBlock blk{};
+    sdr::BatchCursor cursor[RING];
     int count = b->cum_count, carry = b->carry_cur;
     int64_t total = b->total_frames;
     struct Meta {
@@ -1629,10 +1748,11 @@ int sdr_graph_launch(sdr_bank *b, const float *const *iq_dev)
     for (int k = 0; k < RING; k++) {
         if (!iq_dev[k] || (reinterpret_cast<uintptr_t>(iq_dev[k]) & 15))
             return fail(SDR_ERR_BAD_ARG, "every input pointer must be non-null and 16-byte aligned");
-        blk.c[k].iq = iq_dev[k];
-        blk.c[k].frame_base = (uint32_t)total;
-        blk.c[k].count0 = count;
-        blk.c[k].carry_in = carry;
+        cursor[k] = sdr::BatchCursor{};
+        cursor[k].iq = iq_dev[k];
+        cursor[k].frame_base = (uint32_t)total;
+        cursor[k].count0 = count;
+        cursor[k].carry_in = carry;
         meta[k] = {count, sdr::chunks_completed(count, n_frames), total};
         const int new_count = (count + n_frames) % SDR_CUMULATION_SIZE;
         if (new_count != 0)
@@ -1646,48 +1766,49 @@ int sdr_graph_launch(sdr_bank *b, const float *const *iq_dev)
             if (prc)
                 return prc;
         }
-    void *args[2] = {&b->cursors.p, &blk};
-    hipKernelNodeParams kp{};
-    kp.func = reinterpret_cast<void *>(&k_set_cursors);
-    kp.gridDim = dim3(1);
-    kp.blockDim = dim3(64);
-    kp.sharedMemBytes = 0;
-    kp.kernelParams = args;
-    kp.extra = nullptr;
-    hipError_t e = hipGraphExecKernelNodeSetParams(b->graph_exec, b->graph_cursor_node, &kp);
-    if (e != hipSuccess)
-        return fail(SDR_ERR_HIP, std::string("hipGraphExecKernelNodeSetParams: ") + hipGetErrorString(e));
-    e = hipGraphLaunch(b->graph_exec, b->stream[S_FFT]);
-    if (e != hipSuccess) {
-        b->failed = true;
-        return fail(SDR_ERR_HIP, std::string("hipGraphLaunch: ") + hipGetErrorString(e));
+    for (int k = 0; k < RING; k++) {
+        sdr::BatchCursor *dst = b->cursors.p + k;
+        void *args[2] = {&dst, &cursor[k]};
+        hipKernelNodeParams kp{};
+        kp.func = reinterpret_cast<void *>(&k_set_cursor);
+        kp.gridDim = dim3(1);
+        kp.blockDim = dim3(64);
+        kp.sharedMemBytes = 0;
+        kp.kernelParams = args;
+        kp.extra = nullptr;
+        const hipError_t e = hipGraphExecKernelNodeSetParams(b->graph_exec[S_FFT], b->graph_cursor_node[k], &kp);
+        if (e != hipSuccess)
+            return fail(SDR_ERR_HIP, std::string("hipGraphExecKernelNodeSetParams: ") + hipGetErrorString(e));
     }
-    // the replay's results are in the host blocks when the replay has finished on its stream: these are the events
-    // sdr_poll waits for (GPUTEST r03 caught polls returning the previous replay's blocks: the events recorded while
-    // capturing are graph edges, the host saw them as complete)
-    if (b->results_on)
+    // the host's view first (sdr_poll on another thread must find the sets' metadata in place when the events fire)
+    {
+        std::lock_guard<std::mutex> guard(b->res_mu);
         for (int k = 0; k < RING; k++) {
-            e = hipEventRecord(b->set[k].res_listen, b->stream[S_FFT]);
-            if (e == hipSuccess)
-                e = hipEventRecord(b->set[k].res_peaks, b->stream[S_FFT]);
-            if (e != hipSuccess) {
-                b->failed = true;
-                return fail(SDR_ERR_HIP, std::string("hipEventRecord behind the replay: ") + hipGetErrorString(e));
+            BatchSet &S = b->set[k];
+            if (b->results_on) {
+                S.res_batch = b->batch_index + k;
+                S.res_first_frame = meta[k].first_frame;
+                S.res_frames = n_frames;
+                S.res_chunks = meta[k].chunks;
+                S.res_count0 = meta[k].count0;
+                S.res_slots = max_slots;
+                S.res_center = b->center_frequency;
             }
         }
+    }
+    // every graph on the stream it was recorded on; a stream's event records are enqueued before the waits of the
+    // streams that depend on it: FFT, noise, peaks (thresholds), listen
+    static const int order[N_STAGES] = {S_FFT, S_NOISE, S_PEAKS, S_LISTEN};
+    for (int st : order) {
+        const hipError_t e = hipGraphLaunch(b->graph_exec[st], b->stream[st]);
+        if (e != hipSuccess) {
+            b->failed = true;
+            return fail(SDR_ERR_HIP, std::string("hipGraphLaunch: ") + hipGetErrorString(e));
+        }
+    }
     // the host's view of the carried state, batch by batch, as the eager path commits it
     std::lock_guard<std::mutex> guard(b->res_mu);
     for (int k = 0; k < RING; k++) {
-        BatchSet &S = b->set[k];
-        if (b->results_on) {
-            S.res_batch = b->batch_index;
-            S.res_first_frame = meta[k].first_frame;
-            S.res_frames = n_frames;
-            S.res_chunks = meta[k].chunks;
-            S.res_count0 = meta[k].count0;
-            S.res_slots = max_slots;
-            S.res_center = b->center_frequency;
-        }
         b->last_set = k;
         b->last_frames = n_frames;
         b->last_chunks = meta[k].chunks;

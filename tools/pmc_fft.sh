@@ -1,7 +1,8 @@
 #!/bin/bash
-# Development aid: SQ / TCP counters of the standalone k_fft_psd launch (tools/bin/ft_time1, 2048 frames of
-# N = 16384), one rocprofv3 pass per counter group, no trace domains, the program itself after `--`.
-# Output: gpurun_out/pmc_fft.txt (per-dispatch averages over the kernel's launches).
+# Development aid: SQ / TCP counters of the standalone k_fft_psd launch (tools/bin/$BIN, default fb_prod = the production
+# kernel, built by tools/build_tools.sh; 2048 frames of N = 16384), one rocprofv3 pass per counter group, no trace
+# domains, the program itself after `--`.
+# Output: $OUT (default gpurun_out/pmc_fft.txt): the binary's header (flags, source hash) + per-dispatch averages.
 cd /tmp && export TMPDIR=/tmp
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 export SDR_TOOL_SHORT=1 SDR_FFT_FPW=${SDR_FFT_FPW:-1} SDR_TAP=256
@@ -15,9 +16,11 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "TCP_TCP_TA_DATA_STALL_CYCLES TCP_TCC_READ_REQ TCP_TCC_WRITE_REQ TCP_TCR_TCP_STALL_CYCLES" \
            "GRBM_GUI_ACTIVE GRBM_TA_BUSY"; do
   i=$((i+1))
-  timeout -k 10 120 rocprofv3 --pmc $grp -d gpurun_out/pmc_fft -o g$i --output-format csv -- tools/bin/ft_time1 2048 > gpurun_out/pmc_fft_g$i.log 2>&1 || { echo "group $i failed: $grp"; tail -3 gpurun_out/pmc_fft_g$i.log; }
+  timeout -k 10 120 rocprofv3 --pmc $grp -d gpurun_out/pmc_fft -o g$i --output-format csv -- tools/bin/${BIN:-fb_prod} 2048 > gpurun_out/pmc_fft_g$i.log 2>&1 || { echo "group $i failed: $grp"; tail -3 gpurun_out/pmc_fft_g$i.log; }
 done
-python3 - <<'PY' > gpurun_out/pmc_fft.txt
+OUT=${OUT:-gpurun_out/pmc_fft.txt}
+grep '^#' gpurun_out/pmc_fft_g1.log > $OUT
+python3 - <<'PY' >> $OUT
 import csv, collections, glob
 for f in sorted(glob.glob("gpurun_out/pmc_fft/**/g*_counter_collection.csv", recursive=True)):
     agg = collections.defaultdict(list)
@@ -27,4 +30,4 @@ for f in sorted(glob.glob("gpurun_out/pmc_fft/**/g*_counter_collection.csv", rec
     for k, v in agg.items():
         print(f"{k:32s} {sum(v)/len(v):16.0f}  (n={len(v)})")
 PY
-cat gpurun_out/pmc_fft.txt
+cat $OUT

@@ -1,33 +1,62 @@
 #!/bin/bash
-# Runs on the GPU box (from the repo root): everything tools/make_profiles.py condenses into profiles/ for this round.
+# Runs on the GPU box (from the repo root): everything tools/make_profiles.py condenses into profiles/ for a round.
+#
+# Reproducibility: the harness binaries are built BEFOREHAND on the CPU box by tools/build_tools.sh (flags in that
+# script; every binary prints its flags and the sha256 of the kernel sources at the top of its output, and
+# tools/bin/MANIFEST lists name / hash / flags).  This script REFUSES to run a binary whose recorded hash is not the hash
+# of the sources it sits next to, and the production library must have been built from them too.
 # rocprofv3: the program itself after `--`, PMC passes separate from the kernel trace, a timeout on every call.
 cd /tmp && export TMPDIR=/tmp
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/prof_$R
 rm -rf $O && mkdir -p $O
+HASH=$(python3 -c "from sdrainer_amd.csrc import build; print(build.source_hash())")
+[ "$(cat sdrainer_amd/csrc/libsdrainer_hip.so.srchash 2>/dev/null)" = "$HASH" ] || { echo "libsdrainer_hip.so was not built from these sources"; exit 1; }
+need() {  # binary names: each must be in the manifest with the current hash
+  for n in "$@"; do
+    grep -q "^$n $HASH" tools/bin/MANIFEST 2>/dev/null && [ -x tools/bin/$n ] || { echo "tools/bin/$n is missing or stale (tools/build_tools.sh)"; exit 1; }
+  done
+}
+need fb_prod fb_clock fb_phases fb_abl1 fb_abl3 fb_abl5 fb_abl6 fb_abl8 fb_abl10 fb_abl11 fb_abl12 fb_abl13 fb_abl14 fb_abl15 fb_abl16
+cp tools/bin/MANIFEST $O/tool_manifest.txt
+echo "sources sha256 $HASH" > $O/README.txt
 set -e
+
+# 1. the dominant kernel alone: production binary, per-workgroup spans, ablation matrix, phase order
+FPWS="1" tools/fft_matrix.sh $O/fft_standalone.txt fb_prod fb_clock > /dev/null
+FPWS="1" tools/fft_matrix.sh $O/fft_ablation_matrix.txt fb_prod fb_abl1 fb_abl3 fb_abl5 fb_abl6 fb_abl8 fb_abl10 fb_abl11 fb_abl12 fb_abl13 fb_abl14 fb_abl15 fb_abl16 > $O/fft_ablation_summary.txt
+FPWS="1" tools/fft_matrix.sh $O/fft_phases.txt fb_phases > /dev/null
+echo "fft standalone done"
+
+# 2. SQ / TCP counters of the standalone production launch (one pass per group)
+BIN=fb_prod OUT=$O/fft_sq_counters.txt tools/pmc_fft.sh > /dev/null 2>&1 || true
+
+# 3. the whole pipeline: kernel trace, HBM traffic (separate PMC passes), bench lines
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- python3 bench.py --steps 400 --warmup 40 --no-cpu-baseline > $O/rocprof_bench.log 2>&1
 echo "kernel trace done"
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o fetch --output-format csv -- python3 bench.py --steps 3 --warmup 1 --settle-ms 0 --no-cpu-baseline --serial > $O/pmc_fetch.log 2>&1
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE -d $O/write -o write --output-format csv -- python3 bench.py --steps 3 --warmup 1 --settle-ms 0 --no-cpu-baseline --serial > $O/pmc_write.log 2>&1
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE -d $O/fetch_c5 -o fetch --output-format csv -- python3 bench.py --workload c5 --steps 3 --warmup 1 --settle-ms 0 --no-cpu-baseline --serial > $O/pmc_fetch_c5.log 2>&1
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE -d $O/write_c5 -o write --output-format csv -- python3 bench.py --workload c5 --steps 3 --warmup 1 --settle-ms 0 --no-cpu-baseline --serial > $O/pmc_write_c5.log 2>&1
 echo "pmc done"
 python bench.py > $O/bench_full.json 2> $O/bench_full.err
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_steps20.json 2> /dev/null
 echo "bench done"
 python bench.py --steps 300 --warmup 30 --kernel-breakdown --no-cpu-baseline --serial > $O/bench_serial.json 2> $O/bench_serial.err
 python bench.py --steps 1000 --warmup 100 --kernel-breakdown --no-cpu-baseline > $O/bench_insitu.json 2> $O/bench_insitu.err
-python bench.py --steps 996 --warmup 96 --no-cpu-baseline --graph > $O/bench_graph_c3.json 2>/dev/null
 python bench.py --workload c5 --steps 600 --warmup 60 --no-cpu-baseline > $O/bench_c5.json 2>/dev/null
-python bench.py --workload c5 --steps 600 --warmup 60 --no-cpu-baseline --graph > $O/bench_graph_c5.json 2>/dev/null
 python bench.py --workload c2 --frames 4096 --steps 600 --warmup 60 --no-cpu-baseline > $O/bench_c2.json 2>/dev/null
 python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-delivery > $O/bench_nodelivery.json 2>/dev/null
-python tools/host_input_rate.py > $O/host_input_rate.txt 2>&1
-timeout -k 10 300 python tools/strain_e2e.py > $O/strain_e2e.json 2>/dev/null
-SDR_TAP=256 SDR_TRACE_QUIET=1 SDR_FFT_FPW=1 tools/bin/ft_clock1 2048 > $O/fft_workgroup_spans.txt 2>&1
-SDR_FFT_FPW=1 tools/pmc_fft.sh > /dev/null 2>&1 && cp gpurun_out/pmc_fft.txt $O/fft_sq_counters.txt
-# what DESIGN.md section 5 quotes about sharing a CU and about the FFT inside the pipeline
-tools/bin/ubench_share > $O/ubench_share.txt 2>&1 || true
-if [ -f tools/abl/libfftclk.so ]; then SDR_HIP_LIB=$PWD/tools/abl/libfftclk.so python tools/insitu_fft.py > $O/fft_insitu_spans.txt 2>&1 || true; fi
-if [ -f tools/abl/libdiag.so ]; then tools/ab_skip.sh 0 254 128 32 2 64 160 0 > $O/skip_matrix.txt 2>&1 || true; fi
+# hipGraph A/B: five fresh processes per workload (the stability claim is about fresh processes)
+for i in 1 2 3 4 5; do
+  python bench.py --workload c5 --steps 600 --warmup 60 --no-cpu-baseline --graph > $O/bench_graph_c5_$i.json 2>/dev/null || true
+done
+for i in 1 2 3; do
+  python bench.py --steps 996 --warmup 96 --no-cpu-baseline --graph > $O/bench_graph_c3_$i.json 2>/dev/null || true
+done
+python tools/host_input_rate.py > $O/host_input_rate.txt 2>&1 || true
+timeout -k 10 300 python tools/strain_e2e.py > $O/strain_e2e.json 2>/dev/null || true
+[ -x tools/bin/ubench_mfma_f64 ] && timeout -k 5 120 tools/bin/ubench_mfma_f64 > $O/mfma_f64.txt 2>&1 || true
 echo "all done"
 tail -c 600 $O/bench_full.json
