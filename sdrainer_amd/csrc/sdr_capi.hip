@@ -21,6 +21,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <memory>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -91,6 +94,7 @@ int ilog2(int n)
 const char *kKernelNames[sdr::K_COUNT] = {"k_fft_psd",       "k_window_means", "k_noise_stats", "k_thresholds",
                                           "k_listen_gather", "k_cumulate",     "k_find_peaks",  "k_listen_decode"};
 
+constexpr int GRAPH_PHASES = 4;  // graph mode: replays in flight, each with RING buffer sets of its own (sdr_graph_capture)
 constexpr int RING = 6;  // per-batch buffer sets in flight (a batch lives about four FFT launches from its FFT to its last result)
 enum Stage { S_FFT = 0, S_NOISE, S_LISTEN, S_PEAKS, N_STAGES };  // the bank's streams: four = the hardware queues HIP gives a process; with six streams created (two unused!) the step was 0.49 ms instead of 0.25, with GPU_MAX_HW_QUEUES=8 and five or six in use 0.29-0.60
 
@@ -166,7 +170,7 @@ struct sdr_bank {
     DevBuf<unsigned char> db_tab;   // gomath.h tables of the certified dB shortcut (k_cumulate)
     DevBuf<int32_t> tap_bins;       // [band][L] bin of every listener slot, -1 = free (k_fft_psd tap)
     DevBuf<float> spectrum_row;     // scratch of sdr_read_spectrum
-    BatchSet set[RING];
+    std::vector<BatchSet> set;  // RING sets; graph mode adds its own (sdr_graph_capture)
     DevBuf<sdr::BandState> band_state;
     DevBuf<sdr::ListenerSlot> slots;  // [band][max_listeners]
     DevBuf<uint16_t> morse;
@@ -187,11 +191,15 @@ struct sdr_bank {
     int find_peaks = 1;
     bool failed = false;  // a HIP call failed in the middle of a launch sequence: device state is unknown
     DevBuf<sdr::DropCounters> drops;
-    // graph mode (sdr_graph_*): RING consecutive batches captured as one linear hipGraph PER STREAM
-    DevBuf<sdr::BatchCursor> cursors;  // [RING]
-    hipGraph_t graph[N_STAGES] = {};
-    hipGraphExec_t graph_exec[N_STAGES] = {};
-    hipGraphNode_t graph_cursor_node[RING] = {};  // the FFT stream's graph: the node that writes batch k's cursor
+    // graph mode (sdr_graph_*): RING consecutive batches as one linear, kernel-only hipGraph PER STREAM; GRAPH_PHASES
+    // such groups of four graphs, each over buffer sets of its own, so that consecutive replays overlap stage by stage
+    DevBuf<sdr::BatchCursor> cursors;  // [GRAPH_PHASES][RING]
+    hipGraph_t graph[GRAPH_PHASES][N_STAGES] = {};
+    hipGraphExec_t graph_exec[GRAPH_PHASES][N_STAGES] = {};
+    hipGraphNode_t graph_cursor_node[GRAPH_PHASES][RING] = {};  // the FFT graph's node that writes batch k's cursor
+    hipEvent_t phase_done[GRAPH_PHASES][N_STAGES] = {};         // recorded behind each graph of a replay
+    int64_t graph_base = 0;     // batch_index at the capture
+    int64_t graph_replays = 0;  // launches since the capture
     bool graph_ready = false;
     int graph_frames = 0, graph_slots = 0;
     uint64_t attach_gen = 0, graph_attach_gen = 0;  // sdr_attach / sdr_detach calls so far; as of the capture
@@ -203,13 +211,16 @@ struct sdr_bank {
         int64_t batch, first_frame;
         int frames, chunks, count0, slots;
         std::vector<int64_t> center;
-        std::vector<unsigned char> block;
+        std::unique_ptr<unsigned char[]> block;  // laid out like a set's block; only the used entries are filled in
     };
     std::deque<Parked> parked;
     // sdr_poll may run on a consumer thread of its own beside the producer's process calls (the reference's
     // Reporter is called from other goroutines too): the delivery bookkeeping - parked, deliver_next, the sets'
     // res_* fields, batch_index as sdr_poll reads it - is guarded by this mutex.
     std::mutex res_mu;
+    std::condition_variable res_cv;  // a batch was delivered (a producer about to reuse a set may be waiting for that)
+    int pollers_waiting = 0;         // threads inside sdr_poll(wait = 1)
+    std::chrono::steady_clock::time_point last_poll{};  // when sdr_poll last returned
     int64_t batches_enqueued = 0;  // == batch_index, published under res_mu
 
     // Host-fed input (sdr_push_iq / sdr_push_kiwi_snd -> sdr_process_staged).  Three staging sets rotate, so the
@@ -332,50 +343,6 @@ size_t utf8_encode(uint32_t r, char *out)
     return 3;
 }
 
-// An external event wait inside an open stream capture.  hipStreamWaitEvent(..., hipEventWaitExternal) behind a kernel
-// node throws std::bad_alloc inside the runtime (ROCm 7.2; tools/experiments/probe_graph_ext.hip, scenario 3), so the
-// wait node is added to the capture's graph by hand, behind the stream's current dependency set, and made the
-// dependency of whatever the stream captures next.
-hipError_t capture_wait_external(hipStream_t stream, hipEvent_t event)
-{
-    hipStreamCaptureStatus status;
-    unsigned long long id = 0;
-    hipGraph_t graph = nullptr;
-    const hipGraphNode_t *deps = nullptr;
-    size_t n_deps = 0;
-    hipError_t e = hipStreamGetCaptureInfo_v2(stream, &status, &id, &graph, &deps, &n_deps);
-    if (e != hipSuccess)
-        return e;
-    if (status != hipStreamCaptureStatusActive || !graph)
-        return hipErrorStreamCaptureInvalidated;
-    hipGraphNode_t wait_node = nullptr;
-    e = hipGraphAddEventWaitNode(&wait_node, graph, deps, n_deps, event);
-    if (e != hipSuccess)
-        return e;
-    return hipStreamUpdateCaptureDependencies(stream, &wait_node, 1, hipStreamSetCaptureDependencies);
-}
-
-// ... and the record side the same way (hipEventRecordWithFlags(..., hipEventRecordExternal) is refused with "invalid
-// argument" by the HIP runtime PyTorch brings along, which is the one a Python process ends up with)
-hipError_t capture_record_external(hipStream_t stream, hipEvent_t event)
-{
-    hipStreamCaptureStatus status;
-    unsigned long long id = 0;
-    hipGraph_t graph = nullptr;
-    const hipGraphNode_t *deps = nullptr;
-    size_t n_deps = 0;
-    hipError_t e = hipStreamGetCaptureInfo_v2(stream, &status, &id, &graph, &deps, &n_deps);
-    if (e != hipSuccess)
-        return e;
-    if (status != hipStreamCaptureStatusActive || !graph)
-        return hipErrorStreamCaptureInvalidated;
-    hipGraphNode_t node = nullptr;
-    e = hipGraphAddEventRecordNode(&node, graph, deps, n_deps, event);
-    if (e != hipSuccess)
-        return e;
-    return hipStreamUpdateCaptureDependencies(stream, &node, 1, hipStreamSetCaptureDependencies);
-}
-
 // graph mode: what differs between the batches of a replay lives in device-side cursors; batch k's is written by a node
 // of the FFT stream's graph right in front of that batch's FFT
 __global__ void k_set_cursor(sdr::BatchCursor *dst, sdr::BatchCursor v)
@@ -429,15 +396,39 @@ sdr::ResultsLayout make_results_layout(const sdr_bank *b)
     return l;
 }
 
-// The set is about to be reused while its results were never polled: wait for them and keep a compact copy on
-// the host (the reference's io.Writer never drops).  Only the used parts of the block are copied.
+// The set is about to be reused while its results were never polled: wait for them, and then either let a consumer
+// thread that is polling take the batch (it is blocked on the same events, or between two polls) or keep a copy on the
+// host (the reference's io.Writer never drops; a caller that enqueues many batches and polls afterwards must find them
+// all).  Only the used entries of the block are copied.
 int park_results(sdr_bank *b, BatchSet &S)
 {
-    std::lock_guard<std::mutex> guard(b->res_mu);
+    std::unique_lock<std::mutex> guard(b->res_mu);
     if (S.res_batch < 0)
         return SDR_OK;
-    HIP_TRY(hipEventSynchronize(S.res_listen));
-    HIP_TRY(hipEventSynchronize(S.res_peaks));
+    const int64_t batch = S.res_batch;
+    // (not under the mutex: the consumer must be able to take older batches, and this one, meanwhile; nobody but this
+    // thread - the producer - puts a new batch into the set)
+    guard.unlock();
+    hipError_t we = hipEventSynchronize(S.res_listen);
+    if (we == hipSuccess)
+        we = hipEventSynchronize(S.res_peaks);
+    guard.lock();
+    HIP_TRY(we);
+    // a consumer is at work if a thread sits in sdr_poll(wait) or left it a moment ago: it delivers in order, so it
+    // gets to this batch as long as it makes progress
+    while (S.res_batch == batch) {
+        const bool consumer = b->pollers_waiting > 0 || std::chrono::steady_clock::now() - b->last_poll < std::chrono::milliseconds(2);
+        if (!consumer)
+            break;
+        const int64_t before = b->deliver_next;
+        b->res_cv.wait_for(guard, std::chrono::microseconds(500));
+        if (b->deliver_next == before && S.res_batch == batch && b->pollers_waiting == 0)
+            break;  // it went away
+    }
+    if (S.res_batch != batch)
+        return SDR_OK;
+    const sdr::ResultsLayout &lay = b->res_layout;
+    const sdr_config &c = b->cfg;
     sdr_bank::Parked p;
     p.batch = S.res_batch;
     p.first_frame = S.res_first_frame;
@@ -446,8 +437,32 @@ int park_results(sdr_bank *b, BatchSet &S)
     p.count0 = S.res_count0;
     p.slots = S.res_slots;
     p.center = S.res_center;
-    // (a full copy keeps one decoding routine; batches are parked only when the caller polls too rarely)
-    p.block.assign(S.res_host, S.res_host + b->res_layout.bytes);
+    p.block.reset(new unsigned char[lay.bytes]);
+    unsigned char *dst = p.block.get();
+    const unsigned char *src = S.res_host;
+    auto copy = [&](size_t off, size_t bytes) { memcpy(dst + off, src + off, bytes); };
+    const size_t B = (size_t)c.n_bands, L = (size_t)c.max_listeners, C = (size_t)lay.max_chunks;
+    copy(lay.off_drops, sizeof(sdr::DropCounters));
+    copy(lay.off_peak_counts, B * C * 2 * sizeof(int));
+    copy(lay.off_edge_counts, B * L * sizeof(uint32_t));
+    copy(lay.off_text_counts, B * L * sizeof(uint32_t));
+    const int *peak_counts = reinterpret_cast<const int *>(src + lay.off_peak_counts);
+    const uint32_t *edge_counts = reinterpret_cast<const uint32_t *>(src + lay.off_edge_counts);
+    const uint32_t *text_counts = reinterpret_cast<const uint32_t *>(src + lay.off_text_counts);
+    for (size_t band = 0; band < B; band++) {
+        for (size_t ch = 0; ch < (size_t)p.chunks && ch < C; ch++) {
+            const size_t idx = band * C + ch;
+            const size_t n = (size_t)std::min(std::max(peak_counts[2 * idx], 0), lay.max_peaks);
+            copy(lay.off_peaks + idx * (size_t)lay.max_peaks * sizeof(sdr::DevPeak), n * sizeof(sdr::DevPeak));
+        }
+        for (size_t l = 0; l < (size_t)p.slots && l < L; l++) {
+            const size_t idx = band * L + l;
+            const size_t ne = std::min<size_t>(edge_counts[idx], (size_t)lay.edge_cap), nr = std::min<size_t>(text_counts[idx], (size_t)lay.text_cap);
+            copy(lay.off_edges + idx * (size_t)lay.edge_cap * sizeof(sdr_edge), ne * sizeof(sdr_edge));
+            copy(lay.off_text + idx * (size_t)lay.text_cap * sizeof(uint32_t), nr * sizeof(uint32_t));
+            copy(lay.off_text_frames + idx * (size_t)lay.text_cap * sizeof(uint32_t), nr * sizeof(uint32_t));
+        }
+    }
     b->parked.push_back(std::move(p));
     S.res_batch = -1;
     return SDR_OK;
@@ -462,17 +477,15 @@ constexpr int kDefaultPlan[sdr::K_COUNT] = {
     /* gather */ S_LISTEN, /* cumulate */ S_PEAKS, /* find peaks */ S_PEAKS, /* decode */ S_LISTEN};
 
 // capture_stage: while capturing, ONE stream records at a time (sdr_graph_capture walks the batches once per stream):
-// only what is enqueued on that stream - its kernels, its event records, its waits - is issued, everything else of the
-// batch is skipped in that walk.
+// only the kernels of that stream are issued, everything else of the batch is skipped in that walk, and NO event is
+// recorded or waited for - what orders the streams of a replay are events around whole graphs (sdr_graph_launch).
 // capture_k >= 0: the call is being recorded into a graph as its batch number capture_k (sdr_graph_capture).  Then
-// the batch uses buffer set capture_k, everything that differs from batch to batch comes from the device-side
+// the batch uses buffer set RING + capture_k, everything that differs from batch to batch comes from the device-side
 // cursor of that number instead of the launch parameters, grids cover the most chunks a batch of this length can
 // complete, nothing is asked of the host (no event queries, no profiling, no parking) and no host state changes.
 int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_stride, int capture_k, int capture_stage)
 {
     const bool cap = capture_k >= 0;
-    static const bool pdbg = getenv("SDR_GRAPH_DEBUG") != nullptr;
-#define PDBG(msg) do { if (pdbg && cap) { hipStreamCaptureStatus cs_ = hipStreamCaptureStatusNone; (void)hipStreamIsCapturing(b->stream[capture_stage], &cs_); fprintf(stderr, "[graph body %d stage %d] %s (capture status %d)\n", capture_k, capture_stage, msg, (int)cs_); fflush(stderr); } } while (0)
     const sdr::BatchCursor *cur = cap ? b->cursors.p + capture_k : nullptr;
     const sdr_config &c = b->cfg;
     if (n_frames <= 0)
@@ -487,11 +500,13 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     HIP_TRY(hipSetDevice(b->device));
     const int B = c.n_bands, N = c.block_size, stride = c.max_batch_frames;
     const sdr::NoiseGeom ng = b->noise_geom();
-    const int si = cap ? capture_k : (int)(b->batch_index % RING);
+    const int si = cap ? RING + capture_k : (int)(b->batch_index % RING);  // (capture: the sets sdr_graph_capture added)
     BatchSet &S = b->set[si];
     int plan[sdr::K_COUNT];
     for (int k = 0; k < sdr::K_COUNT; k++)
         plan[k] = kDefaultPlan[k];
+    if (cap)  // the noise graph ends with the thresholds: the peaks graph and the listen graph both start behind it
+        plan[sdr::K_THRESHOLDS] = S_NOISE;
     // is kernel k's stream the one that is recording (always, outside a capture)?
 #define SDR_ON(k) (!cap || plan[k] == capture_stage)
 #if defined(SDR_DIAG)
@@ -515,15 +530,9 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
 #endif
     auto stream_of = [&](int k) { return b->stream[plan[k]]; };
     // kernel k of this batch may start once kernel `dep` of this batch is done (nothing to do on the same stream)
-    // (while capturing, every stream records a graph of its own: an event that crosses streams is an EXTERNAL event
-    // node - it is recorded and waited for at replay time like the eager path's events, it does not merge the captures)
     auto after = [&](int k, int dep) -> int {
-        if (stream_of(k) != stream_of(dep) && SDR_ON(k)) {
-            if (cap)
-                HIP_TRY(capture_wait_external(stream_of(k), S.done[dep]));
-            else
-                HIP_TRY(hipStreamWaitEvent(stream_of(k), S.done[dep], 0));
-        }
+        if (stream_of(k) != stream_of(dep) && !cap)
+            HIP_TRY(hipStreamWaitEvent(stream_of(k), S.done[dep], 0));
         return SDR_OK;
     };
 #define SDR_AFTER(k, dep)          \
@@ -539,9 +548,9 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
 #define SDR_ARM(k) (sdr::t_done_event = ride ? S.done[k] : nullptr)
 #define SDR_DONE(k)                                                                                   \
     do {                                                                                              \
-        if ((!ride || sdr::t_done_event) && SDR_ON(k)) {                                              \
+        if ((!ride || sdr::t_done_event) && !cap) {                                                   \
             sdr::t_done_event = nullptr;                                                              \
-            HIP_TRY(cap ? capture_record_external(stream_of(k), S.done[k]) : hipEventRecord(S.done[k], stream_of(k))); \
+            HIP_TRY(hipEventRecord(S.done[k], stream_of(k)));                                         \
         }                                                                                             \
     } while (0)
 
@@ -569,13 +578,8 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
             const int k = last_on[st];
             if (k < 0 || st == plan[sdr::K_FFT])
                 continue;
-            if (cap) {
-                // a replay's FFT of set k waits for the PREVIOUS replay's readers of set k (the streams replay
-                // graphs of their own and run ahead of each other exactly as the eager pipeline does)
-                if (SDR_ON(sdr::K_FFT))
-                    HIP_TRY(capture_wait_external(stream_of(sdr::K_FFT), S.done[k]));
+            if (cap)  // (sdr_graph_launch waits for the earlier replay that used this phase's sets)
                 continue;
-            }
             if (hipEventQuery(S.done[k]) == hipSuccess)
                 continue;
             if (host_waits)
@@ -584,8 +588,7 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
                 HIP_TRY(hipStreamWaitEvent(stream_of(sdr::K_FFT), S.done[k], 0));
         }
     }
-    PDBG("reuse waits done");
-    if (cap && SDR_ON(sdr::K_FFT))  // this batch's cursor: behind the waits above, so no kernel of the previous replay still reads it
+    if (cap && SDR_ON(sdr::K_FFT))  // this batch's cursor, in front of its FFT
         hipLaunchKernelGGL(k_set_cursor, dim3(1), dim3(64), 0, stream_of(sdr::K_FFT), b->cursors.p + capture_k, sdr::BatchCursor{});
     int max_slots = 0, slots_in_use = 0;
     for (int i = 0; i < B; i++) {
@@ -597,7 +600,6 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         if (prc)
             return prc;
     }
-    PDBG("cursor kernel launched");
     {
         ProfScope ps(b, sdr::K_FFT, stream_of(sdr::K_FFT));
         SDR_ARM(sdr::K_FFT);
@@ -605,9 +607,7 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         SDR_LAUNCH(sdr::K_FFT, sdr::launch_fft(b->logn, iq_dev, cur, b->tw.p, S.psd.p, n_frames, B, in_stride, stride, tap,
                                                stream_of(sdr::K_FFT)));
     }
-    PDBG("fft launched");
     SDR_DONE(sdr::K_FFT);
-    PDBG("fft event");
 
     // noise floor (stateless per batch), then the rolling means -> thresholds, in batch order
     SDR_AFTER(sdr::K_WINDOW_MEANS, sdr::K_FFT);
@@ -634,7 +634,6 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
                                                              stream_of(sdr::K_THRESHOLDS)));
     }
     SDR_DONE(sdr::K_THRESHOLDS);
-    PDBG("noise + thresholds");
 
     // per-signal envelope + decoder
     sdr::ListenGeom lg;
@@ -673,13 +672,10 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         SDR_ARM(sdr::K_LISTEN_DECODE);
         HIP_TRY(sdr::launch_pack_listen(b->slots.p, S.edges.p, S.edge_counts.p, b->text.p, b->text_frames.p, b->drops.p, b->res_layout, max_slots, B,
                                         S.res_host, stream_of(sdr::K_LISTEN_DECODE)));
-        // (inside a capture: an external event node, recorded at replay time - sdr_poll waits for it like for the
-        // eager path's)
-        HIP_TRY(cap ? capture_record_external(stream_of(sdr::K_LISTEN_DECODE), S.res_listen)
-                    : hipEventRecord(S.res_listen, stream_of(sdr::K_LISTEN_DECODE)));
+        if (!cap)  // (a replay records it behind the listen graph)
+            HIP_TRY(hipEventRecord(S.res_listen, stream_of(sdr::K_LISTEN_DECODE)));
     }
     SDR_DONE(sdr::K_LISTEN_DECODE);
-    PDBG("listen");
 
     // dB projection + cumulation, peak scan (rx/receiver.go:404-409,459-460)
     const int count0 = b->cum_count;
@@ -718,8 +714,8 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         SDR_ARM(sdr::K_FIND_PEAKS);
         HIP_TRY(sdr::launch_pack_peaks(S.dev_peaks.p, S.peak_counts.p, cur, b->res_layout, b->find_peaks, n_frames, n_chunks, B,
                                        S.res_host, stream_of(sdr::K_FIND_PEAKS)));
-        HIP_TRY(cap ? capture_record_external(stream_of(sdr::K_FIND_PEAKS), S.res_peaks) : hipEventRecord(S.res_peaks, stream_of(sdr::K_FIND_PEAKS)));
         if (!cap) {
+            HIP_TRY(hipEventRecord(S.res_peaks, stream_of(sdr::K_FIND_PEAKS)));
             std::lock_guard<std::mutex> guard(b->res_mu);
             S.res_batch = b->batch_index;
             S.res_first_frame = b->total_frames;
@@ -732,7 +728,6 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         }
     }
     SDR_DONE(sdr::K_FIND_PEAKS);
-    PDBG("peaks");
 #undef SDR_AFTER
 #undef SDR_DONE
 #undef SDR_ARM
@@ -764,7 +759,76 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
 // graph's first node from its kernel arguments
 // (one node per batch; its kernel argument is what a replay updates)
 
+void drop_graphs(sdr_bank *b)
+{
+    for (int ph = 0; ph < GRAPH_PHASES; ph++) {
+        for (int st = 0; st < N_STAGES; st++) {
+            if (b->graph_exec[ph][st])
+                (void)hipGraphExecDestroy(b->graph_exec[ph][st]);
+            if (b->graph[ph][st])
+                (void)hipGraphDestroy(b->graph[ph][st]);
+            b->graph_exec[ph][st] = nullptr;
+            b->graph[ph][st] = nullptr;
+        }
+        for (auto &n : b->graph_cursor_node[ph])
+            n = nullptr;
+    }
+}
+
+// the buffer set of batch `batch` (graph mode: phase-major, the sets behind the eager ring's)
+inline int set_index(const sdr_bank *b, int64_t batch)
+{
+    if (!b->graph_ready)
+        return (int)(batch % RING);
+    return RING + (int)((batch - b->graph_base) % (GRAPH_PHASES * RING));
+}
 }  // namespace
+
+// one batch's buffers, stage events and (if bulk delivery is on) its block of pinned host memory
+static hipError_t alloc_set(sdr_bank *b, BatchSet &S)
+{
+    const sdr_config &c = b->cfg;
+    const size_t B = (size_t)c.n_bands, F = (size_t)c.max_batch_frames, L = (size_t)c.max_listeners, N = (size_t)c.block_size;
+    hipError_t e = hipSuccess;
+#define SET_ALLOC(buf, count)            \
+    do {                                 \
+        if (e == hipSuccess)             \
+            e = (buf).alloc(count);      \
+    } while (0)
+    SET_ALLOC(S.psd, B * F * N);
+    SET_ALLOC(S.tap, B * F * std::max<size_t>(L, 1));
+    SET_ALLOC(S.win_mean, B * F * 10);
+    SET_ALLOC(S.recs, B * F);
+    SET_ALLOC(S.raw_bits, B * L * (size_t)b->bit_words);
+    SET_ALLOC(S.bits, B * L * (size_t)b->bit_words);
+    SET_ALLOC(S.edges, B * L * (size_t)b->edge_cap);
+    SET_ALLOC(S.edge_counts, B * L);
+    if (c.trace) {
+        SET_ALLOC(S.tr_values, B * F * L);
+        SET_ALLOC(S.tr_raw, B * F * L);
+        SET_ALLOC(S.tr_deb, B * F * L);
+    }
+    SET_ALLOC(S.cum_out, B * (size_t)b->max_chunks * N);
+    SET_ALLOC(S.dev_peaks, B * (size_t)b->max_chunks * (size_t)c.max_peaks);
+    SET_ALLOC(S.peak_counts, B * (size_t)b->max_chunks);
+#undef SET_ALLOC
+#ifndef SDR_STAGE_EVENT_FLAGS
+#define SDR_STAGE_EVENT_FLAGS hipEventDisableTiming
+#endif
+    for (auto &ev : S.done)
+        if (e == hipSuccess)
+            e = hipEventCreateWithFlags(&ev, SDR_STAGE_EVENT_FLAGS);
+    if (e == hipSuccess && b->res_layout.bytes && !S.res_host) {
+        e = hipHostMalloc(reinterpret_cast<void **>(&S.res_host), b->res_layout.bytes, hipHostMallocDefault);
+        if (e == hipSuccess) {
+            memset(S.res_host, 0, b->res_layout.bytes);
+            e = hipEventCreateWithFlags(&S.res_listen, hipEventDisableTiming);
+        }
+        if (e == hipSuccess)
+            e = hipEventCreateWithFlags(&S.res_peaks, hipEventDisableTiming);
+    }
+    return e;
+}
 
 extern "C" {
 #pragma GCC visibility push(default)
@@ -843,38 +907,17 @@ int sdr_create(const sdr_config *cfg, sdr_bank **out)
             return fail(SDR_ERR_HIP, "twiddle / table upload failed");
         }
     }
+    b->set.resize(RING);
     for (int r = 0; r < RING; r++) {
-        BatchSet &S = b->set[r];
-        ALLOC(S.psd, B * F * N);
-        ALLOC(S.tap, B * F * std::max<size_t>(L, 1));
-        ALLOC(S.win_mean, B * F * 10);
-        ALLOC(S.recs, B * F);
-        ALLOC(S.raw_bits, B * L * (size_t)b->bit_words);
-        ALLOC(S.bits, B * L * (size_t)b->bit_words);
-        ALLOC(S.edges, B * L * (size_t)b->edge_cap);
-        ALLOC(S.edge_counts, B * L);
-        if (cfg->trace) {
-            ALLOC(S.tr_values, B * F * L);
-            ALLOC(S.tr_raw, B * F * L);
-            ALLOC(S.tr_deb, B * F * L);
-        }
-        ALLOC(S.cum_out, B * (size_t)b->max_chunks * N);
-        ALLOC(S.dev_peaks, B * (size_t)b->max_chunks * (size_t)cfg->max_peaks);
-        ALLOC(S.peak_counts, B * (size_t)b->max_chunks);
-        for (auto &e : S.done) {
-#ifndef SDR_STAGE_EVENT_FLAGS
-#define SDR_STAGE_EVENT_FLAGS hipEventDisableTiming
-#endif
-            hipError_t he = hipEventCreateWithFlags(&e, SDR_STAGE_EVENT_FLAGS);
-            if (he != hipSuccess) {
-                sdr_destroy(b);
-                return fail(SDR_ERR_HIP, "hipEventCreate failed");
-            }
+        const hipError_t se = alloc_set(b, b->set[r]);
+        if (se != hipSuccess) {
+            sdr_destroy(b);
+            return fail(SDR_ERR_HIP, std::string("allocating a batch buffer set: ") + hipGetErrorString(se));
         }
     }
     ALLOC(b->band_state, B);
     ALLOC(b->drops, 1);
-    ALLOC(b->cursors, RING);
+    ALLOC(b->cursors, GRAPH_PHASES * RING);
     ALLOC(b->spectrum_row, (size_t)N);
     ALLOC(b->tap_bins, B * std::max<size_t>(L, 1));
     {
@@ -922,12 +965,11 @@ int sdr_destroy(sdr_bank *b)
     for (int s = 0; s < N_STAGES; s++)
         (void)hipStreamSynchronize(b->stream[s]);
     resolve_profile(b);
-    for (int st = 0; st < N_STAGES; st++) {
-        if (b->graph_exec[st])
-            (void)hipGraphExecDestroy(b->graph_exec[st]);
-        if (b->graph[st])
-            (void)hipGraphDestroy(b->graph[st]);
-    }
+    drop_graphs(b);
+    for (auto &ph : b->phase_done)
+        for (auto &ev : ph)
+            if (ev)
+                (void)hipEventDestroy(ev);
     b->tw.release();
     b->drops.release();
     b->cursors.release();
@@ -1566,18 +1608,26 @@ int sdr_read_decoder_state(sdr_bank *b, int band, int lid, double *out12)
 }
 
 // ---- graph mode ------------------------------------------------------------------------------------------------
-// RING consecutive batches recorded once and replayed: ONE LINEAR GRAPH PER STREAM of the bank (the FFT stream's, the
-// noise, peaks and listen streams'), each holding its stream's kernels of the six batches in order, with the events
-// that cross streams as external event record / wait nodes - the same events, in the same places, as the eager path.
-// A replay is four hipGraphLaunch calls, each on the stream it was recorded on: every stage keeps its own hardware
-// queue, consecutive replays overlap like consecutive eager batches do, and the host enqueues four commands per six
-// batches instead of sixty.  (Round 2 captured one graph with fork / join over the four streams: the runtime put its
-// branches on queues of its own choosing - 7-10 % slower than eager and, one process in three, three times slower - and
-// a replay, being one stream operation, could not overlap the next one.)
+// RING consecutive batches recorded once and replayed as FOUR LINEAR, KERNEL-ONLY GRAPHS, one per stream of the bank:
+// the FFT graph (cursor + FFT of the six batches), the noise graph (window means, statistics, thresholds), the peaks
+// graph (cumulate, find peaks, pack) and the listen graph (gather, decode, pack).  Inside a replay the streams are
+// ordered by ordinary events around whole graphs (FFT -> noise -> {peaks, listen}); replay r+1's FFT graph runs while
+// replay r's noise graph and replay r-1's peaks / listen graphs do - the same kernels side by side as in the eager
+// pipeline, only taken from different replays.  That needs buffer sets per replay in flight: GRAPH_PHASES groups of RING
+// sets, each group with graphs of its own (the buffers are baked into the kernel nodes), used round robin.
+// The host enqueues per six batches: 4 graph launches, 5 event waits, 4 + 12 event records (sixty-odd commands eager).
+// Why not one graph per replay, or events inside the graphs (both were built and measured, rounds 2 and 3):
+//  - one graph with fork / join over four streams: the runtime maps its branches to queues of its own choosing (7-10 %
+//    slower than eager; one process in three, three times slower) and a replay, being one stream operation, cannot
+//    overlap the next one;
+//  - per-stream graphs stitched by EXTERNAL event nodes at batch granularity (the eager path's events, in the same
+//    places): correct, but every such node costs 70-120 us at replay (c3: 15-21 GS/s against 153 eager); and the
+//    capture API for them is broken in this runtime (hipStreamWaitEvent(External) behind a kernel node throws
+//    std::bad_alloc, several captures open at once corrupt memory: tools/experiments/probe_graph_ext.hip).
 // What differs between batches (input pointer, frame numbering, cumulation phase, carry buffer) is read by the kernels
-// from device-side cursors; batch k's cursor is written by a node of the FFT stream's graph right in front of that
-// batch's FFT, behind the waits for the previous replay's readers of set k; its kernel argument is the only thing a
-// replay updates (hipGraphExecKernelNodeSetParams), so no host memory is read while a replay runs.
+// from device-side cursors; batch k's cursor is written by a node of the FFT graph right in front of that batch's FFT;
+// its kernel argument is the only thing a replay updates (hipGraphExecKernelNodeSetParams), so no host memory is read
+// while a replay runs.
 int sdr_graph_batches(sdr_bank *b) { return b ? RING : 0; }
 
 int sdr_graph_release(sdr_bank *b)
@@ -1587,16 +1637,12 @@ int sdr_graph_release(sdr_bank *b)
     int rc = sync_bank(b);
     if (rc)
         return rc;
-    for (int st = 0; st < N_STAGES; st++) {
-        if (b->graph_exec[st])
-            (void)hipGraphExecDestroy(b->graph_exec[st]);
-        if (b->graph[st])
-            (void)hipGraphDestroy(b->graph[st]);
-        b->graph_exec[st] = nullptr;
-        b->graph[st] = nullptr;
-    }
-    for (auto &n : b->graph_cursor_node)
-        n = nullptr;
+    // results not polled yet move to the host-side queue: the eager ring takes over from here
+    if (b->results_on && b->graph_ready)
+        for (int64_t i = std::max(b->deliver_next, b->graph_base); i < b->batch_index; i++)
+            if ((rc = park_results(b, b->set[set_index(b, i)])))
+                return rc;
+    drop_graphs(b);
     b->graph_ready = false;
     return SDR_OK;
 }
@@ -1620,64 +1666,62 @@ int sdr_graph_capture(sdr_bank *b, int n_frames)
         for (auto &S : b->set)
             if ((rc = park_results(b, S)))
                 return rc;
-    static const bool dbg = getenv("SDR_GRAPH_DEBUG") != nullptr;
-#define GDBG(msg) do { if (dbg) { fprintf(stderr, "[graph] %s\n", msg); fflush(stderr); } } while (0)
-    GDBG("enter");
     HIP_TRY(hipSetDevice(b->device));
-    // every event a graph will wait for has been recorded at least once (the first replay waits for "the previous
-    // replay's" stage events: a wait node must find a completed record, not an event that was never recorded)
-    for (auto &S : b->set) {
-        for (int k = 0; k < sdr::K_COUNT; k++)
-            HIP_TRY(hipEventRecord(S.done[k], b->stream[kDefaultPlan[k]]));
-        if (S.res_listen) {
-            HIP_TRY(hipEventRecord(S.res_listen, b->stream[S_LISTEN]));
-            HIP_TRY(hipEventRecord(S.res_peaks, b->stream[S_PEAKS]));
+    // the replays' buffer sets and events, once
+    const size_t want = (size_t)RING + (size_t)GRAPH_PHASES * RING;
+    if (b->set.size() < want) {
+        const size_t have = b->set.size();
+        b->set.resize(want);
+        for (size_t i = have; i < want; i++) {
+            const hipError_t se = alloc_set(b, b->set[i]);
+            if (se != hipSuccess) {
+                for (size_t j = have; j < want; j++)
+                    b->set[j].release();
+                b->set.resize(have);
+                return fail(SDR_ERR_HIP, std::string("graph mode needs ") + std::to_string(GRAPH_PHASES * RING) +
+                                             " more batch buffer sets: " + hipGetErrorString(se));
+            }
         }
     }
-    for (int st = 0; st < N_STAGES; st++)
-        HIP_TRY(hipStreamSynchronize(b->stream[st]));
-    GDBG("events recorded");
+    for (auto &ph : b->phase_done)
+        for (auto &ev : ph)
+            if (!ev)
+                HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     const bool was_profiling = b->profiling;
     b->profiling = false;
-    // one stream records at a time (the legacy default stream cannot be captured: the bank must have been given a
-    // stream, sdr_set_stream); what crosses streams are external event nodes, so the four captures share nothing.
-    // (Four captures open at once corrupted the runtime's memory - bad_alloc / segfault inside the second stream's
-    // first wait, ROCm 7.2 - although two did not: tools/experiments/probe_graph_ext.hip.)
+    // One stream records at a time (the legacy default stream cannot be captured: the bank must have been given a
+    // stream, sdr_set_stream); the captures hold kernels only and share nothing.
     int max_slots = 0;
     for (int i = 0; i < b->cfg.n_bands; i++)
         max_slots = std::max(max_slots, b->n_slots[i]);
-    hipGraph_t g[N_STAGES] = {};
     hipError_t e = hipSuccess;
     rc = SDR_OK;
-    for (int st = 0; st < N_STAGES && rc == SDR_OK; st++) {
-        e = hipStreamBeginCapture(b->stream[st], hipStreamCaptureModeRelaxed);
-        if (e != hipSuccess) {
-            rc = fail(SDR_ERR_HIP, std::string("hipStreamBeginCapture (the bank's stream must not be the null stream): ") + hipGetErrorString(e));
-            break;
+    for (int ph = 0; ph < GRAPH_PHASES && rc == SDR_OK; ph++)
+        for (int st = 0; st < N_STAGES && rc == SDR_OK; st++) {
+            e = hipStreamBeginCapture(b->stream[st], hipStreamCaptureModeRelaxed);
+            if (e != hipSuccess) {
+                rc = fail(SDR_ERR_HIP, std::string("hipStreamBeginCapture (the bank's stream must not be the null stream): ") + hipGetErrorString(e));
+                break;
+            }
+            for (int k = 0; k < RING && rc == SDR_OK; k++)
+                rc = process_device_body(b, nullptr, n_frames, n_frames, ph * RING + k, st);
+            e = hipStreamEndCapture(b->stream[st], &b->graph[ph][st]);
+            if ((e != hipSuccess || !b->graph[ph][st]) && rc == SDR_OK)
+                rc = fail(SDR_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
         }
-        for (int k = 0; k < RING && rc == SDR_OK; k++)
-            rc = process_device_body(b, nullptr, n_frames, n_frames, k, st);
-        e = hipStreamEndCapture(b->stream[st], &g[st]);
-        if ((e != hipSuccess || !g[st]) && rc == SDR_OK)
-            rc = fail(SDR_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-    }
-    GDBG("captures ended");
     b->profiling = was_profiling;
-    auto drop = [&] {
-        for (auto &gg : g)
-            if (gg)
-                (void)hipGraphDestroy(gg);
-    };
     if (rc != SDR_OK) {
-        drop();
+        drop_graphs(b);
         return rc;
     }
-    // the cursor nodes: the kernel nodes of the FFT stream's graph that run k_set_cursor, told apart by their target
-    {
+    // the cursor nodes: the kernel nodes of an FFT graph that run k_set_cursor, told apart by their target
+    for (int ph = 0; ph < GRAPH_PHASES; ph++) {
         size_t n_nodes = 0;
-        HIP_TRY(hipGraphGetNodes(g[S_FFT], nullptr, &n_nodes));
+        hipGraph_t g = b->graph[ph][S_FFT];
+        e = hipGraphGetNodes(g, nullptr, &n_nodes);
         std::vector<hipGraphNode_t> nodes(n_nodes);
-        HIP_TRY(hipGraphGetNodes(g[S_FFT], nodes.data(), &n_nodes));
+        if (e == hipSuccess)
+            e = hipGraphGetNodes(g, nodes.data(), &n_nodes);
         int found = 0;
         for (hipGraphNode_t nd : nodes) {
             hipGraphNodeType t;
@@ -1687,36 +1731,28 @@ int sdr_graph_capture(sdr_bank *b, int n_frames)
             if (hipGraphKernelNodeGetParams(nd, &kp) != hipSuccess || kp.func != reinterpret_cast<void *>(&k_set_cursor) || !kp.kernelParams)
                 continue;
             const sdr::BatchCursor *dst = *static_cast<sdr::BatchCursor *const *>(kp.kernelParams[0]);
-            const ptrdiff_t k = dst - b->cursors.p;
-            if (k >= 0 && k < RING && !b->graph_cursor_node[k]) {
-                b->graph_cursor_node[k] = nd;
+            const ptrdiff_t k = dst - (b->cursors.p + ph * RING);
+            if (k >= 0 && k < RING && !b->graph_cursor_node[ph][k]) {
+                b->graph_cursor_node[ph][k] = nd;
                 found++;
             }
         }
-        if (found != RING) {
-            drop();
-            for (auto &n : b->graph_cursor_node)
-                n = nullptr;
+        if (e != hipSuccess || found != RING) {
+            drop_graphs(b);
             return fail(SDR_ERR_HIP, "captured graph does not hold one cursor node per batch");
         }
     }
-    GDBG("cursor nodes found");
-    for (int st = 0; st < N_STAGES; st++) {
-        if (dbg) { size_t nn = 0; (void)hipGraphGetNodes(g[st], nullptr, &nn); fprintf(stderr, "[graph] stream %d: %zu nodes\n", st, nn); fflush(stderr); }
-        e = hipGraphInstantiate(&b->graph_exec[st], g[st], nullptr, nullptr, 0);
-        if (e != hipSuccess) {
-            for (int j = 0; j < st; j++) {
-                (void)hipGraphExecDestroy(b->graph_exec[j]);
-                b->graph_exec[j] = nullptr;
+    for (int ph = 0; ph < GRAPH_PHASES; ph++)
+        for (int st = 0; st < N_STAGES; st++) {
+            e = hipGraphInstantiate(&b->graph_exec[ph][st], b->graph[ph][st], nullptr, nullptr, 0);
+            if (e != hipSuccess) {
+                drop_graphs(b);
+                return fail(SDR_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
             }
-            drop();
-            return fail(SDR_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
         }
-    }
-    GDBG("instantiated");
-    for (int st = 0; st < N_STAGES; st++)
-        b->graph[st] = g[st];
     b->graph_ready = true;
+    b->graph_base = b->batch_index;
+    b->graph_replays = 0;
     b->graph_frames = n_frames;
     b->graph_slots = max_slots;
     b->graph_attach_gen = b->attach_gen;
@@ -1737,7 +1773,17 @@ int sdr_graph_launch(sdr_bank *b, const float *const *iq_dev)
     if (max_slots != b->graph_slots || b->attach_gen != b->graph_attach_gen)
         return fail(SDR_ERR_STATE, "listeners were attached or detached since the capture: capture again");
     HIP_TRY(hipSetDevice(b->device));
+    static const bool dbg = getenv("SDR_GRAPH_DEBUG") != nullptr;
+    double tdbg[8] = {};
+    int ndbg = 0;
+    auto stamp = [&] {
+        if (dbg && ndbg < 8)
+            tdbg[ndbg++] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    };
+    stamp();
     const int n_frames = b->graph_frames;
+    const int ph = (int)(b->graph_replays % GRAPH_PHASES);
+    const int set0 = RING + ph * RING;
     sdr::BatchCursor cursor[RING];
     int count = b->cum_count, carry = b->carry_cur;
     int64_t total = b->total_frames;
@@ -1760,14 +1806,16 @@ int sdr_graph_launch(sdr_bank *b, const float *const *iq_dev)
         count = new_count;
         total += n_frames;
     }
+    // results of the replay that used these sets GRAPH_PHASES replays ago and were never polled: to the host-side queue
     if (b->results_on)
         for (int k = 0; k < RING; k++) {
-            const int prc = park_results(b, b->set[k]);
+            const int prc = park_results(b, b->set[set0 + k]);
             if (prc)
                 return prc;
         }
+    stamp();
     for (int k = 0; k < RING; k++) {
-        sdr::BatchCursor *dst = b->cursors.p + k;
+        sdr::BatchCursor *dst = b->cursors.p + ph * RING + k;
         void *args[2] = {&dst, &cursor[k]};
         hipKernelNodeParams kp{};
         kp.func = reinterpret_cast<void *>(&k_set_cursor);
@@ -1776,40 +1824,61 @@ int sdr_graph_launch(sdr_bank *b, const float *const *iq_dev)
         kp.sharedMemBytes = 0;
         kp.kernelParams = args;
         kp.extra = nullptr;
-        const hipError_t e = hipGraphExecKernelNodeSetParams(b->graph_exec[S_FFT], b->graph_cursor_node[k], &kp);
+        const hipError_t e = hipGraphExecKernelNodeSetParams(b->graph_exec[ph][S_FFT], b->graph_cursor_node[ph][k], &kp);
         if (e != hipSuccess)
             return fail(SDR_ERR_HIP, std::string("hipGraphExecKernelNodeSetParams: ") + hipGetErrorString(e));
     }
-    // the host's view first (sdr_poll on another thread must find the sets' metadata in place when the events fire)
-    {
-        std::lock_guard<std::mutex> guard(b->res_mu);
-        for (int k = 0; k < RING; k++) {
-            BatchSet &S = b->set[k];
-            if (b->results_on) {
-                S.res_batch = b->batch_index + k;
-                S.res_first_frame = meta[k].first_frame;
-                S.res_frames = n_frames;
-                S.res_chunks = meta[k].chunks;
-                S.res_count0 = meta[k].count0;
-                S.res_slots = max_slots;
-                S.res_center = b->center_frequency;
-            }
-        }
+    // FFT graph: once every reader of this phase's sets (the replay GRAPH_PHASES back) is done; then
+    // noise behind FFT, peaks and listen behind noise (which ends with the thresholds).  From the first failure on the
+    // replay is half enqueued and the bank refuses further work.
+    hipError_t e = hipSuccess;
+    auto step = [&](hipError_t r) {
+        if (e == hipSuccess)
+            e = r;
+    };
+    stamp();
+    hipEvent_t *done = b->phase_done[ph];
+    if (b->graph_replays >= GRAPH_PHASES)
+        for (int st : {S_NOISE, S_PEAKS, S_LISTEN})
+            step(hipStreamWaitEvent(b->stream[S_FFT], done[st], 0));
+    step(hipGraphLaunch(b->graph_exec[ph][S_FFT], b->stream[S_FFT]));
+    step(hipEventRecord(done[S_FFT], b->stream[S_FFT]));
+    stamp();
+    step(hipStreamWaitEvent(b->stream[S_NOISE], done[S_FFT], 0));
+    step(hipGraphLaunch(b->graph_exec[ph][S_NOISE], b->stream[S_NOISE]));
+    step(hipEventRecord(done[S_NOISE], b->stream[S_NOISE]));
+    stamp();
+    for (int st : {S_PEAKS, S_LISTEN}) {
+        step(hipStreamWaitEvent(b->stream[st], done[S_NOISE], 0));
+        step(hipGraphLaunch(b->graph_exec[ph][st], b->stream[st]));
+        step(hipEventRecord(done[st], b->stream[st]));
+        if (b->results_on)
+            for (int k = 0; k < RING; k++)
+                step(hipEventRecord(st == S_PEAKS ? b->set[set0 + k].res_peaks : b->set[set0 + k].res_listen, b->stream[st]));
     }
-    // every graph on the stream it was recorded on; a stream's event records are enqueued before the waits of the
-    // streams that depend on it: FFT, noise, peaks (thresholds), listen
-    static const int order[N_STAGES] = {S_FFT, S_NOISE, S_PEAKS, S_LISTEN};
-    for (int st : order) {
-        const hipError_t e = hipGraphLaunch(b->graph_exec[st], b->stream[st]);
-        if (e != hipSuccess) {
-            b->failed = true;
-            return fail(SDR_ERR_HIP, std::string("hipGraphLaunch: ") + hipGetErrorString(e));
-        }
+    stamp();
+    if (dbg)
+        fprintf(stderr, "[graph launch %lld] park %.0f us, cursors %.0f us, fft %.0f us, noise %.0f us, peaks+listen %.0f us\n", (long long)b->graph_replays,
+                tdbg[1] - tdbg[0], tdbg[2] - tdbg[1], tdbg[3] - tdbg[2], tdbg[4] - tdbg[3], tdbg[5] - tdbg[4]);
+    if (e != hipSuccess) {
+        b->failed = true;
+        return fail(SDR_ERR_HIP, std::string("enqueueing a replay: ") + hipGetErrorString(e));
     }
-    // the host's view of the carried state, batch by batch, as the eager path commits it
+    // the host's view of the carried state, batch by batch, as the eager path commits it (sdr_poll on another thread
+    // finds a batch only now: its events are recorded)
     std::lock_guard<std::mutex> guard(b->res_mu);
     for (int k = 0; k < RING; k++) {
-        b->last_set = k;
+        BatchSet &S = b->set[set0 + k];
+        if (b->results_on) {
+            S.res_batch = b->batch_index;
+            S.res_first_frame = meta[k].first_frame;
+            S.res_frames = n_frames;
+            S.res_chunks = meta[k].chunks;
+            S.res_count0 = meta[k].count0;
+            S.res_slots = max_slots;
+            S.res_center = b->center_frequency;
+        }
+        b->last_set = set0 + k;
         b->last_frames = n_frames;
         b->last_chunks = meta[k].chunks;
         b->last_count0 = meta[k].count0;
@@ -1819,6 +1888,7 @@ int sdr_graph_launch(sdr_bank *b, const float *const *iq_dev)
     b->cum_count = count;
     b->carry_cur = carry;
     b->total_frames = total;
+    b->graph_replays++;
     return SDR_OK;
 }
 
@@ -1953,7 +2023,7 @@ static int sdr_poll_parked(sdr_bank *b, sdr_results *r)
         return fail(SDR_ERR_STATE, "results of the next batch are not where they should be");
     const sdr_bank::Parked &p = b->parked.front();
     const BatchMeta m{p.batch, p.first_frame, p.frames, p.chunks, p.count0, p.slots, &p.center};
-    const int rc = deliver_block(b, p.block.data(), m, r);
+    const int rc = deliver_block(b, p.block.get(), m, r);
     if (rc == SDR_OK) {
         b->parked.pop_front();
         b->deliver_next++;
@@ -2065,12 +2135,24 @@ int sdr_poll(sdr_bank *b, sdr_results *r, int wait)
     if (!b->results_on)
         return fail(SDR_ERR_STATE, "bulk delivery is off (sdr_enable_results)");
     std::unique_lock<std::mutex> guard(b->res_mu);
+    // (a producer that needs a set back gives a polling consumer the chance to take its batch: park_results)
+    struct Polling {
+        sdr_bank *b;
+        bool waiting;
+        Polling(sdr_bank *b_, bool w) : b(b_), waiting(w) { b->pollers_waiting += waiting ? 1 : 0; }
+        ~Polling()  // (the mutex is held again whenever sdr_poll returns)
+        {
+            b->pollers_waiting -= waiting ? 1 : 0;
+            b->last_poll = std::chrono::steady_clock::now();
+            b->res_cv.notify_all();
+        }
+    } polling(b, wait != 0);
     if (b->deliver_next >= b->batches_enqueued)
         return fail(SDR_ERR_WOULD_BLOCK, "no batch waiting");
     // oldest first: parked batches are older than anything still in the ring
     if (!b->parked.empty() && b->parked.front().batch == b->deliver_next)
         return sdr_poll_parked(b, r);
-    BatchSet &S = b->set[b->deliver_next % RING];
+    BatchSet &S = b->set[set_index(b, b->deliver_next)];
     if (S.res_batch != b->deliver_next)
         return fail(SDR_ERR_STATE, "results of the next batch are not where they should be");
     HIP_TRY(hipSetDevice(b->device));
