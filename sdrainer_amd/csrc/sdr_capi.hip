@@ -94,6 +94,9 @@ int ilog2(int n)
 const char *kKernelNames[sdr::K_COUNT] = {"k_fft_psd",       "k_window_means", "k_noise_stats", "k_thresholds",
                                           "k_listen_gather", "k_cumulate",     "k_find_peaks",  "k_listen_decode"};
 
+// graph mode records the four streams' kernels plus, as a graph of its own in front of the peaks stream's, the thresholds
+// (the listen graph starts behind them, not behind the cumulations)
+constexpr int G_THRESHOLDS = 4, N_GRAPHS = 5;
 constexpr int GRAPH_PHASES = 4;  // graph mode: replays in flight, each with RING buffer sets of its own (sdr_graph_capture)
 constexpr int RING = 6;  // per-batch buffer sets in flight (a batch lives about four FFT launches from its FFT to its last result)
 enum Stage { S_FFT = 0, S_NOISE, S_LISTEN, S_PEAKS, N_STAGES };  // the bank's streams: four = the hardware queues HIP gives a process; with six streams created (two unused!) the step was 0.49 ms instead of 0.25, with GPU_MAX_HW_QUEUES=8 and five or six in use 0.29-0.60
@@ -194,10 +197,10 @@ struct sdr_bank {
     // graph mode (sdr_graph_*): RING consecutive batches as one linear, kernel-only hipGraph PER STREAM; GRAPH_PHASES
     // such groups of four graphs, each over buffer sets of its own, so that consecutive replays overlap stage by stage
     DevBuf<sdr::BatchCursor> cursors;  // [GRAPH_PHASES][RING]
-    hipGraph_t graph[GRAPH_PHASES][N_STAGES] = {};
-    hipGraphExec_t graph_exec[GRAPH_PHASES][N_STAGES] = {};
-    hipGraphNode_t graph_cursor_node[GRAPH_PHASES][RING] = {};  // the FFT graph's node that writes batch k's cursor
-    hipEvent_t phase_done[GRAPH_PHASES][N_STAGES] = {};         // recorded behind each graph of a replay
+    hipGraph_t graph[GRAPH_PHASES][N_GRAPHS] = {};
+    hipGraphExec_t graph_exec[GRAPH_PHASES][N_GRAPHS] = {};
+    hipGraphNode_t graph_cursor_node[GRAPH_PHASES] = {};  // the FFT graph's first node: writes the replay's cursors
+    hipEvent_t phase_done[GRAPH_PHASES][N_GRAPHS] = {};  // recorded behind each graph of a replay
     int64_t graph_base = 0;     // batch_index at the capture
     int64_t graph_replays = 0;  // launches since the capture
     bool graph_ready = false;
@@ -344,11 +347,15 @@ size_t utf8_encode(uint32_t r, char *out)
 }
 
 // graph mode: what differs between the batches of a replay lives in device-side cursors; batch k's is written by a node
-// of the FFT stream's graph right in front of that batch's FFT
-__global__ void k_set_cursor(sdr::BatchCursor *dst, sdr::BatchCursor v)
+// of the FFT graph - its first one, for all the replay's batches (no kernel of an earlier replay reads these cursors any
+// more: the FFT graph starts behind every reader of its phase)
+struct CursorPack {
+    sdr::BatchCursor c[RING];
+};
+__global__ void k_set_cursors(sdr::BatchCursor *dst, CursorPack v)
 {
-    if (threadIdx.x == 0)
-        *dst = v;
+    if (threadIdx.x < RING)
+        dst[threadIdx.x] = v.c[threadIdx.x];
 }
 
 int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_stride, int capture_k = -1, int capture_stage = -1);
@@ -505,10 +512,8 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     int plan[sdr::K_COUNT];
     for (int k = 0; k < sdr::K_COUNT; k++)
         plan[k] = kDefaultPlan[k];
-    if (cap)  // the noise graph ends with the thresholds: the peaks graph and the listen graph both start behind it
-        plan[sdr::K_THRESHOLDS] = S_NOISE;
-    // is kernel k's stream the one that is recording (always, outside a capture)?
-#define SDR_ON(k) (!cap || plan[k] == capture_stage)
+    // is kernel k part of the graph that is recording (always, outside a capture)?
+#define SDR_ON(k) (!cap || (capture_stage == G_THRESHOLDS ? (k) == sdr::K_THRESHOLDS : (plan[k] == capture_stage && (k) != sdr::K_THRESHOLDS)))
 #if defined(SDR_DIAG)
     // diagnostic builds only (tools/abl): SDR_DIAG_SKIP = bit mask of kernel ids not to launch, to see
     // which stage holds the pipelined step up (results are wrong by construction); SDR_DIAG_PLAN = stream plan.
@@ -588,8 +593,8 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
                 HIP_TRY(hipStreamWaitEvent(stream_of(sdr::K_FFT), S.done[k], 0));
         }
     }
-    if (cap && SDR_ON(sdr::K_FFT))  // this batch's cursor, in front of its FFT
-        hipLaunchKernelGGL(k_set_cursor, dim3(1), dim3(64), 0, stream_of(sdr::K_FFT), b->cursors.p + capture_k, sdr::BatchCursor{});
+    if (cap && SDR_ON(sdr::K_FFT) && capture_k % RING == 0)  // the replay's cursors, in front of its first FFT
+        hipLaunchKernelGGL(k_set_cursors, dim3(1), dim3(64), 0, stream_of(sdr::K_FFT), b->cursors.p + capture_k, CursorPack{});
     int max_slots = 0, slots_in_use = 0;
     for (int i = 0; i < B; i++) {
         max_slots = std::max(max_slots, b->n_slots[i]);
@@ -762,7 +767,7 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
 void drop_graphs(sdr_bank *b)
 {
     for (int ph = 0; ph < GRAPH_PHASES; ph++) {
-        for (int st = 0; st < N_STAGES; st++) {
+        for (int st = 0; st < N_GRAPHS; st++) {
             if (b->graph_exec[ph][st])
                 (void)hipGraphExecDestroy(b->graph_exec[ph][st]);
             if (b->graph[ph][st])
@@ -770,8 +775,7 @@ void drop_graphs(sdr_bank *b)
             b->graph_exec[ph][st] = nullptr;
             b->graph[ph][st] = nullptr;
         }
-        for (auto &n : b->graph_cursor_node[ph])
-            n = nullptr;
+        b->graph_cursor_node[ph] = nullptr;
     }
 }
 
@@ -1608,14 +1612,15 @@ int sdr_read_decoder_state(sdr_bank *b, int band, int lid, double *out12)
 }
 
 // ---- graph mode ------------------------------------------------------------------------------------------------
-// RING consecutive batches recorded once and replayed as FOUR LINEAR, KERNEL-ONLY GRAPHS, one per stream of the bank:
-// the FFT graph (cursor + FFT of the six batches), the noise graph (window means, statistics, thresholds), the peaks
-// graph (cumulate, find peaks, pack) and the listen graph (gather, decode, pack).  Inside a replay the streams are
-// ordered by ordinary events around whole graphs (FFT -> noise -> {peaks, listen}); replay r+1's FFT graph runs while
-// replay r's noise graph and replay r-1's peaks / listen graphs do - the same kernels side by side as in the eager
-// pipeline, only taken from different replays.  That needs buffer sets per replay in flight: GRAPH_PHASES groups of RING
-// sets, each group with graphs of its own (the buffers are baked into the kernel nodes), used round robin.
-// The host enqueues per six batches: 4 graph launches, 5 event waits, 4 + 12 event records (sixty-odd commands eager).
+// RING consecutive batches recorded once and replayed as LINEAR, KERNEL-ONLY GRAPHS, one per stream of the bank: the FFT
+// graph (cursors + FFT of the six batches), the noise graph (window means, statistics), the peaks stream's two graphs
+// (thresholds; then cumulate, find peaks, pack) and the listen graph (gather, decode, pack).  Inside a replay the streams
+// are ordered by ordinary events around whole graphs (FFT -> noise -> thresholds -> {peaks, listen}); replay r+1's FFT
+// graph runs while replay r's noise graph and replay r-1's peaks / listen graphs do - the same kernels side by side as
+// in the eager pipeline, only taken from different replays.  That needs buffer sets per replay in flight: GRAPH_PHASES
+// groups of RING sets, each group with graphs of its own (the buffers are baked into the kernel nodes), used round robin.
+// The host enqueues per six batches: 5 graph launches, 3-6 event waits, 5 + 12 event records (sixty-odd commands eager).
+// (Thresholds in the noise graph instead - one graph fewer - made the noise stream the longest: c3 143 GS/s against 152.)
 // Why not one graph per replay, or events inside the graphs (both were built and measured, rounds 2 and 3):
 //  - one graph with fork / join over four streams: the runtime maps its branches to queues of its own choosing (7-10 %
 //    slower than eager; one process in three, three times slower) and a replay, being one stream operation, cannot
@@ -1625,8 +1630,8 @@ int sdr_read_decoder_state(sdr_bank *b, int band, int lid, double *out12)
 //    capture API for them is broken in this runtime (hipStreamWaitEvent(External) behind a kernel node throws
 //    std::bad_alloc, several captures open at once corrupt memory: tools/experiments/probe_graph_ext.hip).
 // What differs between batches (input pointer, frame numbering, cumulation phase, carry buffer) is read by the kernels
-// from device-side cursors; batch k's cursor is written by a node of the FFT graph right in front of that batch's FFT;
-// its kernel argument is the only thing a replay updates (hipGraphExecKernelNodeSetParams), so no host memory is read
+// from device-side cursors, written by the first node of the FFT graph; its kernel argument is the only thing a replay
+// updates (hipGraphExecKernelNodeSetParams), so no host memory is read
 // while a replay runs.
 int sdr_graph_batches(sdr_bank *b) { return b ? RING : 0; }
 
@@ -1697,15 +1702,16 @@ int sdr_graph_capture(sdr_bank *b, int n_frames)
     hipError_t e = hipSuccess;
     rc = SDR_OK;
     for (int ph = 0; ph < GRAPH_PHASES && rc == SDR_OK; ph++)
-        for (int st = 0; st < N_STAGES && rc == SDR_OK; st++) {
-            e = hipStreamBeginCapture(b->stream[st], hipStreamCaptureModeRelaxed);
+        for (int st = 0; st < N_GRAPHS && rc == SDR_OK; st++) {
+            hipStream_t cs = b->stream[st == G_THRESHOLDS ? S_PEAKS : st];
+            e = hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed);
             if (e != hipSuccess) {
                 rc = fail(SDR_ERR_HIP, std::string("hipStreamBeginCapture (the bank's stream must not be the null stream): ") + hipGetErrorString(e));
                 break;
             }
             for (int k = 0; k < RING && rc == SDR_OK; k++)
                 rc = process_device_body(b, nullptr, n_frames, n_frames, ph * RING + k, st);
-            e = hipStreamEndCapture(b->stream[st], &b->graph[ph][st]);
+            e = hipStreamEndCapture(cs, &b->graph[ph][st]);
             if ((e != hipSuccess || !b->graph[ph][st]) && rc == SDR_OK)
                 rc = fail(SDR_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
         }
@@ -1714,7 +1720,7 @@ int sdr_graph_capture(sdr_bank *b, int n_frames)
         drop_graphs(b);
         return rc;
     }
-    // the cursor nodes: the kernel nodes of an FFT graph that run k_set_cursor, told apart by their target
+    // the cursor node: the kernel node of an FFT graph that runs k_set_cursors
     for (int ph = 0; ph < GRAPH_PHASES; ph++) {
         size_t n_nodes = 0;
         hipGraph_t g = b->graph[ph][S_FFT];
@@ -1728,22 +1734,18 @@ int sdr_graph_capture(sdr_bank *b, int n_frames)
             if (hipGraphNodeGetType(nd, &t) != hipSuccess || t != hipGraphNodeTypeKernel)
                 continue;
             hipKernelNodeParams kp{};
-            if (hipGraphKernelNodeGetParams(nd, &kp) != hipSuccess || kp.func != reinterpret_cast<void *>(&k_set_cursor) || !kp.kernelParams)
+            if (hipGraphKernelNodeGetParams(nd, &kp) != hipSuccess || kp.func != reinterpret_cast<void *>(&k_set_cursors))
                 continue;
-            const sdr::BatchCursor *dst = *static_cast<sdr::BatchCursor *const *>(kp.kernelParams[0]);
-            const ptrdiff_t k = dst - (b->cursors.p + ph * RING);
-            if (k >= 0 && k < RING && !b->graph_cursor_node[ph][k]) {
-                b->graph_cursor_node[ph][k] = nd;
-                found++;
-            }
+            b->graph_cursor_node[ph] = nd;
+            found++;
         }
-        if (e != hipSuccess || found != RING) {
+        if (e != hipSuccess || found != 1) {
             drop_graphs(b);
-            return fail(SDR_ERR_HIP, "captured graph does not hold one cursor node per batch");
+            return fail(SDR_ERR_HIP, "captured FFT graph does not hold exactly one cursor node");
         }
     }
     for (int ph = 0; ph < GRAPH_PHASES; ph++)
-        for (int st = 0; st < N_STAGES; st++) {
+        for (int st = 0; st < N_GRAPHS; st++) {
             e = hipGraphInstantiate(&b->graph_exec[ph][st], b->graph[ph][st], nullptr, nullptr, 0);
             if (e != hipSuccess) {
                 drop_graphs(b);
@@ -1784,7 +1786,8 @@ int sdr_graph_launch(sdr_bank *b, const float *const *iq_dev)
     const int n_frames = b->graph_frames;
     const int ph = (int)(b->graph_replays % GRAPH_PHASES);
     const int set0 = RING + ph * RING;
-    sdr::BatchCursor cursor[RING];
+    CursorPack pack{};
+    sdr::BatchCursor *cursor = pack.c;
     int count = b->cum_count, carry = b->carry_cur;
     int64_t total = b->total_frames;
     struct Meta {
@@ -1814,17 +1817,17 @@ int sdr_graph_launch(sdr_bank *b, const float *const *iq_dev)
                 return prc;
         }
     stamp();
-    for (int k = 0; k < RING; k++) {
-        sdr::BatchCursor *dst = b->cursors.p + ph * RING + k;
-        void *args[2] = {&dst, &cursor[k]};
+    {
+        sdr::BatchCursor *dst = b->cursors.p + ph * RING;
+        void *args[2] = {&dst, &pack};
         hipKernelNodeParams kp{};
-        kp.func = reinterpret_cast<void *>(&k_set_cursor);
+        kp.func = reinterpret_cast<void *>(&k_set_cursors);
         kp.gridDim = dim3(1);
         kp.blockDim = dim3(64);
         kp.sharedMemBytes = 0;
         kp.kernelParams = args;
         kp.extra = nullptr;
-        const hipError_t e = hipGraphExecKernelNodeSetParams(b->graph_exec[ph][S_FFT], b->graph_cursor_node[ph][k], &kp);
+        const hipError_t e = hipGraphExecKernelNodeSetParams(b->graph_exec[ph][S_FFT], b->graph_cursor_node[ph], &kp);
         if (e != hipSuccess)
             return fail(SDR_ERR_HIP, std::string("hipGraphExecKernelNodeSetParams: ") + hipGetErrorString(e));
     }
@@ -1840,7 +1843,8 @@ int sdr_graph_launch(sdr_bank *b, const float *const *iq_dev)
     hipEvent_t *done = b->phase_done[ph];
     if (b->graph_replays >= GRAPH_PHASES)
         for (int st : {S_NOISE, S_PEAKS, S_LISTEN})
-            step(hipStreamWaitEvent(b->stream[S_FFT], done[st], 0));
+            if (hipEventQuery(done[st]) != hipSuccess)  // (ask the host first, as the eager path does: a wait is a barrier packet in the FFT queue)
+                step(hipStreamWaitEvent(b->stream[S_FFT], done[st], 0));
     step(hipGraphLaunch(b->graph_exec[ph][S_FFT], b->stream[S_FFT]));
     step(hipEventRecord(done[S_FFT], b->stream[S_FFT]));
     stamp();
@@ -1848,14 +1852,21 @@ int sdr_graph_launch(sdr_bank *b, const float *const *iq_dev)
     step(hipGraphLaunch(b->graph_exec[ph][S_NOISE], b->stream[S_NOISE]));
     step(hipEventRecord(done[S_NOISE], b->stream[S_NOISE]));
     stamp();
-    for (int st : {S_PEAKS, S_LISTEN}) {
-        step(hipStreamWaitEvent(b->stream[st], done[S_NOISE], 0));
-        step(hipGraphLaunch(b->graph_exec[ph][st], b->stream[st]));
-        step(hipEventRecord(done[st], b->stream[st]));
-        if (b->results_on)
-            for (int k = 0; k < RING; k++)
-                step(hipEventRecord(st == S_PEAKS ? b->set[set0 + k].res_peaks : b->set[set0 + k].res_listen, b->stream[st]));
-    }
+    // the peaks stream: thresholds (batch order, behind the noise statistics), then cumulate / find peaks / pack, which
+    // need this replay's spectra (implied by the noise graph) and thresholds (same stream)
+    step(hipStreamWaitEvent(b->stream[S_PEAKS], done[S_NOISE], 0));
+    step(hipGraphLaunch(b->graph_exec[ph][G_THRESHOLDS], b->stream[S_PEAKS]));
+    step(hipEventRecord(done[G_THRESHOLDS], b->stream[S_PEAKS]));
+    step(hipGraphLaunch(b->graph_exec[ph][S_PEAKS], b->stream[S_PEAKS]));
+    step(hipEventRecord(done[S_PEAKS], b->stream[S_PEAKS]));
+    step(hipStreamWaitEvent(b->stream[S_LISTEN], done[G_THRESHOLDS], 0));
+    step(hipGraphLaunch(b->graph_exec[ph][S_LISTEN], b->stream[S_LISTEN]));
+    step(hipEventRecord(done[S_LISTEN], b->stream[S_LISTEN]));
+    if (b->results_on)
+        for (int k = 0; k < RING; k++) {
+            step(hipEventRecord(b->set[set0 + k].res_peaks, b->stream[S_PEAKS]));
+            step(hipEventRecord(b->set[set0 + k].res_listen, b->stream[S_LISTEN]));
+        }
     stamp();
     if (dbg)
         fprintf(stderr, "[graph launch %lld] park %.0f us, cursors %.0f us, fft %.0f us, noise %.0f us, peaks+listen %.0f us\n", (long long)b->graph_replays,
