@@ -30,6 +30,11 @@
  *   sdr_enable_results / sdr_poll   the consumer side in bulk: what Receiver.run hands to its listeners'
  *                                   io.Writer (rx/receiver.go:123, ChannelWriter :508-539) and to the
  *                                   Reporter (rx/rx.go:11-17), one call per processed batch
+ *   sdr_defer_listen / sdr_poll_peaks / sdr_attach_at / sdr_process_listen
+ *                                   the discovery branch of Receiver.run - FindPeaks at a cumulation boundary,
+ *                                   PeaksTable.FindNext, ListenerPool.BindNext, Listener.Attach, the listener
+ *                                   hearing the next frame - without one host round trip per cumulation
+ *                                                                               rx/receiver.go:404-426
  *   sdr_scope_*                     scope.Scope.ShowSpectralFrame / ShowTimeFrame  scope/scope.go:14-37,
  *                                   call sites rx/receiver.go:428-457, cw/spectral.go:56-81
  *
@@ -243,6 +248,22 @@ int sdr_enable_results(sdr_bank *bank, int on);
 /* Oldest finished, undelivered batch -> *r.  SDR_ERR_WOULD_BLOCK if there is none (yet); with wait != 0 the
  * call blocks until the oldest undelivered batch has finished (WOULD_BLOCK only if nothing was processed). */
 int sdr_poll(sdr_bank *bank, sdr_results *r, int wait);
+
+/* Strain-mode discovery over a long batch (rx/receiver.go:404-426: one listener bound per completed cumulation, to a
+ * peak of that cumulation, listening from the very next frame).  With deferral on (needs sdr_enable_results), a
+ * sdr_process_* call runs the spectral half of the batch only - FFT, noise floor, thresholds, cumulations and FindPeaks
+ * of EVERY cumulation the batch completes - and the bank refuses further batches until sdr_process_listen has run the
+ * listeners over the retained spectra.  In between the host reads the peaks (sdr_poll_peaks: the chunks / peaks part of
+ * sdr_results, the batch stays undelivered; sdr_poll delivers it whole once the listen half has run) and binds listeners
+ * with sdr_attach_at: like sdr_attach, but the listener listens from bank frame `start_frame` on (counted from the
+ * bank's first frame; between the first frame of the waiting batch and the next frame to be processed).  Frames before
+ * start_frame never reach its debouncer or decoder, so it produces exactly what a listener attached there frame by frame
+ * would have.  Neither call waits for the device. */
+int sdr_defer_listen(sdr_bank *bank, int on);
+int sdr_listen_pending(sdr_bank *bank);
+int sdr_poll_peaks(sdr_bank *bank, sdr_results *results, int wait);
+int sdr_attach_at(sdr_bank *bank, int band, int bin, int64_t start_frame, int *listener_id);
+int sdr_process_listen(sdr_bank *bank);
 /* Batches processed but not yet delivered. */
 int sdr_results_pending(sdr_bank *bank);
 /* Overflow counters without bulk delivery (synchronises): runes the decoders could not store because a text

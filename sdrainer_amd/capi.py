@@ -88,7 +88,7 @@ SYMBOLS = (
     "sdr_set_peak_threshold sdr_set_edge_width sdr_set_signal_debounce sdr_set_center_frequency sdr_set_find_peaks "
     "sdr_last_batch_frames sdr_total_frames sdr_last_batch_chunks sdr_read_peaks sdr_read_cumulation sdr_read_text "
     "sdr_read_edges sdr_read_keying_bits sdr_read_frame_records sdr_read_trace sdr_read_spectrum "
-    "sdr_read_decoder_state sdr_graph_batches sdr_graph_capture sdr_graph_launch sdr_graph_release sdr_scope_active sdr_scope_read_spectral sdr_scope_read_demod sdr_enable_results sdr_poll sdr_results_pending sdr_read_drop_counters sdr_profile_enable sdr_profile_read sdr_profile_reset sdr_kernel_name sdr_audio_create "
+    "sdr_read_decoder_state sdr_graph_batches sdr_graph_capture sdr_graph_launch sdr_graph_release sdr_scope_active sdr_scope_read_spectral sdr_scope_read_demod sdr_enable_results sdr_poll sdr_defer_listen sdr_listen_pending sdr_poll_peaks sdr_attach_at sdr_process_listen sdr_results_pending sdr_read_drop_counters sdr_profile_enable sdr_profile_read sdr_profile_reset sdr_kernel_name sdr_audio_create "
     "sdr_audio_destroy sdr_audio_blocksize sdr_audio_set_scale sdr_audio_set_debounce "
     "sdr_audio_set_magnitude_threshold sdr_audio_write sdr_audio_close sdr_audio_read_text sdr_audio_read_trace"
 ).split()
@@ -162,6 +162,11 @@ def load():
     sig("sdr_scope_read_demod", C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, ip)
     sig("sdr_enable_results", C.c_int, vp, C.c_int)
     sig("sdr_poll", C.c_int, vp, C.POINTER(Results), C.c_int)
+    sig("sdr_defer_listen", C.c_int, vp, C.c_int)
+    sig("sdr_listen_pending", C.c_int, vp)
+    sig("sdr_poll_peaks", C.c_int, vp, C.POINTER(Results), C.c_int)
+    sig("sdr_attach_at", C.c_int, vp, C.c_int, C.c_int, C.c_int64, ip)
+    sig("sdr_process_listen", C.c_int, vp)
     sig("sdr_results_pending", C.c_int, vp)
     sig("sdr_read_drop_counters", C.c_int, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
     sig("sdr_profile_enable", C.c_int, vp, C.c_int)
@@ -274,6 +279,22 @@ class Bank:
         lid = C.c_int()
         _check(self._L.sdr_attach(self._h, band, int(bin_), C.byref(lid)))
         return lid.value
+
+    def attach_at(self, band: int, bin_: int, start_frame: int) -> int:
+        """sdr_attach_at: a listener that listens from bank frame `start_frame` of the batch waiting for its listen half."""
+        lid = C.c_int(-1)
+        _check(self._L.sdr_attach_at(self._h, band, int(bin_), int(start_frame), C.byref(lid)))
+        return lid.value
+
+    def defer_listen(self, on: bool = True) -> None:
+        _check(self._L.sdr_defer_listen(self._h, int(on)))
+
+    @property
+    def listen_pending(self) -> bool:
+        return bool(self._L.sdr_listen_pending(self._h))
+
+    def process_listen(self) -> None:
+        _check(self._L.sdr_process_listen(self._h))
 
     def detach(self, band: int, lid: int):
         _check(self._L.sdr_detach(self._h, band, lid))
@@ -431,10 +452,14 @@ class Bank:
             r.rune_frames = self._rune_frames.ctypes.data
             self._res = r
 
-    def poll(self, wait: bool = False, copy: bool = True):
+    def poll_peaks(self, wait: bool = True, copy: bool = True):
+        """sdr_poll_peaks: chunks and peaks of the batch that waits for its listen half (it stays undelivered)."""
+        return self.poll(wait, copy, _entry=self._L.sdr_poll_peaks)
+
+    def poll(self, wait: bool = False, copy: bool = True, _entry=None):
         """Oldest finished batch as a dict of record arrays (views into reused buffers unless `copy`), or None."""
         r = self._res
-        rc = self._L.sdr_poll(self._h, C.byref(r), int(wait))
+        rc = (_entry or self._L.sdr_poll)(self._h, C.byref(r), int(wait))
         if rc == ERR_WOULD_BLOCK:
             return None
         _check(rc)

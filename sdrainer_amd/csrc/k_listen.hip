@@ -43,12 +43,15 @@ constexpr int DECODE_WAVES = SDR_DECODE_WAVES;  // signal groups per workgroup, 
 // the literal Go algorithm, out of line: it is rare (about three values in 10^5 fail the shortcut's certificate)
 __device__ __attribute__((noinline)) float gather_db_slow(float psd, double inv_n2) { return gomath::psd_value_in_db(psd, inv_n2); }
 
-__global__ __launch_bounds__(64 * GATHER_WAVES) void k_listen_gather(const float *__restrict__ tap, const sdr_frame_rec *__restrict__ recs,
+__global__ __launch_bounds__(64 * GATHER_WAVES) void k_listen_gather(const float *__restrict__ tap, const float *__restrict__ psd,
+                                                      const sdr_frame_rec *__restrict__ recs,
                                                       const ListenerSlot *__restrict__ slots, const void *__restrict__ db_tab,
                                                       uint64_t *__restrict__ raw_bits, float *__restrict__ tr_values,
-                                                      uint8_t *__restrict__ tr_raw, ListenGeom g, int n_frames,
-                                                      int n_slots, double inv_n2)
+                                                      uint8_t *__restrict__ tr_raw, const BatchCursor *__restrict__ cur, ListenGeom g,
+                                                      int n_frames, int n_slots, double inv_n2)
 {
+    if (cur)
+        g.frame_base = cur->frame_base;
     // the tables of the certified dB shortcut (gomath.h; k_cumulate uses the same ones)
     __shared__ __attribute__((aligned(16))) unsigned char s_tab[gomath::kDbTabBytes];
     {
@@ -69,13 +72,18 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) void k_listen_gather(const float
     const int f0 = word * 64;
     const int cnt = min(64, n_frames - f0);
     const size_t frame0 = (size_t)band * g.stride + f0;
+    // a listener bound to this batch after its FFT ran (sdr_attach_at): frames of the batch before `skip` are not its
+    // own, frames before `untapped` have no tap entry - their value comes from the retained psd row
+    const int skip = (int)(slots[lidx].start_frame - g.frame_base), untapped = (int)(slots[lidx].tapped_from - g.frame_base);
+    const int bin = slots[lidx].bin;
     uint64_t mask = 0;
     for (int j0 = 0; j0 < cnt; j0 += 8) {
         float p[8], thr[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            p[k] = tap[(frame0 + min(j0 + k, cnt - 1)) * g.max_listeners + l];
-            thr[k] = recs[frame0 + min(j0 + k, cnt - 1)].listen_thr;
+            const int jj = min(j0 + k, cnt - 1);
+            p[k] = f0 + jj < untapped ? psd[(frame0 + jj) * (size_t)g.n + bin] : tap[(frame0 + jj) * g.max_listeners + l];
+            thr[k] = recs[frame0 + jj].listen_thr;
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -95,6 +103,8 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) void k_listen_gather(const float
             }
         }
     }
+    if (skip > f0)  // (the decoder starts at `skip` too; the word stays clean for readers of the raw states)
+        mask &= skip - f0 >= 64 ? 0ull : ~((1ull << (skip - f0)) - 1ull);
     raw_bits[lidx * g.bit_words + word] = mask;
 }
 
@@ -185,6 +195,8 @@ __global__ __launch_bounds__(64 * DECODE_WAVES) void k_listen_decode(ListenerSlo
     uint64_t *dw = deb_bits + (size_t)idx * g.bit_words;
     uint32_t n_edges = 0;
     const int band = idx / g.max_listeners, l = idx - band * g.max_listeners;
+    // frames of this batch before the listener's first one (sdr_attach_at; 0 or less for everybody else)
+    const int skip = (int)(slot->start_frame - g.frame_base);
 
     // The words of raw states are fetched four ahead: a load per word in the loop would put a trip to memory on the
     // serial path of every 64 frames (32 of them per 2048-frame batch).
@@ -200,11 +212,12 @@ __global__ __launch_bounds__(64 * DECODE_WAVES) void k_listen_decode(ListenerSlo
         ahead[1] = ahead[2];
         ahead[2] = ahead[3];
         ahead[3] = rw[min((f0 >> 6) + 4, n_words - 1)];
-        const uint64_t d = cw::debounce_word(deb, raw, cnt);  // dsp/dsp.go:164-182, a run of equal raw states at a time
+        int pos = skip > f0 ? min(skip - f0, cnt) : 0;  // ticks of this word that are not the listener's
+        // dsp/dsp.go:164-182, a run of equal raw states at a time
+        const uint64_t d = pos >= cnt ? 0ull : pos ? cw::debounce_word(deb, raw >> pos, cnt - pos) << pos : cw::debounce_word(deb, raw, cnt);
         if (writer)
             dw[f0 >> 6] = d;
         // walk the runs of equal debounced bits
-        int pos = 0;
         while (pos < cnt) {
             const bool cur = dec.lastState != 0;
             uint64_t diff = (cur ? ~d : d) >> pos;  // 1 where the bit differs from the decoder's state
@@ -282,14 +295,14 @@ __global__ void k_set_debounce(ListenerSlot *slots, int n, int threshold)
         slots[i].deb.threshold = threshold;
 }
 
-hipError_t launch_listen_gather(const float *tap, const sdr_frame_rec *recs, const ListenerSlot *slots, const void *db_tab,
-                                uint64_t *raw_bits, float *tr_values, uint8_t *tr_raw, ListenGeom g, int n_frames, int n_slots,
-                                int n_bands, hipStream_t stream)
+hipError_t launch_listen_gather(const float *tap, const float *psd, const sdr_frame_rec *recs, const ListenerSlot *slots, const void *db_tab,
+                                uint64_t *raw_bits, float *tr_values, uint8_t *tr_raw, const BatchCursor *cur, ListenGeom g, int n_frames,
+                                int n_slots, int n_bands, hipStream_t stream)
 {
     const double inv_n2 = 1.0 / ((double)g.n * (double)g.n);
     launch_kernel(k_listen_gather, dim3(((n_frames + 63) / 64 + GATHER_WAVES - 1) / GATHER_WAVES, (n_slots + 63) / 64, n_bands),
-                       dim3(64 * GATHER_WAVES), 0, stream, tap, recs,
-                       slots, db_tab, raw_bits, tr_values, tr_raw, g, n_frames, n_slots, inv_n2);
+                       dim3(64 * GATHER_WAVES), 0, stream, tap, psd, recs,
+                       slots, db_tab, raw_bits, tr_values, tr_raw, cur, g, n_frames, n_slots, inv_n2);
     return hipGetLastError();
 }
 

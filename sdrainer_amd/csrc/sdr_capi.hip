@@ -206,6 +206,12 @@ struct sdr_bank {
     bool graph_ready = false;
     int graph_frames = 0, graph_slots = 0;
     uint64_t attach_gen = 0, graph_attach_gen = 0;  // sdr_attach / sdr_detach calls so far; as of the capture
+    // deferred listen half (sdr_defer_listen): the batch whose spectra exist and whose listeners have not run yet
+    bool defer_listen = false, listen_pending = false;
+    struct PendingListen {
+        int set = 0, frames = 0;
+        int64_t first_frame = 0, batch = 0;
+    } pend;
     // bulk delivery
     bool results_on = false;
     sdr::ResultsLayout res_layout{};
@@ -358,7 +364,22 @@ __global__ void k_set_cursors(sdr::BatchCursor *dst, CursorPack v)
         dst[threadIdx.x] = v.c[threadIdx.x];
 }
 
-int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_stride, int capture_k = -1, int capture_stage = -1);
+// sdr_attach_at: the new listener's slot and tap bin reach the device as kernel arguments, in stream order, without a
+// synchronous copy (the pipeline keeps running while the host binds listeners)
+__global__ void k_put_slot(sdr::ListenerSlot *dst, sdr::ListenerSlot v)
+{
+    if (threadIdx.x == 0)
+        *dst = v;
+}
+__global__ void k_put_int(int32_t *dst, int32_t v)
+{
+    if (threadIdx.x == 0)
+        *dst = v;
+}
+
+enum Parts { PART_SPECTRA = 1, PART_LISTEN = 2, PART_ALL = 3 };
+int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_stride, int capture_k = -1, int capture_stage = -1,
+                        int parts = PART_ALL);
 
 // A failure after the first launch leaves the pipeline half enqueued (some stages of this batch ran, the
 // carried state of others did not advance): no later batch can be trusted, so the bank refuses further work.
@@ -368,7 +389,9 @@ int process_device_impl(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         return fail(SDR_ERR_STATE, "an earlier process call failed half way; destroy the bank");
     if (b->graph_ready)
         return fail(SDR_ERR_STATE, "a graph is captured: process through sdr_graph_launch, or sdr_graph_release first");
-    const int rc = process_device_body(b, iq_dev, n_frames, in_stride);
+    if (b->listen_pending)
+        return fail(SDR_ERR_STATE, "the previous batch still waits for its listen half (sdr_process_listen)");
+    const int rc = process_device_body(b, iq_dev, n_frames, in_stride, -1, -1, b->defer_listen ? PART_SPECTRA : PART_ALL);
     if (rc == SDR_ERR_HIP)
         b->failed = true;
     return rc;
@@ -490,9 +513,15 @@ constexpr int kDefaultPlan[sdr::K_COUNT] = {
 // the batch uses buffer set RING + capture_k, everything that differs from batch to batch comes from the device-side
 // cursor of that number instead of the launch parameters, grids cover the most chunks a batch of this length can
 // complete, nothing is asked of the host (no event queries, no profiling, no parking) and no host state changes.
-int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_stride, int capture_k, int capture_stage)
+// parts: PART_SPECTRA leaves the batch's listeners for a later PART_LISTEN call (sdr_defer_listen / sdr_process_listen:
+// the host binds listeners to peaks of this very batch in between, rx/receiver.go:409-426); the later call takes the
+// batch's set, length and first frame from b->pend.
+int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_stride, int capture_k, int capture_stage, int parts)
 {
     const bool cap = capture_k >= 0;
+    const bool do_spectra = (parts & PART_SPECTRA) != 0, do_listen = (parts & PART_LISTEN) != 0;
+    if (!do_spectra)
+        n_frames = b->pend.frames;
     const sdr::BatchCursor *cur = cap ? b->cursors.p + capture_k : nullptr;
     const sdr_config &c = b->cfg;
     if (n_frames <= 0)
@@ -507,7 +536,8 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     HIP_TRY(hipSetDevice(b->device));
     const int B = c.n_bands, N = c.block_size, stride = c.max_batch_frames;
     const sdr::NoiseGeom ng = b->noise_geom();
-    const int si = cap ? RING + capture_k : (int)(b->batch_index % RING);  // (capture: the sets sdr_graph_capture added)
+    const int si = cap ? RING + capture_k : do_spectra ? (int)(b->batch_index % RING) : b->pend.set;  // (capture: the sets sdr_graph_capture added)
+    const int64_t first_frame = do_spectra ? b->total_frames : b->pend.first_frame;
     BatchSet &S = b->set[si];
     int plan[sdr::K_COUNT];
     for (int k = 0; k < sdr::K_COUNT; k++)
@@ -570,6 +600,12 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     // set is free, the FFT queue holds kernels only): 0.161 ms with nothing else running, but 0.237 against 0.234
     // with the whole pipeline, where the FFT launches are spaced by the CUs the tail holds, not by their queue.
     static const bool host_waits = getenv("SDR_HOST_THROTTLE") && atoi(getenv("SDR_HOST_THROTTLE")) != 0;
+    int max_slots = 0, slots_in_use = 0;
+    for (int i = 0; i < B; i++) {
+        max_slots = std::max(max_slots, b->n_slots[i]);
+        slots_in_use += b->n_slots[i];
+    }
+    if (do_spectra) {
     {
         // the last stage launched on a stream stands for all of that stream's
         static const int launch_order[] = {sdr::K_WINDOW_MEANS, sdr::K_NOISE_STATS, sdr::K_THRESHOLDS, sdr::K_LISTEN_GATHER,
@@ -595,11 +631,6 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     }
     if (cap && SDR_ON(sdr::K_FFT) && capture_k % RING == 0)  // the replay's cursors, in front of its first FFT
         hipLaunchKernelGGL(k_set_cursors, dim3(1), dim3(64), 0, stream_of(sdr::K_FFT), b->cursors.p + capture_k, CursorPack{});
-    int max_slots = 0, slots_in_use = 0;
-    for (int i = 0; i < B; i++) {
-        max_slots = std::max(max_slots, b->n_slots[i]);
-        slots_in_use += b->n_slots[i];
-    }
     if (b->results_on && !cap) {
         const int prc = park_results(b, S);
         if (prc)
@@ -639,6 +670,7 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
                                                              stream_of(sdr::K_THRESHOLDS)));
     }
     SDR_DONE(sdr::K_THRESHOLDS);
+    }  // do_spectra
 
     // per-signal envelope + decoder
     sdr::ListenGeom lg;
@@ -649,7 +681,8 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     lg.edge_cap = b->edge_cap;
     lg.bit_words = b->bit_words;
     lg.trace = c.trace;
-    lg.frame_base = (uint32_t)b->total_frames;
+    lg.frame_base = (uint32_t)first_frame;
+    if (do_listen) {
     SDR_AFTER(sdr::K_LISTEN_GATHER, sdr::K_THRESHOLDS);
     SDR_AFTER(sdr::K_LISTEN_GATHER, sdr::K_FFT);
     // (armed whether or not the stage launches: SDR_DONE records a stage event nobody took the ordinary way, and a
@@ -657,8 +690,8 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     SDR_ARM(sdr::K_LISTEN_GATHER);
     if (max_slots > 0) {
         ProfScope ps(b, sdr::K_LISTEN_GATHER, stream_of(sdr::K_LISTEN_GATHER));
-        SDR_LAUNCH(sdr::K_LISTEN_GATHER, sdr::launch_listen_gather(S.tap.p, S.recs.p, b->slots.p, b->db_tab.p, S.raw_bits.p, S.tr_values.p,
-                                                                   S.tr_raw.p, lg, n_frames, max_slots, B,
+        SDR_LAUNCH(sdr::K_LISTEN_GATHER, sdr::launch_listen_gather(S.tap.p, S.psd.p, S.recs.p, b->slots.p, b->db_tab.p, S.raw_bits.p, S.tr_values.p,
+                                                                   S.tr_raw.p, cur, lg, n_frames, max_slots, B,
                                                                    stream_of(sdr::K_LISTEN_GATHER)));
     }
     SDR_DONE(sdr::K_LISTEN_GATHER);
@@ -681,6 +714,15 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
             HIP_TRY(hipEventRecord(S.res_listen, stream_of(sdr::K_LISTEN_DECODE)));
     }
     SDR_DONE(sdr::K_LISTEN_DECODE);
+    }  // do_listen
+    if (!do_spectra) {
+        // the batch is complete: sdr_poll may have it
+        std::lock_guard<std::mutex> guard(b->res_mu);
+        S.res_slots = max_slots;
+        b->batches_enqueued = b->pend.batch + 1;
+        b->listen_pending = false;
+        return SDR_OK;
+    }
 
     // dB projection + cumulation, peak scan (rx/receiver.go:404-409,459-460)
     const int count0 = b->cum_count;
@@ -727,9 +769,10 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
             S.res_frames = n_frames;
             S.res_chunks = n_chunks;
             S.res_count0 = count0;
-            S.res_slots = max_slots;
+            S.res_slots = do_listen ? max_slots : 0;  // (sdr_poll_peaks delivers the spectral half; the listen half fills this in)
             S.res_center = b->center_frequency;
-            b->batches_enqueued = b->batch_index + 1;
+            if (do_listen)
+                b->batches_enqueued = b->batch_index + 1;
         }
     }
     SDR_DONE(sdr::K_FIND_PEAKS);
@@ -751,6 +794,13 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     b->last_frames = n_frames;
     b->last_chunks = n_chunks;
     b->last_count0 = count0;
+    if (!do_listen) {
+        b->pend.set = si;
+        b->pend.frames = n_frames;
+        b->pend.first_frame = b->total_frames;
+        b->pend.batch = b->batch_index;
+        b->listen_pending = true;
+    }
     b->total_frames += n_frames;
     b->batch_index++;
     if (!b->results_on) {
@@ -1268,6 +1318,7 @@ int sdr_attach(sdr_bank *b, int band, int bin, int *listener_id)
     cw::debouncer_init(s.deb, c.signal_debounce);          // NewSpectralDemodulator, cw/spectral.go:25-33
     cw::decoder_init(s.dec, c.sample_rate, c.block_size);  // NewDecoder, cw/decode.go:131-147
     cw::decoder_reset(s.dec);                              // Listener.Attach -> demodulator.Reset, listener.go:88
+    s.start_frame = s.tapped_from = (uint32_t)b->total_frames;  // listens from the next frame processed
     rc = sync_bank(b);
     if (rc)
         return rc;
@@ -1298,6 +1349,86 @@ int sdr_detach(sdr_bank *b, int band, int lid)
     HIP_TRY(hipMemcpy(b->tap_bins.p + (size_t)band * b->cfg.max_listeners + lid, &free_bin, sizeof free_bin,
                       hipMemcpyHostToDevice));
     b->attach_gen++;
+    return SDR_OK;
+}
+
+// ---- deferred listen half: strain-mode discovery without a host round trip per cumulation -----------------------
+// rx/receiver.go:409-426 binds one listener per completed cumulation, to a peak of that cumulation, and the listener
+// hears the very next frame.  Frame by frame that is a decision on the host every 100 frames.  Here the spectral half
+// of a long batch runs first (FFT .. FindPeaks of EVERY cumulation in it), the host reads those peaks (sdr_poll_peaks),
+// makes the same decisions in the same order and binds each listener with the frame it starts at (sdr_attach_at); then
+// the listen half runs over the retained spectra (sdr_process_listen).  Listeners are independent of each other, so a
+// listener that starts in the middle of the batch produces exactly what it would have produced attached there live.
+int sdr_defer_listen(sdr_bank *b, int on)
+{
+    if (!b)
+        return fail(SDR_ERR_BAD_ARG, "null bank");
+    if (on && !b->results_on)
+        return fail(SDR_ERR_STATE, "deferred listening needs bulk delivery (sdr_enable_results)");
+    if (b->listen_pending)
+        return fail(SDR_ERR_STATE, "a batch waits for its listen half (sdr_process_listen)");
+    b->defer_listen = on != 0;
+    return SDR_OK;
+}
+
+int sdr_listen_pending(sdr_bank *b) { return b && b->listen_pending ? 1 : 0; }
+
+int sdr_process_listen(sdr_bank *b)
+{
+    if (!b)
+        return fail(SDR_ERR_BAD_ARG, "null bank");
+    if (b->failed)
+        return fail(SDR_ERR_STATE, "an earlier process call failed half way; destroy the bank");
+    if (!b->listen_pending)
+        return fail(SDR_ERR_STATE, "no batch waits for its listen half");
+    const int rc = process_device_body(b, nullptr, b->pend.frames, b->pend.frames, -1, -1, PART_LISTEN);
+    if (rc == SDR_ERR_HIP)
+        b->failed = true;
+    return rc;
+}
+
+int sdr_attach_at(sdr_bank *b, int band, int bin, int64_t start_frame, int *listener_id)
+{
+    int rc = check_band(b, band);
+    if (rc)
+        return rc;
+    const sdr_config &c = b->cfg;
+    if (bin < 0 || bin >= c.block_size)
+        return fail(SDR_ERR_BAD_ARG, "bin out of range");
+    const int64_t lo = b->listen_pending ? b->pend.first_frame : b->total_frames;
+    if (start_frame < lo || start_frame > b->total_frames)
+        return fail(SDR_ERR_BAD_ARG, "start_frame must lie in the batch that waits for its listen half (or be the next frame)");
+    if (b->graph_ready)
+        return fail(SDR_ERR_STATE, "a graph is captured (sdr_graph_release first)");
+    HIP_TRY(hipSetDevice(b->device));
+    int lid = -1;
+    for (int i = 0; i < b->n_slots[band]; i++)
+        if (!b->h_slots[(size_t)band * c.max_listeners + i].active) {
+            lid = i;
+            break;
+        }
+    if (lid < 0) {
+        if (b->n_slots[band] >= c.max_listeners)
+            return fail(SDR_ERR_NO_SLOT, "listener pool exhausted");
+        lid = b->n_slots[band]++;
+    }
+    sdr::ListenerSlot &s = b->h_slots[(size_t)band * c.max_listeners + lid];
+    memset(&s, 0, sizeof s);
+    s.active = 1;
+    s.bin = bin;
+    cw::debouncer_init(s.deb, c.signal_debounce);
+    cw::decoder_init(s.dec, c.sample_rate, c.block_size);
+    cw::decoder_reset(s.dec);
+    s.start_frame = (uint32_t)start_frame;
+    s.tapped_from = (uint32_t)b->total_frames;  // the FFT of every frame before that has run without this listener
+    // the slot is only ever touched on the listen stream, the tap bins are read by the FFT kernel
+    hipLaunchKernelGGL(k_put_slot, dim3(1), dim3(64), 0, b->stream[S_LISTEN], b->slots.p + (size_t)band * c.max_listeners + lid, s);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_put_int, dim3(1), dim3(64), 0, b->stream[S_FFT], b->tap_bins.p + (size_t)band * c.max_listeners + lid, (int32_t)bin);
+    HIP_TRY(hipGetLastError());
+    b->attach_gen++;
+    if (listener_id)
+        *listener_id = lid;
     return SDR_OK;
 }
 
@@ -2191,6 +2322,30 @@ int sdr_poll(sdr_bank *b, sdr_results *r, int wait)
         b->deliver_next++;
     }
     return rc;
+}
+
+int sdr_poll_peaks(sdr_bank *b, sdr_results *r, int wait)
+{
+    if (!b || !r)
+        return fail(SDR_ERR_BAD_ARG, "null argument");
+    if (r->struct_size != (int32_t)sizeof(sdr_results))
+        return fail(SDR_ERR_BAD_ARG, "sdr_results.struct_size mismatch (ABI)");
+    if (!b->results_on || !b->listen_pending)
+        return fail(SDR_ERR_STATE, "no batch waits for its listen half");
+    HIP_TRY(hipSetDevice(b->device));
+    BatchSet &S = b->set[b->pend.set];
+    if (wait) {
+        HIP_TRY(hipEventSynchronize(S.res_peaks));
+    } else {
+        const hipError_t q = hipEventQuery(S.res_peaks);
+        if (q == hipErrorNotReady)
+            return fail(SDR_ERR_WOULD_BLOCK, "the batch's cumulations have not finished");
+        HIP_TRY(q);
+    }
+    std::unique_lock<std::mutex> guard(b->res_mu);
+    // (no listeners' output yet: res_slots is 0 until the listen half has run; the batch stays undelivered)
+    const BatchMeta m{S.res_batch, S.res_first_frame, S.res_frames, S.res_chunks, S.res_count0, 0, &S.res_center};
+    return deliver_block(b, S.res_host, m, r);
 }
 
 int sdr_read_drop_counters(sdr_bank *b, uint64_t *runes_dropped, uint64_t *edges_dropped)

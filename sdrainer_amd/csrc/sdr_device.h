@@ -28,8 +28,13 @@ struct ListenerSlot {
     cw::DecoderState dec;
     uint32_t text_count;    // runes in the text buffer not yet read by the host
     uint32_t text_dropped;  // runes dropped because the buffer was full (since attach)
-    uint32_t reserved0;
-    int32_t reserved1;
+    // Bank frame index (32 bits, wrapping like every frame number on the device) from which the listener listens, and
+    // from which the FFT kernel has tapped its bin (k_fft_psd.hip "The tap").  Equal for a listener attached between
+    // batches.  A listener bound to a batch whose spectra already exist (sdr_attach_at: strain-mode discovery without a
+    // host round trip per cumulation) starts inside that batch - frames before start_frame do not reach its debouncer
+    // or decoder - and reads its bin from the retained psd rows up to tapped_from.
+    uint32_t start_frame;
+    uint32_t tapped_from;
 };
 
 // Bank-wide overflow counters (device memory): what the reference's never-dropping io.Writer would have kept.
@@ -129,9 +134,9 @@ hipError_t launch_noise_stats(const float *psd, const double *win_mean, sdr_fram
                               int n_bands, int stride, hipStream_t stream);
 hipError_t launch_thresholds(sdr_frame_rec *recs, BandState *st, int n_frames, int n_bands, int stride,
                              hipStream_t stream);
-hipError_t launch_listen_gather(const float *tap, const sdr_frame_rec *recs, const ListenerSlot *slots, const void *db_tab,
-                                uint64_t *raw_bits, float *tr_values, uint8_t *tr_raw, ListenGeom g, int n_frames, int n_slots,
-                                int n_bands, hipStream_t stream);
+hipError_t launch_listen_gather(const float *tap, const float *psd, const sdr_frame_rec *recs, const ListenerSlot *slots, const void *db_tab,
+                                uint64_t *raw_bits, float *tr_values, uint8_t *tr_raw, const BatchCursor *cur, ListenGeom g, int n_frames,
+                                int n_slots, int n_bands, hipStream_t stream);
 hipError_t launch_listen_decode(ListenerSlot *slots, const uint16_t *morse, const uint64_t *raw_bits,
                                 uint64_t *deb_bits, uint32_t *text, uint32_t *text_frames, sdr_edge *edges,
                                 uint32_t *edge_counts, uint8_t *tr_deb, DropCounters *drops, const BatchCursor *cur, ListenGeom g,

@@ -12,7 +12,7 @@ if [ $# -eq 0 ]; then
   set -- fb_prod "" fb_clock "-DSDR_FFT_CLOCK" fb_phases "-DSDR_FFT_PHASES=1000" \
          fb_abl1 "-DSDR_ABLATE=1" fb_abl3 "-DSDR_ABLATE=3" fb_abl5 "-DSDR_ABLATE=5" fb_abl6 "-DSDR_ABLATE=6" fb_abl7 "-DSDR_ABLATE=7" \
          fb_abl8 "-DSDR_ABLATE=8" fb_abl10 "-DSDR_ABLATE=10" fb_abl11 "-DSDR_ABLATE=11" fb_abl12 "-DSDR_ABLATE=12" \
-         fb_abl13 "-DSDR_ABLATE=13" fb_abl14 "-DSDR_ABLATE=14"
+         fb_abl13 "-DSDR_ABLATE=13" fb_abl14 "-DSDR_ABLATE=14" fb_abl15 "-DSDR_ABLATE=15" fb_abl16 "-DSDR_ABLATE=16"
 fi
 pids=()
 names=()
