@@ -13,9 +13,11 @@
 // listener is bound to which peak, time-outs.  Everything per frame is on the device.
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <memory>
 #include <atomic>
@@ -106,12 +108,13 @@ public:
         const double now = clock_->Now();
         int i = 0;
         while (i < (int)bins_.size()) {
-            std::shared_ptr<Entry> p = bins_[i];
+            const Entry *p = bins_[i].get();
             i++;
             if (!p || p->state == peakActive || now - p->since < peakTimeout_)
                 continue;
-            clear(p->peak.from, p->peak.to);
-            i = p->peak.to + 1;
+            const int from = p->peak.from, to = p->peak.to;  // (clear drops the entry)
+            clear(from, to);
+            i = to + 1;
         }
     }
     void Reset() { std::fill(bins_.begin(), bins_.end(), nullptr); }  // :149-151
@@ -676,7 +679,9 @@ public:
                 return resolvePending();
             const int limit = segmentLimit(staged);
             int n = 0;
-            int rc = sdr_process_staged_limit(bank_, limit, &n);
+            int rc = sdr_defer_listen(bank_, speculative_ ? 1 : 0);
+            if (rc == SDR_OK)
+                rc = sdr_process_staged_limit(bank_, limit, &n);
             if (rc != SDR_OK)
                 return rc;
             if (n == 0)
@@ -696,7 +701,9 @@ public:
         int done = 0;
         while (done < n_frames) {
             const int n = segmentLimit(n_frames - done);
-            int rc = sdr_process_device(bank_, iq_dev + (size_t)done * 2 * (size_t)blockSize_, n);
+            int rc = sdr_defer_listen(bank_, speculative_ ? 1 : 0);
+            if (rc == SDR_OK)
+                rc = sdr_process_device(bank_, iq_dev + (size_t)done * 2 * (size_t)blockSize_, n);
             if (rc != SDR_OK)
                 return rc;
             rc = segmentLaunched(n);
@@ -710,7 +717,11 @@ public:
     PeaksTable &Peaks() { return *peaks_; }
     ListenerPool &Listeners() { return listeners_; }
     sdr_bank *Bank() { return bank_; }
-    int64_t FramesProcessed() const { return framesProcessed_; }
+    // frames the receiver has been through; inside a Reporter callback: up to and including the frame the event belongs
+    // to (the device may be further ahead - segments in flight, or a segment whose boundaries are being decided)
+    int64_t FramesProcessed() const { return reportFrames_ >= 0 ? reportFrames_ : framesProcessed_; }
+    // seconds spent in discoverAhead so far: waiting for the peaks, deciding + binding, enqueueing the listen half
+    const double *AheadTiming() const { return aheadTiming_; }
     const std::vector<Peak> &LastPeaks() const { return lastPeaks_; }
 
     // :474-500 (peakPadding = 0: a found run is re-centred to its strongest bin)
@@ -780,10 +791,12 @@ private:
         l->SetSilenceTimeout(silenceTimeout_);
         return l;
     }
-    int attach(const std::shared_ptr<Listener> &listener, const Peak &peak)
+    // first_frame >= 0: the frame the listener hears first, inside (or right behind) a segment whose spectra exist
+    int attach(const std::shared_ptr<Listener> &listener, const Peak &peak, int64_t first_frame = -1)
     {
         int dev = -1;
-        const int rc = sdr_attach(bank_, 0, peak.signal_bin, &dev);
+        const int rc = first_frame >= 0 && sdr_listen_pending(bank_) ? sdr_attach_at(bank_, 0, peak.signal_bin, first_frame, &dev)
+                                                                      : sdr_attach(bank_, 0, peak.signal_bin, &dev);
         if (rc != SDR_OK)
             return rc;
         listener->Attach(peak, dev);
@@ -813,12 +826,27 @@ private:
     {
         int limit = std::min(available, maxBatchFrames_);
         segExpiryAtEnd_ = false;
+        speculative_ = false;
         if (mode_ != StrainMode)
             return limit;
         const int until_boundary = kCumulationSize - (int)(framesProcessed_ % kCumulationSize);
         const bool hunting = listeners_.Available();
-        if (hunting)
+        // Hunting over a long segment (stream clock only - with a caller's clock the time of a frame inside a segment
+        // is not defined): the device runs the spectral half of the whole segment, the host then makes the decisions
+        // of every cumulation boundary in it, in order (discoverAhead), and only then the listeners run.  A listener
+        // bound at the segment's first boundary must not be able to time out inside the segment: that bounds its length.
+        speculative_ = hunting && clock_ == &streamClock_ && !std::getenv("SDR_RX_NO_SPECULATION");
+        if (hunting && !speculative_)
             limit = std::min(limit, until_boundary);
+        if (speculative_) {
+            const double T = (double)blockSize_ / (double)sampleRate_;
+            const double shortest = std::min(attachmentTimeout_, silenceTimeout_);
+            if (shortest < 1e17) {
+                // bound at frame b (clock frameTime(b)), it fires at the first f with (f - b) * T > shortest
+                const int64_t quiet = (int64_t)std::floor(shortest / T) - 1;  // frames after b that are certainly safe
+                limit = (int)std::max<int64_t>(std::min<int64_t>(limit, until_boundary + std::max<int64_t>(quiet, 0)), 1);
+            }
+        }
         if (clock_ == &streamClock_) {
             int64_t first = INT64_MAX;
             for (auto &l : listeners_.Listeners())
@@ -842,27 +870,74 @@ private:
     // segmentLimit only makes the next cut earlier than necessary, never later.
     int segmentLaunched(int n)
     {
+        const int64_t start = framesProcessed_;
         framesProcessed_ += n;
-        pending_.push_back(n);
-        const bool decide = mode_ == StrainMode && (listeners_.Available() || segExpiryAtEnd_);
+        bool end_decided = false;
+        if (speculative_) {
+            // while the device runs the spectral half just enqueued: the results of everything older (their listeners
+            // ran beside it), so the runes are fed and the clock moves in frame order
+            int rc = resolvePending(0);
+            if (rc == SDR_OK)
+                rc = discoverAhead(start, n, &end_decided);
+            if (rc != SDR_OK)
+                return rc;
+        }
+        pending_.push_back(Segment{n, end_decided});
+        const bool decide = mode_ == StrainMode && ((listeners_.Available() && !speculative_) || segExpiryAtEnd_);
         if (decide || (int)pending_.size() > 4)
             return resolvePending(decide ? 0 : 4);
         return SDR_OK;
+    }
+    // The decisions of every cumulation boundary inside the segment [start, start + n), whose spectral half has been
+    // enqueued (sdr_defer_listen): for each completed cumulation, in order - the stream clock at that frame, the peaks
+    // table's clean-up, Put / FindNext / BindNext / Activate / Attach (:409-426) - with the listener listening from the
+    // frame after its boundary (sdr_attach_at).  No time-out can fire inside the segment (segmentLimit), so nothing here
+    // depends on what the listeners decode; their runes arrive with the segment's results as usual.  A boundary on
+    // the segment's LAST frame is left to afterSegment when a time-out may fire on that frame (it frees a slot first).
+    int discoverAhead(int64_t start, int n, bool *end_decided)
+    {
+        sdr_results r = pollBuffers();
+        const auto t0 = std::chrono::steady_clock::now();
+        int rc = sdr_poll_peaks(bank_, &r, 1);
+        if (rc != SDR_OK)
+            return rc;
+        const auto t1 = std::chrono::steady_clock::now();
+        const int64_t last = start + n - 1;
+        for (int ci = 0; ci < r.n_chunks && listeners_.Available(); ci++) {
+            const int64_t boundary = r.chunks[ci].frame;
+            if (boundary == last && segExpiryAtEnd_)
+                break;
+            streamClock_.Set(frameTime(boundary));
+            reportFrames_ = boundary + 1;
+            cleanupPeaks();
+            discover(r, ci, boundary + 1);
+            if (boundary == last)
+                *end_decided = true;
+        }
+        reportFrames_ = -1;
+        const auto t2 = std::chrono::steady_clock::now();
+        rc = sdr_process_listen(bank_);
+        aheadTiming_[0] += std::chrono::duration<double>(t1 - t0).count();
+        aheadTiming_[1] += std::chrono::duration<double>(t2 - t1).count();
+        aheadTiming_[2] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count();
+        return rc;
     }
     int resolvePending(int keep = 0)
     {
         while ((int)pending_.size() > keep) {
             int64_t ahead = 0;  // frames launched behind the segment being resolved
             for (size_t i = 1; i < pending_.size(); i++)
-                ahead += pending_[i];
-            const int rc = afterSegment(framesProcessed_ - ahead);
+                ahead += pending_[i].frames;
+            reportFrames_ = framesProcessed_ - ahead;
+            const int rc = afterSegment(framesProcessed_ - ahead, pending_.front().end_decided);
+            reportFrames_ = -1;
             if (rc != SDR_OK)
                 return rc;
             pending_.erase(pending_.begin());
         }
         return SDR_OK;
     }
-    int afterSegment(int64_t segment_end)  // results of the oldest unresolved segment, which ended before frame segment_end
+    sdr_results pollBuffers()
     {
         sdr_results r{};
         r.struct_size = sizeof r;
@@ -877,6 +952,13 @@ private:
         r.runes = resRunes_.data();
         r.rune_frames = resRuneFrames_.data();
         r.runes_cap = (int)resRunes_.size();
+        return r;
+    }
+    // results of the oldest unresolved segment, which ended before frame segment_end (end_decided: discoverAhead has
+    // already made the decision of a boundary on its last frame)
+    int afterSegment(int64_t segment_end, bool end_decided)
+    {
+        sdr_results r = pollBuffers();
         const int rc = sdr_poll(bank_, &r, 1);
         if (rc != SDR_OK)
             return rc;
@@ -917,21 +999,33 @@ private:
         }
         for (auto &w : work)
             w.first->FlushEvents();
-        streamClock_.Set(frameTime(segment_end - 1));
+        // (segments behind this one may already have moved the clock on: discoverAhead.  It only ever runs forward -
+        // what is evaluated here, time-outs and the once-a-second clean-up, then sees the later time, as it would a
+        // moment later anyway; no listener bound ahead can have timed out by then: segmentLimit)
+        if (frameTime(segment_end - 1) > streamClock_.Now() || clock_ != &streamClock_)
+            streamClock_.Set(frameTime(segment_end - 1));
         housekeeping();
         checkTimeouts();
-        if (mode_ == StrainMode && segment_end % kCumulationSize == 0 && listeners_.Available() && r.n_chunks > 0)
-            discover(r, r.n_chunks - 1);
+        if (mode_ == StrainMode && !end_decided && segment_end % kCumulationSize == 0 && listeners_.Available() && r.n_chunks > 0)
+            discover(r, r.n_chunks - 1, segment_end);
         return SDR_OK;
     }
     void housekeeping()  // the cleanupTicker case, :359-363: once per second of clock time
     {
         const double now = clock_->Now();
-        if (now - lastCleanup_ < 1.0)
+        if (now - lastCleanup_ >= 1.0) {
+            lastCleanup_ = now;
+            for (auto &l : listeners_.Listeners())
+                l->CheckWriteTimeout();
+        }
+        cleanupPeaks();
+    }
+    void cleanupPeaks()  // the peaks table's half of the ticker (discoverAhead runs it boundary by boundary)
+    {
+        const double now = clock_->Now();
+        if (now - lastPeaksCleanup_ < 1.0)
             return;
-        lastCleanup_ = now;
-        for (auto &l : listeners_.Listeners())
-            l->CheckWriteTimeout();
+        lastPeaksCleanup_ = now;
         if (peaks_)
             peaks_->Cleanup();
     }
@@ -950,7 +1044,8 @@ private:
         for (auto &l : detached)
             listeners_.Release(l);
     }
-    void discover(const sdr_results &r, int chunk)  // :409-426
+    // :409-426; the listener hears frame `first_frame` first (the frame after the cumulation's last)
+    void discover(const sdr_results &r, int chunk, int64_t first_frame)
     {
         const sdr_chunk_result &cr = r.chunks[chunk];
         lastPeaks_.assign(r.peaks + cr.first_peak, r.peaks + cr.first_peak + cr.n_peaks);
@@ -964,7 +1059,7 @@ private:
             return;
         const Peak chosen = *selected;
         peaks_->Activate(chosen);
-        attach(listener, chosen);
+        attach(listener, chosen, first_frame);
     }
 
     std::string id_;
@@ -983,12 +1078,18 @@ private:
     PeaksTable::RandFn rand_;
     PeaksTable::Policy policy_ = PeaksTable::ReferenceOrder;
     ListenerPool listeners_;
-    int64_t framesProcessed_ = 0;
+    int64_t framesProcessed_ = 0, reportFrames_ = -1;
+    double aheadTiming_[3] = {0, 0, 0};
     int maxBatchFrames_ = 256;
     bool segExpiryAtEnd_ = false;
-    std::vector<int> pending_;  // frames of the segments enqueued but not yet resolved (oldest first)
+    bool speculative_ = false;  // the segment being cut is processed spectra first, decisions next, listeners last
+    struct Segment {
+        int frames;
+        bool end_decided;
+    };
+    std::vector<Segment> pending_;  // the segments enqueued but not yet resolved (oldest first)
     std::unique_ptr<Workers> workers_;
-    double lastCleanup_ = 0;
+    double lastCleanup_ = 0, lastPeaksCleanup_ = 0;
     std::vector<Peak> lastPeaks_;
     // sdr_poll buffers
     std::vector<sdr_chunk_result> resChunks_;

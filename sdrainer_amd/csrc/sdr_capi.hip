@@ -212,6 +212,7 @@ struct sdr_bank {
         int set = 0, frames = 0;
         int64_t first_frame = 0, batch = 0;
     } pend;
+    std::vector<int> late_attached;  // flattened slot indices bound by sdr_attach_at, not on the device yet
     // bulk delivery
     bool results_on = false;
     sdr::ResultsLayout res_layout{};
@@ -307,9 +308,15 @@ void resolve_profile(sdr_bank *b)
     b->pending.clear();
 }
 
+int flush_late_attached(sdr_bank *b);
 int sync_bank(sdr_bank *b)
 {
     HIP_TRY(hipSetDevice(b->device));
+    {
+        const int frc = flush_late_attached(b);  // (whoever synchronises next may read or write slots)
+        if (frc)
+            return frc;
+    }
     for (int s = 0; s < N_STAGES; s++)
         HIP_TRY(hipStreamSynchronize(b->stream[s]));
     resolve_profile(b);
@@ -366,15 +373,60 @@ __global__ void k_set_cursors(sdr::BatchCursor *dst, CursorPack v)
 
 // sdr_attach_at: the new listener's slot and tap bin reach the device as kernel arguments, in stream order, without a
 // synchronous copy (the pipeline keeps running while the host binds listeners)
-__global__ void k_put_slot(sdr::ListenerSlot *dst, sdr::ListenerSlot v)
+constexpr int PUT_SLOTS = 16, PUT_BINS = 128;  // per launch (kernel arguments: 16 slots are about 2.5 KB)
+struct SlotPack {
+    int32_t n;
+    int32_t index[PUT_SLOTS];
+    sdr::ListenerSlot slot[PUT_SLOTS];
+};
+struct BinPack {
+    int32_t n;
+    int32_t index[PUT_BINS], bin[PUT_BINS];
+};
+__global__ void k_put_slots(sdr::ListenerSlot *slots, SlotPack p)
 {
-    if (threadIdx.x == 0)
-        *dst = v;
+    // (word-wise: a slot is a few dozen words)
+    constexpr int W = sizeof(sdr::ListenerSlot) / 4;
+    static_assert(sizeof(sdr::ListenerSlot) % 4 == 0, "word copy");
+    for (int i = threadIdx.x; i < p.n * W; i += blockDim.x)
+        reinterpret_cast<uint32_t *>(slots + p.index[i / W])[i % W] = reinterpret_cast<const uint32_t *>(&p.slot[i / W])[i % W];
 }
-__global__ void k_put_int(int32_t *dst, int32_t v)
+__global__ void k_put_bins(int32_t *bins, BinPack p)
 {
-    if (threadIdx.x == 0)
-        *dst = v;
+    for (int i = threadIdx.x; i < p.n; i += blockDim.x)
+        bins[p.index[i]] = p.bin[i];
+}
+
+// The listeners bound by sdr_attach_at since the last flush, to the device: their slots on the listen stream (the only
+// stream that touches slots), their tap bins on the FFT stream (read by the next FFT) - a handful of launches whatever
+// their number, and no synchronous copy.
+int flush_late_attached(sdr_bank *b)
+{
+    if (b->late_attached.empty())
+        return SDR_OK;
+    const std::vector<int> &v = b->late_attached;
+    for (size_t at = 0; at < v.size(); at += PUT_SLOTS) {
+        SlotPack p{};
+        p.n = (int32_t)std::min<size_t>(PUT_SLOTS, v.size() - at);
+        for (int i = 0; i < p.n; i++) {
+            p.index[i] = v[at + i];
+            p.slot[i] = b->h_slots[(size_t)v[at + i]];
+        }
+        hipLaunchKernelGGL(k_put_slots, dim3(1), dim3(256), 0, b->stream[S_LISTEN], b->slots.p, p);
+        HIP_TRY(hipGetLastError());
+    }
+    for (size_t at = 0; at < v.size(); at += PUT_BINS) {
+        BinPack p{};
+        p.n = (int32_t)std::min<size_t>(PUT_BINS, v.size() - at);
+        for (int i = 0; i < p.n; i++) {
+            p.index[i] = v[at + i];
+            p.bin[i] = b->h_slots[(size_t)v[at + i]].bin;
+        }
+        hipLaunchKernelGGL(k_put_bins, dim3(1), dim3(128), 0, b->stream[S_FFT], b->tap_bins.p, p);
+        HIP_TRY(hipGetLastError());
+    }
+    b->late_attached.clear();
+    return SDR_OK;
 }
 
 enum Parts { PART_SPECTRA = 1, PART_LISTEN = 2, PART_ALL = 3 };
@@ -534,6 +586,11 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     if (n_frames > c.max_batch_frames)
         return fail(SDR_ERR_BAD_ARG, "n_frames exceeds max_batch_frames");
     HIP_TRY(hipSetDevice(b->device));
+    if (!cap) {
+        const int frc = flush_late_attached(b);
+        if (frc)
+            return frc;
+    }
     const int B = c.n_bands, N = c.block_size, stride = c.max_batch_frames;
     const sdr::NoiseGeom ng = b->noise_geom();
     const int si = cap ? RING + capture_k : do_spectra ? (int)(b->batch_index % RING) : b->pend.set;  // (capture: the sets sdr_graph_capture added)
@@ -1421,11 +1478,8 @@ int sdr_attach_at(sdr_bank *b, int band, int bin, int64_t start_frame, int *list
     cw::decoder_reset(s.dec);
     s.start_frame = (uint32_t)start_frame;
     s.tapped_from = (uint32_t)b->total_frames;  // the FFT of every frame before that has run without this listener
-    // the slot is only ever touched on the listen stream, the tap bins are read by the FFT kernel
-    hipLaunchKernelGGL(k_put_slot, dim3(1), dim3(64), 0, b->stream[S_LISTEN], b->slots.p + (size_t)band * c.max_listeners + lid, s);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_put_int, dim3(1), dim3(64), 0, b->stream[S_FFT], b->tap_bins.p + (size_t)band * c.max_listeners + lid, (int32_t)bin);
-    HIP_TRY(hipGetLastError());
+    // (reaches the device with the next sdr_process_listen / process call: flush_late_attached)
+    b->late_attached.push_back(band * c.max_listeners + lid);
     b->attach_gen++;
     if (listener_id)
         *listener_id = lid;

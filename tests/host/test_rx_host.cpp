@@ -244,7 +244,7 @@ struct PrintReporter : rx::Reporter {
 };
 
 static int run_strain(const char *path, int rate, int n, int frames, int pool, bool strongest = false, double silence = 1e9,
-                      double attachment = 1e9, int max_batch = 256)
+                      double attachment = 1e9, int max_batch = 256, int piece = 0)
 {
     FILE *f = fopen(path, "rb");
     if (!f)
@@ -271,10 +271,11 @@ static int run_strain(const char *path, int rate, int n, int frames, int pool, b
     if (r.IQData(rate + 1, iq.data(), 2 * (size_t)n) != SDR_ERR_BAD_RATE || r.IQData(rate, iq.data(), 2 * (size_t)n - 2) != SDR_ERR_BAD_SIZE)
         return 4;
     // frames arrive in ragged pieces, Process() is called whenever some are staged
+    // (or, argv[11], in equal pieces of that many frames: long segments with many cumulation boundaries each)
     const int pieces[] = {1, 37, 100, 163, 7, 250};
     int done = 0, k = 0;
     while (done < frames) {
-        const int m = std::min(pieces[k++ % 6], frames - done);
+        const int m = std::min(piece > 0 ? piece : pieces[k++ % 6], frames - done);
         if (r.IQData(rate, iq.data() + (size_t)done * 2 * n, (size_t)m * 2 * n) != SDR_OK)
             return 5;
         done += m;
@@ -524,7 +525,7 @@ int main(int argc, char **argv)
     if (argc >= 7 && !strcmp(argv[1], "strain"))
         return run_strain(argv[2], atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]),
                           argc >= 8 && !strcmp(argv[7], "strongest"), argc >= 9 ? atof(argv[8]) : 1e9,
-                          argc >= 10 ? atof(argv[9]) : 1e9, argc >= 11 ? atoi(argv[10]) : 256);
+                          argc >= 10 ? atof(argv[9]) : 1e9, argc >= 11 ? atoi(argv[10]) : 256, argc >= 12 ? atoi(argv[11]) : 0);
     if (argc >= 7 && !strcmp(argv[1], "decode"))
         return run_decode(argv[2], atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoll(argv[6]));
     fprintf(stderr, "usage: %s cpu | text | strain <iq.f32> <rate> <N> <frames> <pool>\n", argv[0]);

@@ -898,3 +898,79 @@ def test_peak_frequencies_follow_the_batch_not_the_poll(capi):
                for p in res["peaks"][ch["first_peak"]:ch["first_peak"] + ch["n_peaks"]]]
         assert got == refs[k] and len(got) >= 1
     bank.close()
+
+
+def test_listeners_bound_inside_a_batch(capi):
+    """sdr_defer_listen / sdr_poll_peaks / sdr_attach_at / sdr_process_listen (rx/receiver.go:404-426): a batch's
+    spectral half runs first, listeners are bound to frames inside it afterwards - one at every cumulation boundary,
+    as the reference binds them - and everything each listener produces (keying edges, runes) is what the oracle
+    produces for a listener attached at that very frame, frame by frame.  The peaks of every cumulation are the
+    oracle's as well, and the batch is delivered once, whole, by sdr_poll."""
+    n, rate, tones = 1024, 96000, 6
+    frames = 730
+    iq, bins, _ = synth.make_band(frames, rate, n, tones, seed=91)
+    edge = synth.default_edge_width(n)
+    # the oracle, frame by frame as the reference runs: a listener is attached after frames 99, 199, 299 and 499
+    ref = orc.Receiver(rate, n, edge, 15.0, 1, center_frequency=3500000)
+    lid0 = ref.attach(int(bins[0]))  # one listener is there from the start
+    starts = {lid0: 0}
+    outs = []
+    pos = 0
+    for boundary, b in zip((100, 200, 300, 500), bins[1:5]):
+        outs.append((pos, ref.process(iq[pos:boundary])))
+        pos = boundary
+        starts[ref.attach(int(b))] = boundary
+    outs.append((pos, ref.process(iq[pos:])))
+
+    bank = capi.Bank(rate, n, edge_width=edge, max_batch_frames=512, max_listeners=8, max_peaks=128)
+    bank.set_center_frequency(0, 3500000)
+    assert bank.attach(0, int(bins[0])) == lid0
+    bank.enable_results(True)
+    bank.defer_listen(True)
+    text = {lid: "" for lid in starts}
+    edges = {lid: [] for lid in starts}
+    first = 0
+    for a, e in ((0, 450), (450, 730)):
+        assert bank.process_host(iq[a:e]) == e - a
+        assert bank.listen_pending and bank.poll() is None  # the batch is not deliverable before its listen half
+        with pytest.raises(Exception):
+            bank.process_device(256, 10)  # refused until sdr_process_listen (the pointer is never touched)
+        pk = bank.poll_peaks(wait=True)
+        assert pk["first_frame"] == a and pk["n_frames"] == e - a and len(pk["listeners"]) == 0
+        want_frames = [f for f in range(99, frames, 100) if a <= f < e]
+        assert [int(c["frame"]) for c in pk["chunks"]] == want_frames
+        # bind at every boundary of the batch, exactly where the oracle run attached
+        for lid, s in sorted(starts.items()):
+            if lid != lid0 and a < s <= e and s - 1 in want_frames:
+                assert bank.attach_at(0, int(bins[lid]), s) == lid
+        with pytest.raises(Exception):
+            bank.attach_at(0, int(bins[5]), a - 1)  # not inside the waiting batch
+        bank.process_listen()
+        assert not bank.listen_pending
+        res = bank.poll(wait=True)
+        assert res["first_frame"] == a and res["n_frames"] == e - a
+        assert [int(c["frame"]) for c in res["chunks"]] == want_frames
+        for r in res["listeners"]:
+            lid = int(r["listener"])
+            ed = res["edges"][r["first_edge"]:r["first_edge"] + r["n_edges"]]
+            edges[lid] += [(int(x["frame"]), int(x["state"])) for x in ed]
+            text[lid] += "".join(chr(int(x)) for x in res["runes"][r["first_rune"]:r["first_rune"] + r["n_runes"]])
+        first = e
+    assert first == frames
+    # oracle edges per listener from the segment outputs (a listener's column exists from its attach on)
+    for lid, s in starts.items():
+        want = []
+        last = 0
+        for base, out in outs:
+            if out["deb"].shape[1] <= lid or base + out["deb"].shape[0] <= s:
+                continue
+            deb = out["deb"][:, lid].astype(np.int8)
+            for j, v in enumerate(deb):
+                if base + j >= s and v != last:
+                    want.append((base + j, int(v)))
+                    last = int(v)
+        assert edges[lid] == want, lid
+        assert text[lid] == ref.text(lid), lid
+    assert sum(len(t) for t in text.values()) > 0
+    bank.defer_listen(False)
+    bank.close()

@@ -255,6 +255,43 @@ def test_strain_mode_finite_timeouts_per_frame(exe, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("silence,attachment", [(1e9, 1e9), (2.5, 6.3)])
+def test_strain_mode_long_segments_decide_like_one_cumulation_at_a_time(exe, tmp_path, silence, attachment):
+    """Discovery over long segments (rx.h discoverAhead: the spectral half of up to 1024 frames first, the decisions of
+    every cumulation boundary in it next, the listeners - bound to frames INSIDE the segment, sdr_attach_at - last)
+    against the per-frame simulation of rx/receiver.go:388-426 on the oracle, and against the same receiver made to
+    resolve every 100-frame cumulation on the host before the next (SDR_RX_NO_SPECULATION=1): same listeners on the
+    same peaks at the same frames, same time-outs, same text, same callsign events."""
+    from sdrainer_amd import synth
+
+    rate, n, pool, tones = 48000, 512, 5, 7
+    frames = 2350
+    iq, bins, _ = synth.make_band(frames, rate, n, tones, seed=58)
+    quiet, _, _ = synth.make_band(frames, rate, n, 0, seed=59)
+    iq[1700:] = quiet[1700:]
+    path = tmp_path / "iq.f32"
+    iq.astype(np.float32).tofile(path)
+    cmd = [exe, "strain", str(path), str(rate), str(n), str(frames), str(pool), "linear", str(silence), str(attachment),
+           "1024", "1000"]
+    ahead = subprocess.run(cmd, capture_output=True, text=True)
+    assert ahead.returncode == 0, ahead.stdout + ahead.stderr
+    one = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, SDR_RX_NO_SPECULATION="1"))
+    assert one.returncode == 0, one.stdout + one.stderr
+    got, ref = json.loads(ahead.stdout), json.loads(one.stdout)
+    assert got["frames"] == frames
+    assert got["events"] == ref["events"] and got["event_frames"] == ref["event_frames"]
+    assert got["listeners"] == ref["listeners"]
+    assert sorted(got["callsigns"]) == sorted(ref["callsigns"])  # (per listener in order; listeners interleave freely)
+    for lid in {c.split(" ")[0] for c in got["callsigns"]}:
+        assert [c for c in got["callsigns"] if c.startswith(lid + " ")] == [c for c in ref["callsigns"] if c.startswith(lid + " ")]
+    events, event_frames, live, sessions = _simulate_strain(iq, rate, n, pool, silence, attachment, 70)
+    assert len([e for e in events if e[0] == "+"]) >= pool
+    assert got["events"] == events and got["event_frames"] == event_frames
+    for g, l in zip(got["listeners"], live):
+        assert g["bin"] == l["bin"] and bytes(ord(ch) for ch in g["text"]).decode("utf-8") == l["text"]
+
+
+@pytest.mark.gpu
 def test_decode_mode_vfo_listener(exe, tmp_path):
     """DecodeMode (rx/receiver.go:272-297): SetVFOOffset forces a peak at the VFO frequency, the receiver's single
     listener decodes it; retuning resets the pool of one and a fresh listener takes over.  No peak scan runs."""

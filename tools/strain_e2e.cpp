@@ -1,7 +1,9 @@
 // Development aid: end-to-end strain mode through the C++ host mirror (rx::Receiver over the C ABI) on device-resident
 // IQ - discover -> attach -> decode -> callsign spots - timed in its two regimes: while the listener pool is still
-// filling (one listener bound per 100-frame cumulation, rx/receiver.go:409-426, so every segment is 100 frames and
-// is resolved before the next) and once it is full (segments of max_batch frames, three in flight).
+// filling (one listener bound per 100-frame cumulation, rx/receiver.go:409-426: the spectral half of a long segment
+// first, the boundary decisions next, the listeners last - rx.h discoverAhead; with SDR_RX_NO_SPECULATION=1 the
+// round-2 way, a 100-frame segment resolved on the host before the next) and once it is full (segments of max_batch
+// frames, up to four in flight).
 // Built as a shared library and driven by tools/strain_e2e.py, which owns the device buffer.
 #include <chrono>
 #include <cstdio>
@@ -37,22 +39,24 @@ extern "C" int strain_e2e(const float *iq_dev, int frames, int rate, int n, int 
         fprintf(stderr, "Start: %s\n", sdr_last_error());
         return rc;
     }
-    // phase 1: hunting.  The buffer is replayed from a cumulation-aligned offset so segments stay 100 frames.
+    // phase 1: hunting.  The buffer is handed over whole (cumulation-aligned: `frames` is a multiple of 100 or the
+    // replay starts over at a boundary), the receiver cuts it into segments itself.
     double t0 = now_s();
     long hunted = 0;
-    int pos = 0;
+    const int whole = frames - frames % 100;
     while (r.Listeners().Available() && hunted < 400L * pool) {
-        const int m = std::min(100, frames - pos);
-        rc = r.ProcessDevice(iq_dev + (size_t)pos * 2 * (size_t)n, m);
+        rc = r.ProcessDevice(iq_dev, whole, false);
         if (rc != SDR_OK)
             return rc;
-        hunted += m;
-        pos = (pos + m) % frames;
-        if (frames - pos < 100)
-            pos = 0;
+        hunted += whole;
     }
+    rc = r.Flush();
+    if (rc != SDR_OK)
+        return rc;
     sdr_sync(r.Bank());
     double t1 = now_s();
+    fprintf(stderr, "hunting: %.2f ms in all; deciding ahead: %.2f ms waiting for the peaks, %.2f ms deciding and binding, %.2f ms enqueueing the listeners\n",
+            (t1 - t0) * 1e3, r.AheadTiming()[0] * 1e3, r.AheadTiming()[1] * 1e3, r.AheadTiming()[2] * 1e3);
     // phase 2: pool full
     long full = 0;
     while (full < total_frames) {

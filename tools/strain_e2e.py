@@ -33,6 +33,12 @@ def main():
     iq, bins, _ = synth.make_band_torch(frames, rate, n, tones, seed=3017, device="cuda", free_last_window=True)
     torch.cuda.synchronize()
     out = (C.c_double * 8)()
+    # the round-2 way first (every 100-frame segment resolved on the host before the next), on a short run
+    os.environ["SDR_RX_NO_SPECULATION"] = "1"
+    rc = lib.strain_e2e(C.c_void_p(iq.data_ptr()), frames, rate, n, pool, 2048, frames, out)
+    assert rc == 0, rc
+    classic = list(out)
+    del os.environ["SDR_RX_NO_SPECULATION"]
     rc = lib.strain_e2e(C.c_void_p(iq.data_ptr()), frames, rate, n, pool, 2048, 400 * frames, out)
     assert rc == 0, rc
     o = list(out)
@@ -40,7 +46,10 @@ def main():
         "workload": "BASELINE config 3 through rx::Receiver (strain mode), device-resident IQ",
         "pool": pool, "listeners_bound": int(o[4]),
         "hunting": {"frames": int(o[0]), "seconds": round(o[1], 4), "MSamples_per_s": round(o[0] * n / o[1] / 1e6, 1),
-                    "segment_frames": 100},
+                    "segment_frames": "up to 2048: spectra first, the boundary decisions, then the listeners (sdr_attach_at)"},
+        "hunting_one_cumulation_per_round_trip": {"frames": int(classic[0]), "seconds": round(classic[1], 4),
+                                                  "MSamples_per_s": round(classic[0] * n / classic[1] / 1e6, 1), "segment_frames": 100,
+                                                  "listeners_bound": int(classic[4])},
         "pool_full": {"frames": int(o[2]), "seconds": round(o[3], 4), "MSamples_per_s": round(o[2] * n / o[3] / 1e6, 1),
                       "segment_frames": 2048},
         "runes_decoded": int(o[5]), "callsigns_decoded": int(o[6]), "callsigns_spotted": int(o[7]),
