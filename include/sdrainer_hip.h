@@ -272,11 +272,13 @@ int sdr_read_drop_counters(sdr_bank *bank, uint64_t *runes_dropped, uint64_t *ed
 
 /* graph mode --------------------------------------------------------------------------------- */
 /* The steady state of Receiver.run (rx/receiver.go:353-463) for sdr_graph_batches() consecutive batches of
- * n_frames frames each - every kernel launch with its fork / join over the bank's streams - captured once as a
- * hipGraph and replayed with a single launch.  Needs a bank on a real stream (sdr_set_stream with a non-null
- * stream) and, once captured, all processing to go through sdr_graph_launch (sdr_process_* return SDR_ERR_STATE
- * until sdr_graph_release).  Attaching or detaching a listener invalidates the capture (capture again).  Results are
- * read / polled exactly as after sdr_process_device; the "last batch" of the read calls is the replay's last. */
+ * n_frames frames each, recorded once and replayed: one kernel-only hipGraph per stream of the bank (two on the peaks
+ * stream), ordered inside a replay by events around whole graphs, with up to four replays in flight over buffer sets of
+ * their own (allocated at capture), so that consecutive replays overlap stage by stage like consecutive eager batches.
+ * Needs a bank on a real stream (sdr_set_stream with a non-null stream) and, once captured, all processing to go
+ * through sdr_graph_launch (sdr_process_* return SDR_ERR_STATE until sdr_graph_release).  Attaching or detaching a
+ * listener invalidates the capture (capture again).  Results are read / polled exactly as after sdr_process_device;
+ * the "last batch" of the read calls is the last replay's last. */
 int sdr_graph_batches(sdr_bank *bank);
 int sdr_graph_capture(sdr_bank *bank, int n_frames);
 /* iq_dev: sdr_graph_batches() device pointers, one batch each, layout and alignment as sdr_process_device. */

@@ -54,7 +54,20 @@ def needs_build() -> bool:
         return f.read().strip() != source_hash()
 
 
+def _drop_link_temporaries():
+    # the link step leaves its offload-bundler temporaries beside the output (libsdrainer_hip.so.N.hipv4-... /
+    # .host-...): they are not part of the product (and a build that was interrupted leaves them behind)
+    import glob
+
+    for tmp in glob.glob(LIB + ".*.hipv4-*") + glob.glob(LIB + ".*.host-*"):
+        try:
+            os.remove(tmp)
+        except OSError:
+            pass
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    _drop_link_temporaries()
     if not force and not needs_build():
         return LIB
     cc = hipcc()
@@ -73,12 +86,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    # the link step leaves its offload-bundler temporaries beside the output (libsdrainer_hip.so.N.hipv4-... /
-    # .host-...): they are not part of the product
-    import glob
-
-    for tmp in glob.glob(LIB + ".*.hipv4-*") + glob.glob(LIB + ".*.host-*"):
-        os.remove(tmp)
+    _drop_link_temporaries()
     with open(STAMP, "w") as f:
         f.write(source_hash() + "\n")
     return LIB
