@@ -45,6 +45,11 @@ WORKLOADS = {
     "c3": (2_000_000, 16384, 256, 1, True),
     "c5": (2_000_000, 8192, 16, 8, False),
 }
+# frames per band per step.  A step is one batch through the whole path; its size is the caller's choice (the bank takes
+# any), and the fixed costs of a batch - the ramp and the tail of each kernel's grid over the 256 CUs, the serial chains'
+# latency - are spread over it: config 3 at 2048 / 4096 / 8192 frames per batch runs 152 / 156 / 160 GS/s in the steady
+# state and 141 / 146 / 147 over a 20-step run, where the last batch's trip through the tail stages is in the timed region.
+DEFAULT_FRAMES = {"c2": 4096, "c3": 8192, "c5": 2048}
 WORKLOAD_TEXT = {
     "c2": "BASELINE config 2: one TCI-shaped IQ stream, 192 kS/s, 4096-pt FFT, 16 tracked peaks",
     "c3": "BASELINE config 3: wideband synthetic IQ, 2 MS/s, 16384-pt FFT, 256 concurrent CW peaks, one band per GPU "
@@ -59,7 +64,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
-    ap.add_argument("--frames", type=int, default=2048, help="frames per band per step (batch)")
+    ap.add_argument("--frames", type=int, default=None,
+                    help="frames per band per step (batch); default per workload: " +
+                         ", ".join(f"{k} {v}" for k, v in sorted(DEFAULT_FRAMES.items())))
     ap.add_argument("--ring", type=int, default=3, help="distinct input batches cycled through (defeats cache reuse)")
     ap.add_argument("--settle-ms", type=float, default=500.0,
                     help="untimed run-in before the warmup steps so the GPU's clocks have left their idle state "
@@ -234,7 +241,7 @@ def main():
     from sdrainer_amd import capi, sharding, synth
 
     rate, n, tones, bands_per_gpu, free_last = WORKLOADS[args.workload]
-    frames = args.frames
+    frames = args.frames or DEFAULT_FRAMES[args.workload]
     edge = synth.default_edge_width(n)
 
     # the one genuinely shared piece of state: configuration / thresholds, broadcast from rank 0

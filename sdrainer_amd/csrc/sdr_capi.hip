@@ -663,6 +663,16 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         slots_in_use += b->n_slots[i];
     }
     if (do_spectra) {
+    // With bulk delivery on, the set's previous batch must have been delivered (or be parked) before its block is
+    // written again - and a delivered batch is a finished one: every reader of the set is done, the queries below
+    // succeed and the FFT queue gets no barrier packets at all (each costs the command processor microseconds between
+    // two FFT kernels, and the FFT queue is the one that bounds the step).
+    static const bool park_first = !(getenv("SDR_PARK_FIRST") && atoi(getenv("SDR_PARK_FIRST")) == 0);
+    if (b->results_on && !cap && park_first) {
+        const int prc = park_results(b, S);
+        if (prc)
+            return prc;
+    }
     {
         // the last stage launched on a stream stands for all of that stream's
         static const int launch_order[] = {sdr::K_WINDOW_MEANS, sdr::K_NOISE_STATS, sdr::K_THRESHOLDS, sdr::K_LISTEN_GATHER,
@@ -686,13 +696,13 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
                 HIP_TRY(hipStreamWaitEvent(stream_of(sdr::K_FFT), S.done[k], 0));
         }
     }
-    if (cap && SDR_ON(sdr::K_FFT) && capture_k % RING == 0)  // the replay's cursors, in front of its first FFT
-        hipLaunchKernelGGL(k_set_cursors, dim3(1), dim3(64), 0, stream_of(sdr::K_FFT), b->cursors.p + capture_k, CursorPack{});
-    if (b->results_on && !cap) {
+    if (b->results_on && !cap && !park_first) {
         const int prc = park_results(b, S);
         if (prc)
             return prc;
     }
+    if (cap && SDR_ON(sdr::K_FFT) && capture_k % RING == 0)  // the replay's cursors, in front of its first FFT
+        hipLaunchKernelGGL(k_set_cursors, dim3(1), dim3(64), 0, stream_of(sdr::K_FFT), b->cursors.p + capture_k, CursorPack{});
     {
         ProfScope ps(b, sdr::K_FFT, stream_of(sdr::K_FFT));
         SDR_ARM(sdr::K_FFT);

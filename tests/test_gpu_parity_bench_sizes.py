@@ -1,7 +1,8 @@
 """GPU parity at the sizes bench.py runs ("do this" 1): the HIP path through its C ABI against the CPU
 oracle, bit for bit, on the benchmark's own generator (synth.make_band_torch) and batch geometry.
 
-  config 3   N = 16384, 256 listeners, 2048-frame batches (two of them: everything carried between batches)
+  config 3   N = 16384, 256 listeners, 2048-frame batches (two of them: everything carried between batches) and the
+             bench's default 8192-frame batch
   config 2   N = 4096, 16 listeners, 4096-frame batches
   config 5   8 channels x N = 8192 x 16 listeners, 2048-frame batches (the per-GPU share), eager and as hipGraph replays
 
@@ -96,11 +97,12 @@ def _check_batch_polled(res, outs, a, e, tones, text, n_bands):
     return n_edges, n_peaks
 
 
-def _eager_case(capi, rate, n, tones, n_bands, frames, n_batches, free_last, seed):
+def _eager_case(capi, rate, n, tones, n_bands, frames, n_batches, free_last, seed, tail_frames=0):
+    """n_batches batches of `frames` frames (and, if tail_frames, a shorter one behind them)."""
     import torch
 
     edge = synth.default_edge_width(n)
-    total = frames * n_batches
+    total = frames * n_batches + tail_frames
     dev_iq, bins_per_band, host_iq = [], [], []
     for b in range(n_bands):
         iq, bins, _ = synth.make_band_torch(total, rate, n, tones, seed=seed + 17 * b, device="cuda", free_last_window=free_last)
@@ -118,10 +120,10 @@ def _eager_case(capi, rate, n, tones, n_bands, frames, n_batches, free_last, see
     bank.enable_results(True)
     text = [["" for _ in range(tones)] for _ in range(n_bands)]
     edges = peaks = 0
-    for k in range(n_batches):
-        a, e = k * frames, (k + 1) * frames
+    spans = [(k * frames, (k + 1) * frames) for k in range(n_batches)] + ([(frames * n_batches, total)] if tail_frames else [])
+    for k, (a, e) in enumerate(spans):
         batch = torch.stack([iq[a:e] for iq in dev_iq]).contiguous()  # [band][frame][2N]
-        bank.process_device(batch.data_ptr(), frames)
+        bank.process_device(batch.data_ptr(), e - a)
         res = bank.poll(wait=True)
         assert res["batch_index"] == k
         ne, npk = _check_batch_polled(res, outs, a, e, tones, text, n_bands)
@@ -151,6 +153,12 @@ def test_config3_at_bench_size(capi):
     """bench.py's default workload: N = 16384, 256 listeners, two 2048-frame batches (decoder 4 signals per wave,
     80-workgroup window sums, 21-cumulation batches: the geometry the throughput number is quoted on)."""
     _eager_case(capi, 2_000_000, 16384, 256, 1, 2048, 2, True, seed=3000)
+
+
+def test_config3_at_bench_default_batch(capi):
+    """bench.py's default batch for config 3: 8192 frames (82 cumulations per batch, 128-word keying rows, four times
+    the edges and runes per delivery), then a short batch behind it for everything that is carried over."""
+    _eager_case(capi, 2_000_000, 16384, 256, 1, 8192, 1, True, seed=3100, tail_frames=300)
 
 
 def test_config2_at_bench_size(capi):

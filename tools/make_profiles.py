@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 from sdrainer_amd.csrc import build  # noqa: E402
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
-key = "c3_f2048"
+key = "c3_f8192"  # bench.py's default batch for config 3
 G = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 P = os.path.join(ROOT, "profiles")
 
@@ -75,14 +75,14 @@ doc = {
              "intermediate of the path, SURVEY 8(d))"),
     "_source_hash": measured_hash,
     "_round": tag,
-    key: traffic("fetch", "write", 8 * 2048 * 16384),
+    key: traffic("fetch", "write", 8 * 8192 * 16384),
     "c5_f2048": traffic("fetch_c5", "write_c5", 8 * 8 * 2048 * 8192),
 }
 json.dump(doc, open(os.path.join(P, "traffic.json"), "w"), indent=1)
 
 copies = [("bench_full.json", f"{tag}_bench_{key}.json"), ("bench_serial.err", f"{tag}_kernel_breakdown_serial.txt"),
           ("bench_insitu.err", f"{tag}_kernel_breakdown_pipelined.txt"), ("fft_sq_counters.txt", f"{tag}_fft_sq_counters.txt"),
-          ("fft_standalone.txt", f"{tag}_fft_standalone.txt"), ("fft_ablation_summary.txt", f"{tag}_fft_ablation_matrix.txt"),
+          ("fft_standalone.txt", f"{tag}_fft_standalone.txt"), ("fft_standalone_f8192.txt", f"{tag}_fft_standalone_f8192.txt"), ("fft_ablation_summary.txt", f"{tag}_fft_ablation_matrix.txt"),
           ("fft_phases.txt", f"{tag}_fft_phase_order.txt"), ("tool_manifest.txt", f"{tag}_tool_manifest.txt"),
           ("host_input_rate.txt", f"{tag}_host_input_rate.txt"), ("strain_e2e.json", f"{tag}_strain_e2e.json"),
           ("mfma_f64.txt", f"{tag}_mfma_f64_probe.txt")]
@@ -102,7 +102,7 @@ def line(name):
 
 
 other = {}
-names = ["bench_steps20", "bench_insitu", "bench_nodelivery", "bench_c5", "bench_c2"] + \
+names = ["bench_steps20", "bench_f2048", "bench_f2048_steps20", "bench_insitu", "bench_nodelivery", "bench_c5", "bench_c2"] + \
         [f"bench_graph_c5_{i}" for i in range(1, 6)] + [f"bench_graph_c3_{i}" for i in range(1, 4)]
 for name in names:
     try:

@@ -24,7 +24,9 @@ echo "sources sha256 $HASH" > $O/README.txt
 set -e
 
 # 1. the dominant kernel alone: production binary, per-workgroup spans, ablation matrix, phase order
+# (2048 frames per launch: the size every earlier round's standalone numbers were taken at; then the bench's batch)
 FPWS="1" tools/fft_matrix.sh $O/fft_standalone.txt fb_prod fb_clock > /dev/null
+FRAMES=8192 FPWS="1" tools/fft_matrix.sh $O/fft_standalone_f8192.txt fb_prod fb_clock > /dev/null
 FPWS="1" tools/fft_matrix.sh $O/fft_ablation_matrix.txt fb_prod fb_abl1 fb_abl3 fb_abl5 fb_abl6 fb_abl8 fb_abl10 fb_abl11 fb_abl12 fb_abl13 fb_abl14 fb_abl15 fb_abl16 > $O/fft_ablation_summary.txt
 FPWS="1" tools/fft_matrix.sh $O/fft_phases.txt fb_phases > /dev/null
 echo "fft standalone done"
@@ -33,7 +35,7 @@ echo "fft standalone done"
 BIN=fb_prod OUT=$O/fft_sq_counters.txt tools/pmc_fft.sh > /dev/null 2>&1 || true
 
 # 3. the whole pipeline: kernel trace, HBM traffic (separate PMC passes), bench lines
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- python3 bench.py --steps 400 --warmup 40 --no-cpu-baseline > $O/rocprof_bench.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/rocprof_bench.log 2>&1
 echo "kernel trace done"
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o fetch --output-format csv -- python3 bench.py --steps 3 --warmup 1 --settle-ms 0 --no-cpu-baseline --serial > $O/pmc_fetch.log 2>&1
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE -d $O/write -o write --output-format csv -- python3 bench.py --steps 3 --warmup 1 --settle-ms 0 --no-cpu-baseline --serial > $O/pmc_write.log 2>&1
@@ -42,21 +44,24 @@ timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE -d $O/write_c5 -o write --output-fo
 echo "pmc done"
 python bench.py > $O/bench_full.json 2> $O/bench_full.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_steps20.json 2> /dev/null
+python bench.py --frames 2048 --steps 2000 --warmup 200 --no-cpu-baseline > $O/bench_f2048.json 2> /dev/null
+python bench.py --frames 2048 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_f2048_steps20.json 2> /dev/null
 echo "bench done"
-python bench.py --steps 300 --warmup 30 --kernel-breakdown --no-cpu-baseline --serial > $O/bench_serial.json 2> $O/bench_serial.err
-python bench.py --steps 1000 --warmup 100 --kernel-breakdown --no-cpu-baseline > $O/bench_insitu.json 2> $O/bench_insitu.err
+python bench.py --steps 100 --warmup 10 --kernel-breakdown --no-cpu-baseline --serial > $O/bench_serial.json 2> $O/bench_serial.err
+python bench.py --steps 400 --warmup 40 --kernel-breakdown --no-cpu-baseline > $O/bench_insitu.json 2> $O/bench_insitu.err
 python bench.py --workload c5 --steps 600 --warmup 60 --no-cpu-baseline > $O/bench_c5.json 2>/dev/null
 python bench.py --workload c2 --frames 4096 --steps 600 --warmup 60 --no-cpu-baseline > $O/bench_c2.json 2>/dev/null
-python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-delivery > $O/bench_nodelivery.json 2>/dev/null
+python bench.py --steps 500 --warmup 50 --no-cpu-baseline --no-delivery > $O/bench_nodelivery.json 2>/dev/null
 # hipGraph A/B: five fresh processes per workload (the stability claim is about fresh processes)
 for i in 1 2 3 4 5; do
   python bench.py --workload c5 --steps 600 --warmup 60 --no-cpu-baseline --graph > $O/bench_graph_c5_$i.json 2>/dev/null || true
 done
 for i in 1 2 3; do
-  python bench.py --steps 996 --warmup 96 --no-cpu-baseline --graph > $O/bench_graph_c3_$i.json 2>/dev/null || true
+  python bench.py --steps 498 --warmup 48 --no-cpu-baseline --graph > $O/bench_graph_c3_$i.json 2>/dev/null || true
 done
 python tools/host_input_rate.py > $O/host_input_rate.txt 2>&1 || true
 timeout -k 10 300 python tools/strain_e2e.py > $O/strain_e2e.json 2>/dev/null || true
+timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1 || true
 [ -x tools/bin/ubench_mfma_f64 ] && timeout -k 5 120 tools/bin/ubench_mfma_f64 > $O/mfma_f64.txt 2>&1 || true
 echo "all done"
 tail -c 600 $O/bench_full.json
