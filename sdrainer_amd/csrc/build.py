@@ -92,5 +92,43 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+VARIANTS = {
+    # the formally fenced protocol in k_noise.hip / k_fft_psd.hip (see there): same bits, slower; checked by the GPU tests
+    "safe_fences": ["-DSDR_SAFE_FENCES"],
+}
+
+
+def variant_path(name: str) -> str:
+    return os.path.join(HERE, f"libsdrainer_hip_{name}.so")
+
+
+def build_variant(name: str, force: bool = False) -> str:
+    """A diagnostic build of the whole library with extra flags, beside the product (selected with SDR_HIP_LIB)."""
+    extra = VARIANTS[name]
+    lib, stamp = variant_path(name), variant_path(name) + ".srchash"
+    want = source_hash() + " " + " ".join(extra)
+    if not force and os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+        return lib
+    cc = hipcc()
+    objdir = os.path.join(HERE, f"obj_{name}")
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    for s in SOURCES:
+        obj = os.path.join(objdir, s.replace(".hip", ".o"))
+        subprocess.check_call([cc] + FLAGS + extra + EXTRA_FLAGS.get(s, []) + ["-c", os.path.join(HERE, s), "-o", obj])
+        objs.append(obj)
+    subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    import glob
+
+    for tmp in glob.glob(lib + ".*.hipv4-*") + glob.glob(lib + ".*.host-*"):
+        os.remove(tmp)
+    with open(stamp, "w") as f:
+        f.write(want + "\n")
+    return lib
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--variants" in sys.argv:
+        for v in VARIANTS:
+            print(build_variant(v, force="--force" in sys.argv))

@@ -41,6 +41,13 @@ extern "C" __attribute__((visibility("default"))) int sdr_debug_fft_wg(unsigned 
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fft_wg), sizeof(g_fft_wg));
 }
 #endif
+// "Everything but the n youngest vector memory operations has completed": relies on loads, stores and LDS-DMA retiring
+// in issue order (MI355X_MICROARCH.md; multi-frame workgroups only).  -DSDR_SAFE_FENCES waits for all of them instead.
+#if defined(SDR_SAFE_FENCES)
+#define SDR_WAIT_ALL_BUT(n) asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define SDR_WAIT_ALL_BUT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#endif
 constexpr int kStampCount = 16;
 enum StampId { ST_START = 0, ST_LOADED = 1, ST_PASS0 = 2, ST_EX0 = 3, ST_PASS1 = 4, ST_EX1 = 5, ST_PASS2 = 6, ST_EX2 = 7,
                ST_PASS3 = 8, ST_STORED = 10, ST_END = 11, ST_LANDED = 12, ST_ALL_LANDED = 13 };
@@ -443,7 +450,7 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
         if (!MULTI || frame == frame0)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PL::R) : "memory");
+            SDR_WAIT_ALL_BUT(PL::R);
         SDR_STAMP(st, ST_LANDED);  // this wave's rows have landed
         __syncthreads();
         SDR_STAMP(st, ST_ALL_LANDED);  // everybody's have
@@ -692,7 +699,7 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, 4) void k_fft_psd_b(const flo
         if (frame == frame0)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PL::R) : "memory");
+            SDR_WAIT_ALL_BUT(PL::R);
         SDR_STAMP(st, ST_LANDED);
         double xr[PL::R], xi[PL::R];
         {

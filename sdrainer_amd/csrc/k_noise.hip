@@ -92,10 +92,23 @@ __device__ __forceinline__ Shared &ring(int group)
 // whose workgroup can span more than one LDS, needs release/acquire fences here instead.  The chains are
 // checked bit for bit against the oracle on every GPU test run (tests/test_gpu_parity.py), which is what
 // would catch a violation.
+//
+// -DSDR_SAFE_FENCES builds the protocol the memory model does promise - a workgroup-scope fence wherever program order
+// is relied on, acquire loads and release stores on the flags - at the price described above.  That variant is built by
+// __graft_entry__.build() beside the product (libsdrainer_hip_safe_fences.so) and the GPU parity tests are run against
+// it too (tests/test_safe_fences.py): the fast protocol's dependence on the hardware is bounded by a build that does not
+// have it and gives the same bits.
+#if defined(SDR_SAFE_FENCES)
+__device__ __forceinline__ void lds_order() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
+__device__ __forceinline__ int lds_flag_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_flag_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#else
 __device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
 
 __device__ __forceinline__ int lds_flag_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_flag_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#endif
 
 // lane `src` (a compile-time constant after unrolling) -> wave-uniform SGPR value: v_readlane_b32, not the
 // LDS-crossbar ds_bpermute a generic __shfl lowers to
