@@ -1857,6 +1857,8 @@ int sdr_graph_capture(sdr_bank *b, int n_frames)
         return fail(SDR_ERR_STATE, "an earlier process call failed half way; destroy the bank");
     if (b->batch_index % RING != 0)
         return fail(SDR_ERR_STATE, "capture needs the bank at a multiple of sdr_graph_batches() processed batches");
+    if (b->listen_pending || b->defer_listen)
+        return fail(SDR_ERR_STATE, "graph mode and the deferred listen half exclude each other (sdr_process_listen / sdr_defer_listen(0) first)");
     if (!b->own_stream[S_NOISE])
         return fail(SDR_ERR_STATE, "graph mode needs the bank's own side streams (SDR_NO_OVERLAP is set)");
     int rc = sdr_graph_release(b);  // (also drains the pipeline)

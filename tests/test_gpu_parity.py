@@ -974,3 +974,79 @@ def test_listeners_bound_inside_a_batch(capi):
     assert sum(len(t) for t in text.values()) > 0
     bank.defer_listen(False)
     bank.close()
+
+
+@pytest.mark.parametrize("mode", ["graph", "eager"])
+def test_many_batches_with_an_erratic_consumer(capi, mode):
+    """Eleven replays of six batches (the four groups of buffer sets graph mode rotates through are each used three
+    times; eager: 66 batches over the six ring sets) while a consumer thread polls in fits and starts - so the producer
+    finds unpolled batches in the sets it wants back and either yields to the consumer or parks them (sdr_capi.hip
+    park_results).  Every batch must arrive once, in order, and be the oracle's, whichever way it went."""
+    import random
+    import threading
+    import time
+
+    import torch
+
+    n, rate, tones, per = 1024, 96000, 3, 70
+    edge = synth.default_edge_width(n)
+    bank = capi.Bank(rate, n, edge_width=edge, max_batch_frames=per, max_listeners=tones, max_peaks=128)
+    K = bank.graph_batches
+    replays = 11
+    frames = replays * K * per
+    iq, bins, _ = synth.make_band(frames, rate, n, tones, seed=4711)
+    ref = orc.Receiver(rate, n, edge, 15.0, 1, center_frequency=10100000)
+    bank.set_center_frequency(0, 10100000)
+    stream = torch.cuda.Stream()
+    bank.set_stream(stream.cuda_stream)
+    for b in bins:
+        assert bank.attach(0, int(b)) == ref.attach(int(b))
+    out = ref.process(iq)
+    bank.enable_results(True)
+    if mode == "graph":
+        bank.graph_capture(per)
+    dev = torch.from_numpy(iq).cuda()
+    torch.cuda.synchronize()
+    text = ["" for _ in range(tones)]
+    got, errors, stop = [], [], threading.Event()
+    rng = random.Random(5)
+
+    def consume():
+        try:
+            while True:
+                res = bank.poll(wait=rng.random() < 0.5)
+                if res is None:
+                    if stop.is_set() and bank.results_pending == 0:
+                        return
+                    time.sleep(rng.choice([0.0, 1e-4, 2e-3]))
+                    continue
+                a = int(res["batch_index"]) * per
+                got.append(int(res["batch_index"]))
+                _check_delivery(res, out, a, a + per, tones, text)
+                if rng.random() < 0.3:
+                    time.sleep(rng.choice([5e-4, 3e-3, 8e-3]))  # falls behind: the producer has to wait or park
+        except Exception as e:  # noqa: BLE001 - reported by the main thread
+            errors.append(e)
+
+    t = threading.Thread(target=consume)
+    t.start()
+    for rep in range(replays):
+        if mode == "graph":
+            bank.graph_launch([dev[(rep * K + k) * per].data_ptr() for k in range(K)])
+        else:
+            for k in range(K):
+                bank.process_device(dev[(rep * K + k) * per].data_ptr(), per)
+        if rep % 4 == 3:
+            time.sleep(2e-3)
+    bank.sync()
+    stop.set()
+    t.join(timeout=60)
+    assert not t.is_alive() and not errors, errors
+    assert got == list(range(replays * K))
+    for lid in range(tones):
+        assert text[lid] == ref.text(lid) and len(text[lid]) > 0
+        assert np.array_equal(bank.read_decoder_state(0, lid), ref.decoder_state(lid))
+    assert bank.read_drop_counters() == (0, 0)
+    if mode == "graph":
+        bank.graph_release()
+    bank.close()
