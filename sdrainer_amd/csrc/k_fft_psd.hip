@@ -331,7 +331,7 @@ __device__ __forceinline__ void store_psd(const double (&xr)[fft64::Plan<LOGN>::
     }
 }
 
-// Where the time of a frame goes (N = 16384, tools/fft_trace.hip with -DSDR_FFT_CLOCK and the -DSDR_ABLATE
+// Where the time of a frame goes (N = 16384, tools/fft_bench.hip with -DSDR_FFT_CLOCK and the -DSDR_ABLATE
 // builds, MI355X at 2.3 GHz in-kernel): the phases of a frame run one after the other on its CU - all 16 waves
 // wait for the input, then all compute, then all exchange, ... - and each phase is bound by a different unit, so
 // their times ADD: nothing of another frame can run beside them, a frame's float64 state is half the CU's

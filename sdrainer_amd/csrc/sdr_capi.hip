@@ -8,16 +8,22 @@
 // also the number of hardware queues HIP maps streams to by default; more streams alias and serialise):
 //
 //   fft     k_fft_psd(i)                                          (the caller's stream)
-//   noise   k_window_means(i) -> k_noise_stats(i) -> k_thresholds(i)
-//   listen  k_listen_gather(i) -> k_listen_decode(i)
-//   peaks   k_cumulate(i) -> k_find_peaks(i)
+//   noise   k_window_means(i) -> k_noise_stats(i)
+//   peaks   k_thresholds(i) -> k_cumulate(i) -> k_find_peaks(i) (-> k_pack_peaks(i))
+//   listen  k_listen_gather(i) -> k_listen_decode(i) (-> k_pack_listen(i))
 //
 // Batch i's per-batch buffers (psd, tap, frame records, keying bits, peaks ...) live in set i % RING, and one
 // event per kernel orders the stages across streams (kDefaultPlan, process_device_body): window means and
-// cumulate after the FFT; gather after thresholds; find_peaks after cumulate and thresholds; fft(i) after every
-// reader of set i % RING from batch i - RING.  State that is carried from frame to frame is only ever touched
-// by one kernel, whose stream keeps it in batch order.  Results are read after sdr_sync(), which drains every
-// stream.
+// cumulate after the FFT; thresholds after the noise statistics; gather after thresholds; find_peaks after cumulate
+// and thresholds; fft(i) after every reader of set i % RING from batch i - RING.  State that is carried from frame to
+// frame is only ever touched by one kernel, whose stream keeps it in batch order.  Results leave the device in bulk
+// (sdr_enable_results / sdr_poll: two pack kernels per batch into pinned host memory, no pipeline drain) or are read
+// after sdr_sync(), which drains every stream.
+//
+// Three more ways to drive the same body: graph mode (sdr_graph_*: six batches as kernel-only graphs, one per stream,
+// four replays in flight over buffer sets of their own), the deferred listen half (sdr_defer_listen ...: the spectral
+// stages of a batch first, listeners bound to frames inside it, then the listen stages) and the staged host input
+// (sdr_push_* / sdr_process_staged: three pinned staging sets, uploads on a copy stream).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -3,7 +3,7 @@
 # usage: tools/kernel_resources.sh sdrainer_amd/csrc/k_fft_psd.hip [extra flags]
 src=$1; shift
 F="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -DSDR_BUILD -Iinclude"
-case $src in *k_fft_psd*|*fft_trace*|*fft_bench*) F="$F -mllvm -disable-machine-licm";; esac
+case $src in *k_fft_psd*|*fft_bench*) F="$F -mllvm -disable-machine-licm";; esac
 /opt/rocm/bin/hipcc $F "$@" --cuda-device-only -Rpass-analysis=kernel-resource-usage -c $src -o /dev/null 2>&1 | python3 -c '
 import re,sys
 cur=None
