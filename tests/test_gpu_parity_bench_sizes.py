@@ -226,3 +226,65 @@ def test_graph_mode_at_config5_geometry(capi):
         bank.graph_launch([batches[0].data_ptr()] * K)
     assert ei.value.code == capi.ERR_STATE
     bank.close()
+
+
+def test_listeners_bound_inside_a_batch_at_config3_size(capi):
+    """The deferred listen half at config 3's geometry (N = 16384, a 2048-frame batch): twenty listeners bound one per
+    cumulation boundary INSIDE the batch (sdr_attach_at: gather from the retained psd rows, decoders starting mid-batch)
+    beside 64 that were there from the start, against the oracle run cumulation by cumulation with a plain attach at
+    every boundary (rx/receiver.go:404-426)."""
+    import torch
+
+    rate, n, frames = 2_000_000, 16384, 2048
+    early, late = 64, 20
+    edge = synth.default_edge_width(n)
+    iq, bins, _ = synth.make_band_torch(frames, rate, n, early + late, seed=3300, device="cuda", free_last_window=True)
+    host = iq.cpu().numpy()
+    ref = orc.Receiver(rate, n, edge, 15.0, 1, center_frequency=14000000)
+    for b in bins[:early]:
+        ref.attach(int(b))
+    starts = {}
+    outs, pos = [], 0
+    for j in range(late):
+        boundary = 100 * (j + 1)
+        outs.append((pos, ref.process(host[pos:boundary])))
+        pos = boundary
+        starts[ref.attach(int(bins[early + j]))] = boundary
+    outs.append((pos, ref.process(host[pos:])))
+
+    bank = capi.Bank(rate, n, edge_width=edge, max_batch_frames=frames, max_listeners=early + late, max_peaks=1024)
+    bank.set_stream(torch.cuda.current_stream().cuda_stream)
+    bank.set_center_frequency(0, 14000000)
+    for i, b in enumerate(bins[:early]):
+        assert bank.attach(0, int(b)) == i
+    bank.enable_results(True)
+    bank.defer_listen(True)
+    bank.process_device(iq.data_ptr(), frames)
+    pk = bank.poll_peaks(wait=True)
+    assert [int(c["frame"]) for c in pk["chunks"]] == list(range(99, frames, 100))
+    for lid, s in sorted(starts.items()):
+        assert bank.attach_at(0, int(bins[lid]), s) == lid
+    bank.process_listen()
+    res = bank.poll(wait=True)
+    assert res["n_frames"] == frames and res["runes_dropped"] == 0 and res["edges_dropped"] == 0
+    by = {int(r["listener"]): r for r in res["listeners"]}
+    n_edges = 0
+    for lid in range(early + late):
+        s = starts.get(lid, 0)
+        want, last = [], 0
+        for base, out in outs:
+            if out["deb"].shape[1] <= lid or base + out["deb"].shape[0] <= s:
+                continue
+            deb = out["deb"][:, lid].astype(np.int8)
+            idx = np.flatnonzero(np.diff(np.concatenate([[last], deb])) != 0)
+            want += [(base + int(i), int(deb[i])) for i in idx if base + i >= s]
+            last = int(deb[-1])
+        r = by.get(lid)
+        got = [] if r is None else [(int(x["frame"]), int(x["state"])) for x in res["edges"][r["first_edge"]:r["first_edge"] + r["n_edges"]]]
+        assert got == want, f"listener {lid} (from frame {s})"
+        text = "" if r is None else "".join(chr(int(x)) for x in res["runes"][r["first_rune"]:r["first_rune"] + r["n_runes"]])
+        assert text == ref.text(lid), f"listener {lid} text"
+        assert np.array_equal(bank.read_decoder_state(0, lid), ref.decoder_state(lid)), f"listener {lid} state"
+        n_edges += len(got)
+    assert n_edges > 20 * early
+    bank.close()

@@ -292,6 +292,33 @@ def test_strain_mode_long_segments_decide_like_one_cumulation_at_a_time(exe, tmp
 
 
 @pytest.mark.gpu
+def test_strain_mode_discovery_ahead_at_wideband_geometry(exe, tmp_path):
+    """The same two receivers - decisions made ahead over long segments, and one cumulation per host round trip - at a
+    wideband geometry (2 MS/s, N = 16384, a pool of 24 filled strongest-first from 40 carriers, 2048-frame segments):
+    same listeners on the same peaks at the same frames, same text, same callsign events."""
+    from sdrainer_amd import synth
+
+    rate, n, pool, tones, frames = 2_000_000, 16384, 24, 40, 2900
+    iq, bins, _ = synth.make_band(frames, rate, n, tones, seed=612, free_last_window=True)
+    path = tmp_path / "iq.f32"
+    iq.astype(np.float32).tofile(path)
+    cmd = [exe, "strain", str(path), str(rate), str(n), str(frames), str(pool), "strongest", "1e9", "1e9", "2048", "2048"]
+    ahead = subprocess.run(cmd, capture_output=True, text=True)
+    assert ahead.returncode == 0, ahead.stdout[-2000:] + ahead.stderr[-2000:]
+    one = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, SDR_RX_NO_SPECULATION="1"))
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
+    got, ref = json.loads(ahead.stdout), json.loads(one.stdout)
+    assert got["frames"] == frames and len(got["listeners"]) == pool
+    assert got["events"] == ref["events"] and got["event_frames"] == ref["event_frames"]
+    assert len(got["events"]) == pool and all(f % 100 == 0 for f in got["event_frames"])  # bound at cumulation boundaries
+    assert got["event_frames"][-1] <= 100 * (pool + 3)  # about one listener per cumulation
+    assert got["listeners"] == ref["listeners"]
+    assert sum(len(l["text"]) for l in got["listeners"]) > 0
+    for lid in {c.split(" ")[0] for c in ref["callsigns"]}:
+        assert [c for c in got["callsigns"] if c.startswith(lid + " ")] == [c for c in ref["callsigns"] if c.startswith(lid + " ")]
+
+
+@pytest.mark.gpu
 def test_decode_mode_vfo_listener(exe, tmp_path):
     """DecodeMode (rx/receiver.go:272-297): SetVFOOffset forces a peak at the VFO frequency, the receiver's single
     listener decodes it; retuning resets the pool of one and a fresh listener takes over.  No peak scan runs."""
