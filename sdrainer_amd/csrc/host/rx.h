@@ -445,6 +445,9 @@ public:
         for (auto &t : threads_)
             t.join();
     }
+    // fn(0) .. fn(n - 1), each once, on the pool's threads and the caller's; returns when all are done.  The items are
+    // short (a listener's runes of one segment: a microsecond or two), so they are handed out a few at a time from an
+    // atomic counter - a mutex round trip per item cost more than the items.
     void Run(size_t n, const std::function<void(size_t)> &fn)
     {
         if (n == 0)
@@ -453,33 +456,51 @@ public:
             std::lock_guard<std::mutex> g(m_);
             fn_ = &fn;
             n_ = n;
-            next_ = 0;
-            done_ = 0;
+            next_.store(0, std::memory_order_relaxed);
+            done_.store(0, std::memory_order_relaxed);
             generation_++;
         }
         cv_.notify_all();
         work();
-        std::unique_lock<std::mutex> g(m_);
-        done_cv_.wait(g, [&] { return done_ == n_; });
-        fn_ = nullptr;
+        // (the others finish within microseconds of the caller; a thread that joined this run has left it again
+        // before the function and the counters may be reused)
+        for (;;) {
+            if (done_.load(std::memory_order_acquire) >= n) {
+                std::lock_guard<std::mutex> g(m_);
+                if (active_ == 0) {
+                    fn_ = nullptr;
+                    return;
+                }
+            }
+            std::this_thread::yield();
+        }
     }
 
 private:
+    static constexpr size_t kChunk = 4;
     void work()
     {
-        for (;;) {
-            size_t i;
-            {
-                std::lock_guard<std::mutex> g(m_);
-                if (!fn_ || next_ >= n_)
-                    return;
-                i = next_++;
-            }
-            (*fn_)(i);
+        const std::function<void(size_t)> *fn;
+        size_t n;
+        {
             std::lock_guard<std::mutex> g(m_);
-            if (++done_ == n_)
-                done_cv_.notify_all();
+            if (!fn_)
+                return;  // (woken after the run it was woken for had finished)
+            fn = fn_;
+            n = n_;
+            active_++;
         }
+        for (;;) {
+            const size_t i0 = next_.fetch_add(kChunk, std::memory_order_relaxed);
+            if (i0 >= n)
+                break;
+            const size_t i1 = std::min(n, i0 + kChunk);
+            for (size_t i = i0; i < i1; i++)
+                (*fn)(i);
+            done_.fetch_add(i1 - i0, std::memory_order_release);
+        }
+        std::lock_guard<std::mutex> g(m_);
+        active_--;
     }
     void loop()
     {
@@ -497,9 +518,11 @@ private:
     }
     std::vector<std::thread> threads_;
     std::mutex m_;
-    std::condition_variable cv_, done_cv_;
+    std::condition_variable cv_;
     const std::function<void(size_t)> *fn_ = nullptr;
-    size_t n_ = 0, next_ = 0, done_ = 0;
+    size_t n_ = 0;
+    std::atomic<size_t> next_{0}, done_{0};
+    int active_ = 0;
     uint64_t generation_ = 0;
     bool stop_ = false;
 };
@@ -722,6 +745,9 @@ public:
     int64_t FramesProcessed() const { return reportFrames_ >= 0 ? reportFrames_ : framesProcessed_; }
     // seconds spent in discoverAhead so far: waiting for the peaks, deciding + binding, enqueueing the listen half
     const double *AheadTiming() const { return aheadTiming_; }
+    // seconds spent resolving segments so far: in sdr_poll (waiting for the device included), feeding the text
+    // processors, replaying their reporter events
+    const double *SegmentTiming() const { return segmentTiming_; }
     const std::vector<Peak> &LastPeaks() const { return lastPeaks_; }
 
     // :474-500 (peakPadding = 0: a found run is re-centred to its strongest bin)
@@ -959,9 +985,11 @@ private:
     int afterSegment(int64_t segment_end, bool end_decided)
     {
         sdr_results r = pollBuffers();
+        const auto ts0 = std::chrono::steady_clock::now();
         const int rc = sdr_poll(bank_, &r, 1);
         if (rc != SDR_OK)
             return rc;
+        const auto ts1 = std::chrono::steady_clock::now();
         // runes -> the listeners' text processors, each Write stamped with the time of its frame.  A listener's text
         // processor is independent of every other's (in the reference each runs in a goroutine of its own,
         // rx/text_processor.go:161-171), so listeners are fed in parallel; the reporter calls this triggers are
@@ -997,8 +1025,13 @@ private:
             for (size_t w = 0; w < work.size(); w++)
                 feed(w);
         }
+        const auto ts2 = std::chrono::steady_clock::now();
         for (auto &w : work)
             w.first->FlushEvents();
+        const auto ts3 = std::chrono::steady_clock::now();
+        segmentTiming_[0] += std::chrono::duration<double>(ts1 - ts0).count();
+        segmentTiming_[1] += std::chrono::duration<double>(ts2 - ts1).count();
+        segmentTiming_[2] += std::chrono::duration<double>(ts3 - ts2).count();
         // (segments behind this one may already have moved the clock on: discoverAhead.  It only ever runs forward -
         // what is evaluated here, time-outs and the once-a-second clean-up, then sees the later time, as it would a
         // moment later anyway; no listener bound ahead can have timed out by then: segmentLimit)
@@ -1079,7 +1112,7 @@ private:
     PeaksTable::Policy policy_ = PeaksTable::ReferenceOrder;
     ListenerPool listeners_;
     int64_t framesProcessed_ = 0, reportFrames_ = -1;
-    double aheadTiming_[3] = {0, 0, 0};
+    double aheadTiming_[3] = {0, 0, 0}, segmentTiming_[3] = {0, 0, 0};
     int maxBatchFrames_ = 256;
     bool segExpiryAtEnd_ = false;
     bool speculative_ = false;  // the segment being cut is processed spectra first, decisions next, listeners last

@@ -36,6 +36,78 @@ inline const std::regex &callsignExp()  // :23-25
     return re;
 }
 
+// callsignExp as straight-line code: the leftmost match in the order a backtracking matcher (Go's regexp for this
+// pattern, std::regex ECMAScript) finds it - first whitespace position from which the pattern matches; the prefix
+// "xx/" tried before no prefix; the four shapes of the call's head in the order they are written; the greedy body
+// backed off to its last letter; then, nothing mandatory being left, each optional suffix taken greedily.  std::regex
+// needs a microsecond or two per 20-character window and runs once per decoded rune per listener (6 000 times per
+// 2048-frame batch at 256 listeners): it was what bounded the end-to-end rate with a full pool.  Checked against
+// callsignExp itself on millions of random windows (tests/host/test_rx_host.cpp "cpu").
+inline bool CallsignSearch(const char *s, int n, int *pos, int *len)
+{
+    auto space = [](char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r'; };
+    auto letter = [](char c) { return c >= 'a' && c <= 'z'; };
+    auto digit = [](char c) { return c >= '0' && c <= '9'; };
+    auto alnum = [&](char c) { return letter(c) || digit(c); };
+    auto at = [&](int i) { return i < n ? s[i] : '\0'; };
+    auto run = [&](int i) {  // length of the [a-z0-9] run starting at i
+        int k = 0;
+        while (i + k < n && alnum(s[i + k]))
+            k++;
+        return k;
+    };
+    // (([a-z]|[a-z][a-z]|[0-9][a-z]|[0-9][a-z][a-z])[0-9][a-z0-9]*[a-z]) then the optional suffixes; returns the end or -1
+    auto call_from = [&](int q) -> int {
+        for (int alt = 0; alt < 4; alt++) {
+            int h;  // end of the head
+            if (alt == 0 && letter(at(q)))
+                h = q + 1;
+            else if (alt == 1 && letter(at(q)) && letter(at(q + 1)))
+                h = q + 2;
+            else if (alt == 2 && digit(at(q)) && letter(at(q + 1)))
+                h = q + 2;
+            else if (alt == 3 && digit(at(q)) && letter(at(q + 1)) && letter(at(q + 2)))
+                h = q + 3;
+            else
+                continue;
+            if (!digit(at(h)))
+                continue;
+            const int body = h + 1, m = run(body);
+            for (int k = m; k >= 0; k--) {  // [a-z0-9]* greedy, backed off until a letter follows
+                if (!letter(at(body + k)))
+                    continue;
+                int e = body + k + 1;
+                if (at(e) == '/') {  // (?:/([a-z0-9]+))?
+                    const int r = run(e + 1);
+                    if (r > 0) {
+                        e += 1 + r;
+                        if (at(e) == '/' && (at(e + 1) == 'p' || at(e + 1) == 'a' || at(e + 1) == 'm'))  // (?:/(p|a|m|mm|am))?
+                            e += 2;
+                    }
+                }
+                return e;
+            }
+        }
+        return -1;
+    };
+    for (int i = 0; i < n; i++) {
+        if (!space(s[i]))
+            continue;
+        const int p = i + 1, r = run(p);
+        int e = -1;
+        if (r > 0 && at(p + r) == '/')  // (?:([a-z0-9]+)/)?  - only the whole run can be followed by the slash
+            e = call_from(p + r + 1);
+        if (e < 0)
+            e = call_from(p);
+        if (e >= 0) {
+            *pos = i;
+            *len = e - i;
+            return true;
+        }
+    }
+    return false;
+}
+
 class TextWindow {  // :326-415
 public:
     explicit TextWindow(int windowSize) : windowSize_(windowSize) {}
@@ -85,6 +157,23 @@ public:
         *out = m.str(0);
         return true;
     }
+    // FindNext(callsignExp(), ...) without the regex machinery
+    bool FindNextCallsign(bool includeTail, std::string *out)
+    {
+        const std::string &cur = window_[current_];
+        if (searchPoint_ >= (int)cur.size())
+            return false;
+        const int n = (int)cur.size() - searchPoint_;
+        int pos = 0, len = 0;
+        if (!CallsignSearch(cur.data() + searchPoint_, n, &pos, &len))
+            return false;
+        const int end = pos + len;
+        if (!includeTail && end >= n)
+            return false;
+        out->assign(cur, (size_t)(searchPoint_ + pos), (size_t)len);
+        searchPoint_ += end;
+        return true;
+    }
     int CurrentWindow() const { return current_; }
     int SearchPoint() const { return searchPoint_; }
     void Preset(const std::string &s) { window_[current_] = s; }  // tests only
@@ -96,27 +185,86 @@ private:
     int searchPoint_ = 0;
 };
 
-// hamradio/callsign.Parse + Callsign.String(): PREFIX/BASE/SUFFIX/WORKING_CONDITION, upper case
-inline bool ParseCallsign(const std::string &s, std::string *canonical)
+// hamradio/callsign.Parse + Callsign.String(): PREFIX/BASE/SUFFIX/WORKING_CONDITION, upper case.  The syntax as a
+// regular expression (kept: the straight-line matcher below is checked against it, tests/host/test_rx_host.cpp "cpu"):
+inline const std::regex &callsignSyntax()
 {
     static const std::regex re(
         R"(^(?:([A-Z0-9]+)/)?((?:[A-Z]|[A-Z][A-Z]|[0-9][A-Z]|[0-9][A-Z][A-Z])[0-9][A-Z0-9]*[A-Z])(?:/([A-Z0-9]+))?(?:/(P|A|M|MM|AM))?$)",
         std::regex::ECMAScript);
+    return re;
+}
+
+// Does the whole (upper-case) string have that syntax?  An anchored match may take ANY way through the pattern, so
+// every end of the call's body is tried, not only the greedy one.  Callsign.String() joins the parts it parsed with
+// slashes again: for a string that matches, the canonical form is the string itself.
+inline bool CallsignSyntaxOK(const std::string &up)
+{
+    const char *s = up.data();
+    const int n = (int)up.size();
+    auto letter = [](char c) { return c >= 'A' && c <= 'Z'; };
+    auto digit = [](char c) { return c >= '0' && c <= '9'; };
+    auto alnum = [&](char c) { return letter(c) || digit(c); };
+    auto at = [&](int i) { return i < n ? s[i] : '\0'; };
+    auto run = [&](int i) {
+        int k = 0;
+        while (i + k < n && alnum(s[i + k]))
+            k++;
+        return k;
+    };
+    // what may follow the call: nothing, "/X+", "/X+/WC" (a lone "/WC" is a "/X+")
+    auto tail_ok = [&](int e) {
+        if (e == n)
+            return true;
+        if (at(e) != '/')
+            return false;
+        const int r = run(e + 1);
+        if (r == 0)
+            return false;
+        const int f = e + 1 + r;
+        if (f == n)
+            return true;
+        if (at(f) != '/')
+            return false;
+        const std::string wc = up.substr((size_t)f + 1);
+        return wc == "P" || wc == "A" || wc == "M" || wc == "MM" || wc == "AM";
+    };
+    auto call_from = [&](int q) {
+        for (int alt = 0; alt < 4; alt++) {
+            int h;
+            if (alt == 0 && letter(at(q)))
+                h = q + 1;
+            else if (alt == 1 && letter(at(q)) && letter(at(q + 1)))
+                h = q + 2;
+            else if (alt == 2 && digit(at(q)) && letter(at(q + 1)))
+                h = q + 2;
+            else if (alt == 3 && digit(at(q)) && letter(at(q + 1)) && letter(at(q + 2)))
+                h = q + 3;
+            else
+                continue;
+            if (!digit(at(h)))
+                continue;
+            const int body = h + 1, m = run(body);
+            for (int k = m; k >= 0; k--)
+                if (letter(at(body + k)) && tail_ok(body + k + 1))
+                    return true;
+        }
+        return false;
+    };
+    const int r = run(0);
+    if (r > 0 && at(r) == '/' && call_from(r + 1))
+        return true;
+    return call_from(0);
+}
+
+inline bool ParseCallsign(const std::string &s, std::string *canonical)
+{
     std::string up;
     for (char c : s)
         up.push_back((char)std::toupper((unsigned char)c));
-    std::smatch m;
-    if (!std::regex_match(up, m, re))
+    if (!CallsignSyntaxOK(up))
         return false;
-    std::string out;
-    if (m[1].matched)
-        out += m[1].str() + "/";
-    out += m[2].str();
-    if (m[3].matched)
-        out += "/" + m[3].str();
-    if (m[4].matched)
-        out += "/" + m[4].str();
-    *canonical = out;
+    *canonical = up;
     return true;
 }
 
@@ -153,7 +301,7 @@ public:
     void WriteTimeout()  // :195-200
     {
         std::string candidate;
-        if (window_.FindNext(callsignExp(), true, &candidate))
+        if (window_.FindNextCallsign(true, &candidate))
             collectCallsign(candidate);
     }
     void Write(const std::string &bytes)  // :202-216 + findNextCallsign :218-242
@@ -165,7 +313,7 @@ public:
             if (n < 0)
                 break;  // the reference panics here; cannot happen because a full window is shifted below
             std::string candidate;
-            if (window_.FindNext(callsignExp(), false, &candidate))
+            if (window_.FindNextCallsign(false, &candidate))
                 collectCallsign(candidate);
             if (n <= (int)rest.size())
                 rest = rest.substr((size_t)n);

@@ -462,6 +462,103 @@ static void TestTextProcessor_WriteTimeout()  // :164-179
 // `test_rx_host text`: replay a script from stdin through a TextProcessor and print its reporter
 // events, one per line.  Script lines: "W <text>" (written rune by rune), "B <text>" (one Write),
 // "A <seconds>" (advance the clock, then CheckWriteTimeout as the receiver's ticker does), "R" (Restart).
+// CallsignSearch (straight-line code) against callsignExp (std::regex) on random windows: same answer - found or not,
+// where, how long - for every one of them, and the two FindNext variants walk a window identically.  argv: how many.
+static void TestCallsignSearchAgainstTheRegex(long count)
+{
+    // mostly the decoder's alphabet, weighted towards what makes and breaks call signs; some bytes the regex must skip
+    static const char alphabet[] = "aaabcdklmpmmz001299  //  \t-.?\xc3\xa4\xc2\xa6\n";
+    const int na = (int)sizeof(alphabet) - 1;
+    unsigned long long x = 88172645463325252ull;
+    auto rnd = [&] {
+        x ^= x << 13;
+        x ^= x >> 7;
+        x ^= x << 17;
+        return x;
+    };
+    const std::regex &re = rx::callsignExp();
+    long found = 0;
+    for (long it = 0; it < count; it++) {
+        const int n = (int)(rnd() % 25);
+        std::string w;
+        for (int i = 0; i < n; i++)
+            w.push_back(alphabet[rnd() % na]);
+        if (it % 3 == 0 && n > 8) {  // plant something call-shaped
+            static const char *seeds[] = {" dl1abc", " 9a1aa/p", " ea8/dl1abc/mm", " w1aw ", " 1a2b/am", " k1a/7 ", " 2e0abc/m"};
+            const char *sd = seeds[rnd() % 7];
+            w.replace(rnd() % (unsigned)(n - 7), std::min<size_t>(strlen(sd), 7), sd);
+        }
+        std::smatch m;
+        const bool a = std::regex_search(w, m, re);
+        int pos = -1, len = -1;
+        const bool b = rx::CallsignSearch(w.data(), (int)w.size(), &pos, &len);
+        if (a != b || (a && (m.position(0) != pos || m.length(0) != len))) {
+            failures++;
+            fprintf(stderr, "CallsignSearch differs from callsignExp on \"%s\": regex %d (%ld, %ld), code %d (%d, %d)\n", w.c_str(), (int)a,
+                    a ? (long)m.position(0) : -1L, a ? (long)m.length(0) : -1L, (int)b, pos, len);
+            if (failures > 10)
+                return;
+        }
+        found += a;
+        // the two FindNext variants on the same window, call after call
+        rx::TextWindow w1(24), w2(24);
+        w1.Preset(w);
+        w2.Preset(w);
+        for (int k = 0; k < 4; k++) {
+            std::string o1, o2;
+            const bool tail = (k & 1) != 0;
+            const bool f1 = w1.FindNext(re, tail, &o1), f2 = w2.FindNextCallsign(tail, &o2);
+            if (f1 != f2 || o1 != o2 || w1.SearchPoint() != w2.SearchPoint()) {
+                failures++;
+                fprintf(stderr, "FindNextCallsign differs from FindNext on \"%s\" (call %d)\n", w.c_str(), k);
+                break;
+            }
+        }
+    }
+    CHECK(found > count / 20);  // (the generator does produce matches)
+
+    // callsign.Parse's syntax: the straight-line check against the anchored regex, and the canonical form against the
+    // parts the regex captures, joined by slashes
+    static const char up_alphabet[] = "AABDKLMMPZ00129//";
+    const int nu = (int)sizeof(up_alphabet) - 1;
+    long ok = 0;
+    for (long it = 0; it < count; it++) {
+        const int n = 1 + (int)(rnd() % 14);
+        std::string w;
+        for (int i = 0; i < n; i++)
+            w.push_back(up_alphabet[rnd() % nu]);
+        if (it % 4 == 0) {
+            static const char *seeds[] = {"DL1ABC", "9A1AA/P", "EA8/DL1ABC/MM", "W1AW", "1A2B/AM", "K1A/7", "2E0ABC/M", "F/DL1ABC/P", "DL1ABC/P/M", "M/1A2B/A"};
+            w = seeds[rnd() % 10];
+            if (rnd() % 3 == 0)
+                w[rnd() % w.size()] = up_alphabet[rnd() % nu];
+        }
+        std::smatch m;
+        const bool a = std::regex_match(w, m, rx::callsignSyntax());
+        std::string canon;
+        const bool b = rx::ParseCallsign(w, &canon);
+        std::string want;
+        if (a) {
+            if (m[1].matched)
+                want += m[1].str() + "/";
+            want += m[2].str();
+            if (m[3].matched)
+                want += "/" + m[3].str();
+            if (m[4].matched)
+                want += "/" + m[4].str();
+        }
+        if (a != b || (a && canon != want)) {
+            failures++;
+            fprintf(stderr, "ParseCallsign differs from the syntax regex on \"%s\": regex %d \"%s\", code %d \"%s\"\n", w.c_str(), (int)a, want.c_str(), (int)b,
+                    canon.c_str());
+            if (failures > 10)
+                return;
+        }
+        ok += a;
+    }
+    CHECK(ok > count / 50);
+}
+
 static int run_text()
 {
     struct Printer : rx::CallsignReporter {
@@ -517,6 +614,7 @@ int main(int argc, char **argv)
         TestTextWindow_FindNext_IncludeTail();
         TestTextProcessor_CollectCallsign();
         TestTextProcessor_WriteTimeout();
+        TestCallsignSearchAgainstTheRegex(argc >= 3 ? atol(argv[2]) : 200000);
         printf("%s\n", failures ? "FAILED" : "ok");
         return failures ? 1 : 0;
     }

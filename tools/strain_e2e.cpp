@@ -70,6 +70,8 @@ extern "C" int strain_e2e(const float *iq_dev, int frames, int rate, int n, int 
         return rc;
     sdr_sync(r.Bank());
     double t2 = now_s();
+    fprintf(stderr, "pool full: %.2f ms in all; resolving segments: %.2f ms in sdr_poll (waiting for the device included), %.2f ms feeding the text processors, %.2f ms replaying their events\n",
+            (t2 - t1) * 1e3, r.SegmentTiming()[0] * 1e3, r.SegmentTiming()[1] * 1e3, r.SegmentTiming()[2] * 1e3);
     long runes = 0;
     for (auto &l : r.Listeners().Listeners())
         runes += (long)l->Text().size();
