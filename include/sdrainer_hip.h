@@ -36,7 +36,7 @@
  *                                   hearing the next frame - without one host round trip per cumulation
  *                                                                               rx/receiver.go:404-426
  *   sdr_scope_*                     scope.Scope.ShowSpectralFrame / ShowTimeFrame  scope/scope.go:14-37,
- *                                   call sites rx/receiver.go:428-457, cw/spectral.go:56-81
+ *                                   call sites rx/receiver.go:428-457, cw/spectral.go:56-81, cw/decode.go:228-243
  *
  * Semantics kept from the reference: setters take effect between frames, never mid-frame (here: at
  * the next process call, rx/receiver.go:166-172); wrong sample rate / block size / a full queue do
@@ -314,6 +314,19 @@ int sdr_scope_active(sdr_bank *bank);
 int sdr_scope_read_spectral(sdr_bank *bank, int band, int chunk, sdr_scope_spectral_frame *frame, double *values, int max_values);
 /* The listener's "demod" time frames of the last batch, one per frame. */
 int sdr_scope_read_demod(sdr_bank *bank, int band, int listener_id, sdr_scope_time_frame *out, int max, int *n_out);
+/* cw.Decoder's scope streams (cw/decode.go:228-243, :433-491) for the last batch, one record per tick the listener
+ * took: scopeDecode {duration, on_threshold, state}, scopeSignalTiming {on_duration = state ? duration : 0, on_threshold,
+ * _low, _high, 2 x _high, state}, scopeGapTiming {off_duration = state ? 0 : duration, off_threshold, _low, _high,
+ * 2 x _high - threshold, state}, scopeSignal {state}: every channel is one of these fields or a sum of two.  *n_out: the
+ * number of ticks (a listener bound inside the batch has fewer than the batch has frames).  trace == 1 only. */
+typedef struct sdr_scope_decode_frame {
+    int64_t frame;     /* bank frame index of the tick */
+    double duration;   /* currentDuration: ticks since the last edge */
+    double state;      /* 0 / 1 */
+    double on_threshold, on_threshold_low, on_threshold_high;
+    double off_threshold, off_threshold_low, off_threshold_high;
+} sdr_scope_decode_frame;
+int sdr_scope_read_decode(sdr_bank *bank, int band, int listener_id, sdr_scope_decode_frame *out, int max, int *n_out);
 
 /* measurement ------------------------------------------------------------------------------- */
 /* When enabled every kernel launch is bracketed by HIP events on the bank's stream. */

@@ -65,6 +65,9 @@ class ScopeSpectralFrame(C.Structure):
 
 
 SCOPE_TIME_DTYPE = np.dtype([("threshold", "<f8"), ("value", "<f8"), ("state", "<f8"), ("debounced", "<f8")])
+SCOPE_DECODE_DTYPE = np.dtype([("frame", "<i8"), ("duration", "<f8"), ("state", "<f8"), ("on_threshold", "<f8"),
+                               ("on_threshold_low", "<f8"), ("on_threshold_high", "<f8"), ("off_threshold", "<f8"),
+                               ("off_threshold_low", "<f8"), ("off_threshold_high", "<f8")])
 
 
 class Results(C.Structure):
@@ -88,7 +91,7 @@ SYMBOLS = (
     "sdr_set_peak_threshold sdr_set_edge_width sdr_set_signal_debounce sdr_set_center_frequency sdr_set_find_peaks "
     "sdr_last_batch_frames sdr_total_frames sdr_last_batch_chunks sdr_read_peaks sdr_read_cumulation sdr_read_text "
     "sdr_read_edges sdr_read_keying_bits sdr_read_frame_records sdr_read_trace sdr_read_spectrum "
-    "sdr_read_decoder_state sdr_graph_batches sdr_graph_capture sdr_graph_launch sdr_graph_release sdr_scope_active sdr_scope_read_spectral sdr_scope_read_demod sdr_enable_results sdr_poll sdr_defer_listen sdr_listen_pending sdr_poll_peaks sdr_attach_at sdr_process_listen sdr_results_pending sdr_read_drop_counters sdr_profile_enable sdr_profile_read sdr_profile_reset sdr_kernel_name sdr_audio_create "
+    "sdr_read_decoder_state sdr_graph_batches sdr_graph_capture sdr_graph_launch sdr_graph_release sdr_scope_active sdr_scope_read_spectral sdr_scope_read_demod sdr_scope_read_decode sdr_enable_results sdr_poll sdr_defer_listen sdr_listen_pending sdr_poll_peaks sdr_attach_at sdr_process_listen sdr_results_pending sdr_read_drop_counters sdr_profile_enable sdr_profile_read sdr_profile_reset sdr_kernel_name sdr_audio_create "
     "sdr_audio_destroy sdr_audio_blocksize sdr_audio_set_scale sdr_audio_set_debounce "
     "sdr_audio_set_magnitude_threshold sdr_audio_write sdr_audio_close sdr_audio_read_text sdr_audio_read_trace"
 ).split()
@@ -160,6 +163,7 @@ def load():
     sig("sdr_scope_active", C.c_int, vp)
     sig("sdr_scope_read_spectral", C.c_int, vp, C.c_int, C.c_int, C.POINTER(ScopeSpectralFrame), C.POINTER(C.c_double), C.c_int)
     sig("sdr_scope_read_demod", C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, ip)
+    sig("sdr_scope_read_decode", C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, ip)
     sig("sdr_enable_results", C.c_int, vp, C.c_int)
     sig("sdr_poll", C.c_int, vp, C.POINTER(Results), C.c_int)
     sig("sdr_defer_listen", C.c_int, vp, C.c_int)
@@ -427,6 +431,14 @@ class Bank:
         out = np.zeros(max(nf, 1), SCOPE_TIME_DTYPE)
         n = C.c_int()
         _check(self._L.sdr_scope_read_demod(self._h, band, lid, _vp(out), nf, C.byref(n)))
+        return out[:min(nf, n.value)]
+
+    def scope_decode_frames(self, band: int, lid: int) -> np.ndarray:
+        """cw.Decoder's scope streams of the last batch (sdr_scope_decode_frame), one record per tick the listener took."""
+        nf = self.last_batch_frames
+        out = np.zeros(max(nf, 1), SCOPE_DECODE_DTYPE)
+        n = C.c_int()
+        _check(self._L.sdr_scope_read_decode(self._h, band, lid, _vp(out), nf, C.byref(n)))
         return out[:min(nf, n.value)]
 
     # bulk delivery ----------------------------------------------------------------------------

@@ -118,6 +118,7 @@ struct BatchSet {
     DevBuf<uint32_t> edge_counts;     // [band][L] edges produced by this batch
     DevBuf<float> tr_values;          // [band][max_batch][L] (trace only)
     DevBuf<uint8_t> tr_raw, tr_deb;
+    DevBuf<sdr::ListenerSlot> slots_before;  // [band][L] the slots as the batch's decoders found them (trace only: sdr_scope_read_decode)
     DevBuf<float> cum_out;            // [band][max_chunks][N]
     DevBuf<sdr::DevPeak> dev_peaks;   // [band][max_chunks][max_peaks]
     DevBuf<int> peak_counts;          // [band][max_chunks]
@@ -148,6 +149,7 @@ struct BatchSet {
         tr_values.release();
         tr_raw.release();
         tr_deb.release();
+        slots_before.release();
         cum_out.release();
         dev_peaks.release();
         peak_counts.release();
@@ -769,6 +771,9 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     }
     SDR_DONE(sdr::K_LISTEN_GATHER);
     SDR_AFTER(sdr::K_LISTEN_DECODE, sdr::K_LISTEN_GATHER);
+    if (c.trace && max_slots > 0 && SDR_ON(sdr::K_LISTEN_DECODE))  // the decoders' state before this batch: the decoder scope replays from it
+        HIP_TRY(hipMemcpyAsync(S.slots_before.p, b->slots.p, sizeof(sdr::ListenerSlot) * (size_t)B * (size_t)c.max_listeners,
+                               hipMemcpyDeviceToDevice, stream_of(sdr::K_LISTEN_DECODE)));
     if (!b->results_on)
         SDR_ARM(sdr::K_LISTEN_DECODE);
     if (max_slots > 0) {
@@ -934,6 +939,7 @@ static hipError_t alloc_set(sdr_bank *b, BatchSet &S)
         SET_ALLOC(S.tr_values, B * F * L);
         SET_ALLOC(S.tr_raw, B * F * L);
         SET_ALLOC(S.tr_deb, B * F * L);
+        SET_ALLOC(S.slots_before, B * L);
     }
     SET_ALLOC(S.cum_out, B * (size_t)b->max_chunks * N);
     SET_ALLOC(S.dev_peaks, B * (size_t)b->max_chunks * (size_t)c.max_peaks);
@@ -2179,6 +2185,64 @@ int sdr_scope_read_demod(sdr_bank *b, int band, int lid, sdr_scope_time_frame *o
         out[i].state = raw[i] ? 100.0 : -1.0;      // cw/spectral.go:61-64
         out[i].debounced = deb[i] ? 80.0 : -1.0;   // cw/spectral.go:65-68
     }
+    return SDR_OK;
+}
+
+// cw.Decoder's scope streams (cw/decode.go:228-243 and :433-491): per tick, what scopeDecode / scopeSignalTiming /
+// scopeGapTiming / scopeSignal show - the current run's duration, both adaptive thresholds with their low and high, the
+// state.  The decoders run on the device in closed form between edges and keep none of this per tick; it is replayed
+// here, on the host, tick by tick with the literal Tick (cw_decoder.h decoder_tick, the function the device's run-length
+// form is checked against), from the decoder's state before the batch and the batch's debounced keying.
+int sdr_scope_read_decode(sdr_bank *b, int band, int lid, sdr_scope_decode_frame *out, int max, int *n_out)
+{
+    int rc = check_listener(b, band, lid);
+    if (rc)
+        return rc;
+    if (!b->cfg.trace)
+        return fail(SDR_ERR_STATE, "scope inactive: the bank was created without trace");
+    if (n_out)
+        *n_out = 0;
+    const int frames = b->last_frames;
+    if (frames <= 0)
+        return SDR_OK;
+    std::vector<uint8_t> deb((size_t)frames);
+    rc = sdr_read_trace(b, band, lid, nullptr, nullptr, deb.data(), frames);  // synchronises
+    if (rc)
+        return rc;
+    const BatchSet &S = b->set[b->last_set];
+    sdr::ListenerSlot slot;
+    HIP_TRY(hipMemcpy(&slot, S.slots_before.p + (size_t)band * b->cfg.max_listeners + lid, sizeof slot, hipMemcpyDeviceToHost));
+    if (!slot.active)
+        return fail(SDR_ERR_STATE, "listener was not attached during the last batch");
+    // a listener bound inside the batch (sdr_attach_at) ticks from its first frame on
+    const int64_t first = b->total_frames - frames;
+    const int skip = (int)std::max<int64_t>(0, (int64_t)(int32_t)(slot.start_frame - (uint32_t)first));
+    std::vector<uint16_t> table(cw::kMorseTableSize);
+    cw::build_morse_table(table.data());
+    struct NullSink {
+        void put(uint32_t) {}
+    } sink;
+    cw::DecoderState d = slot.dec;
+    int n = 0;
+    for (int f = skip; f < frames; f++) {
+        const bool state = deb[(size_t)f] != 0;
+        cw::decoder_tick(d, state, table.data(), sink);
+        if (out && n < max) {
+            sdr_scope_decode_frame &o = out[n];
+            o.frame = first + f;
+            o.duration = state ? d.ticks - d.onStart : d.ticks - d.offStart;  // currentDuration :222-227
+            o.state = state ? 1.0 : 0.0;
+            o.on_threshold = d.onThreshold.threshold;
+            o.on_threshold_low = d.onThreshold.low;
+            o.on_threshold_high = d.onThreshold.high;
+            o.off_threshold = d.offThreshold.threshold;
+            o.off_threshold_low = d.offThreshold.low;
+            o.off_threshold_high = d.offThreshold.high;
+        }
+        n++;
+    }
+    if (n_out)
+        *n_out = n;
     return SDR_OK;
 }
 

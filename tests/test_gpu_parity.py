@@ -1050,3 +1050,78 @@ def test_many_batches_with_an_erratic_consumer(capi, mode):
     if mode == "graph":
         bank.graph_release()
     bank.close()
+
+
+def test_decoder_scope_streams(capi):
+    """cw.Decoder's own scope streams (cw/decode.go:228-243, :433-491): per tick the current run's duration, both
+    adaptive thresholds with their low and high, and the state.  The device decodes in closed form between edges and
+    keeps none of it; sdr_scope_read_decode replays the batch on the host from the decoder's state before it.  Against
+    the oracle's literal Decoder ticked with the same keying, over two batches (the second replay starts mid-stream) and
+    for a listener bound inside a batch (it ticks from its first frame on)."""
+    n, rate, tones, per = 1024, 96000, 4, 260
+    frames = 2 * per
+    iq, bins, _ = synth.make_band(frames, rate, n, tones, seed=1213)
+    edge = synth.default_edge_width(n)
+    ref = orc.Receiver(rate, n, edge)
+    bank = capi.Bank(rate, n, edge_width=edge, max_batch_frames=per, max_listeners=tones + 1, trace=True)
+    for b in bins:
+        assert bank.attach(0, int(b)) == ref.attach(int(b))
+    out = ref.process(iq)
+    decs = []
+    for lid in range(tones):
+        d = orc.Decoder(rate, n)
+        d.reset()  # Listener.Attach -> demodulator.Reset (rx/listener.go:88)
+        decs.append(d)
+
+    def expected(d, keying, first):
+        rows = []
+        for j, st in enumerate(keying):
+            d.tick(bool(st))
+            s = d.state()  # ticks, onStart, offStart, wpm, on{low, high, last, thr}, off{low, high, last, thr}
+            dur = s[0] - (s[1] if st else s[2])
+            rows.append((first + j, dur, float(st), s[7], s[4], s[5], s[11], s[8], s[9]))
+        return rows
+
+    for k in range(2):
+        a, e = k * per, (k + 1) * per
+        assert bank.process_host(iq[a:e]) == per
+        for lid in range(tones):
+            fr = bank.scope_decode_frames(0, lid)
+            want = expected(decs[lid], out["deb"][a:e, lid], a)
+            assert len(fr) == per
+            got = [tuple(float(fr[name][i]) if name != "frame" else int(fr[name][i]) for name in fr.dtype.names) for i in range(per)]
+            assert got == want, f"batch {k} listener {lid}"
+    bank.close()
+    # a listener bound inside the batch: its decoder (fresh, Reset) takes its first tick at its first frame
+    ref2 = orc.Receiver(rate, n, edge)
+    late = capi.Bank(rate, n, edge_width=edge, max_batch_frames=per, max_listeners=2, trace=True)
+    assert late.attach(0, int(bins[0])) == ref2.attach(int(bins[0]))
+    o1 = ref2.process(iq[:130])
+    lid1 = ref2.attach(int(bins[1]))
+    o2 = ref2.process(iq[130:per])
+    late.enable_results(True)
+    late.defer_listen(True)
+    assert late.process_host(iq[:per]) == per
+    late.poll_peaks(wait=True)
+    assert late.attach_at(0, int(bins[1]), 130) == lid1
+    late.process_listen()
+    late.poll(wait=True)
+    fr = late.scope_decode_frames(0, lid1)
+    d = orc.Decoder(rate, n)
+    d.reset()
+    want = expected(d, o2["deb"][:, lid1], 130)
+    got = [tuple(float(fr[name][i]) if name != "frame" else int(fr[name][i]) for name in fr.dtype.names) for i in range(len(fr))]
+    assert len(fr) == per - 130 and got == want
+    fr0 = late.scope_decode_frames(0, 0)
+    d0 = orc.Decoder(rate, n)
+    d0.reset()
+    want0 = expected(d0, np.concatenate([o1["deb"][:, 0], o2["deb"][:, 0]]), 0)
+    assert [int(x) for x in fr0["frame"]] == list(range(per)) and [float(x) for x in fr0["duration"]] == [w[1] for w in want0]
+    late.close()
+    quiet = capi.Bank(rate, n, edge_width=edge, max_batch_frames=per, max_listeners=tones)
+    quiet.attach(0, int(bins[0]))
+    quiet.process_host(iq[:per])
+    with pytest.raises(capi.SdrError) as ei:
+        quiet.scope_decode_frames(0, 0)
+    assert ei.value.code == capi.ERR_STATE
+    quiet.close()
