@@ -363,6 +363,9 @@ private:
     std::string id_;
     const Clock *clock_;
     Reporter *reporter_;
+    // (in front of the text processor: its constructor asks for the time, and the clock lambda reads these)
+    bool timeOverride_ = false, deferEvents_ = false;
+    double overrideNow_ = 0;
     TextProcessor textProcessor_;
     Peak peak_{};
     bool attached_ = false;
@@ -370,8 +373,6 @@ private:
     double lastAttach_ = 0;
     double silenceTimeout_ = kDefaultSilenceTimeout, attachmentTimeout_ = kDefaultAttachmentTimeout;
     std::string text_;
-    bool timeOverride_ = false, deferEvents_ = false;
-    double overrideNow_ = 0;
     std::vector<std::function<void()>> deferred_;
 };
 

@@ -559,6 +559,32 @@ static void TestCallsignSearchAgainstTheRegex(long count)
     CHECK(ok > count / 50);
 }
 
+// rx::Workers: every item of every run exactly once, whatever the threads' timing (runs back to back, so threads woken
+// for one run meet the next; also run under -fsanitize=thread by tests/test_host_mirror.py when the compiler has it)
+static void TestWorkers()
+{
+    rx::Workers pool(7);
+    std::vector<std::atomic<int>> hits(1000);
+    long total = 0;
+    for (int run = 0; run < 3000; run++) {
+        const size_t n = 1 + (size_t)(run * 7919 % 997);
+        for (size_t i = 0; i < n; i++)
+            hits[i].store(0, std::memory_order_relaxed);
+        std::atomic<long> sum{0};
+        pool.Run(n, [&](size_t i) {
+            hits[i].fetch_add(1, std::memory_order_relaxed);
+            sum.fetch_add((long)i, std::memory_order_relaxed);
+        });
+        bool once = true;
+        for (size_t i = 0; i < n; i++)
+            once = once && hits[i].load(std::memory_order_relaxed) == 1;
+        CHECK(once);
+        CHECK(sum.load() == (long)(n * (n - 1) / 2));
+        total += (long)n;
+    }
+    CHECK(total > 0);
+}
+
 static int run_text()
 {
     struct Printer : rx::CallsignReporter {
@@ -615,6 +641,7 @@ int main(int argc, char **argv)
         TestTextProcessor_CollectCallsign();
         TestTextProcessor_WriteTimeout();
         TestCallsignSearchAgainstTheRegex(argc >= 3 ? atol(argv[2]) : 200000);
+        TestWorkers();
         printf("%s\n", failures ? "FAILED" : "ok");
         return failures ? 1 : 0;
     }

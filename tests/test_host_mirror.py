@@ -28,6 +28,24 @@ def test_host_bookkeeping_matches_reference_tests(exe):
     assert out.stdout.strip() == "ok"
 
 
+@pytest.mark.parametrize("sanitizer", ["address,undefined", "thread"])
+def test_host_bookkeeping_under_sanitizers(exe, tmp_path, sanitizer):
+    """The same CPU scenarios (peaks table, listener pool, text window, the call-sign matchers against their regular
+    expressions, the worker pool's hand-out) built with AddressSanitizer + UBSan and with ThreadSanitizer: clean.  (UBSan
+    found the one defect this file has seen so far: the listener's clock lambda read a member that was initialised
+    after the text processor whose constructor calls it.)"""
+    src = os.path.join(ROOT, "tests", "host", "test_rx_host.cpp")
+    out_exe = str(tmp_path / "test_rx_host_san")
+    cc = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-pthread", f"-fsanitize={sanitizer}", "-fno-sanitize-recover=all",
+                         "-o", out_exe, src, "-L" + CSRC, "-lsdrainer_hip", "-Wl,-rpath," + CSRC], capture_output=True, text=True)
+    if cc.returncode != 0 and "sanitize" in cc.stderr:
+        pytest.skip("this compiler has no -fsanitize=" + sanitizer)
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    run = subprocess.run([out_exe, "cpu", "20000"], capture_output=True, text=True,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0", TSAN_OPTIONS="halt_on_error=1"))
+    assert run.returncode == 0 and run.stdout.strip() == "ok", run.stdout[-1000:] + run.stderr[-3000:]
+
+
 @pytest.mark.gpu
 def test_strain_mode_receiver_against_oracle(exe, tmp_path):
     """Strain mode end to end: peaks discovered every 100 frames, one new listener bound per cumulation
