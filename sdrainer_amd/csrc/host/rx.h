@@ -238,8 +238,14 @@ public:
     void FlushEvents()
     {
         deferEvents_ = false;
-        for (auto &e : deferred_)
-            e();
+        for (const Deferred &e : deferred_) {
+            if (e.kind == 0)
+                reporter_->CallsignDecoded(id_, e.callsign, e.frequency, e.count, e.weight);
+            else if (e.kind == 1)
+                reporter_->CallsignSpotted(id_, e.callsign, e.frequency);
+            else
+                reporter_->SpotTimeout(id_, e.callsign, e.frequency);
+        }
         deferred_.clear();
     }
     Listener(const Listener &) = delete;
@@ -335,7 +341,7 @@ private:
             return;
         const int64_t f = peak_.signal_frequency;
         if (deferEvents_)
-            deferred_.push_back([this, callsign, f, count, weight] { reporter_->CallsignDecoded(id_, callsign, f, count, weight); });
+            deferred_.push_back(Deferred{0, count, weight, f, callsign});
         else
             reporter_->CallsignDecoded(id_, callsign, f, count, weight);
     }
@@ -345,7 +351,7 @@ private:
             return;
         const int64_t f = peak_.signal_frequency;
         if (deferEvents_)
-            deferred_.push_back([this, callsign, f] { reporter_->CallsignSpotted(id_, callsign, f); });
+            deferred_.push_back(Deferred{1, 0, 0, f, callsign});
         else
             reporter_->CallsignSpotted(id_, callsign, f);
     }
@@ -355,7 +361,7 @@ private:
             return;
         const int64_t f = peak_.signal_frequency;
         if (deferEvents_)
-            deferred_.push_back([this, callsign, f] { reporter_->SpotTimeout(id_, callsign, f); });
+            deferred_.push_back(Deferred{2, 0, 0, f, callsign});
         else
             reporter_->SpotTimeout(id_, callsign, f);
     }
@@ -373,7 +379,12 @@ private:
     double lastAttach_ = 0;
     double silenceTimeout_ = kDefaultSilenceTimeout, attachmentTimeout_ = kDefaultAttachmentTimeout;
     std::string text_;
-    std::vector<std::function<void()>> deferred_;
+    struct Deferred {  // a reporter call kept until FlushEvents (a record, not a closure: there are hundreds per segment)
+        int kind, count, weight;
+        int64_t frequency;
+        std::string callsign;
+    };
+    std::vector<Deferred> deferred_;
 };
 
 class ListenerPool {  // :180-270
