@@ -310,9 +310,10 @@ def test_audio_path_bit_exact(capi):
 
 
 def test_full_size_properties(capi):
-    """BASELINE config 3 geometry at a size the oracle cannot finish in seconds: size-independent
-    properties instead — keying round trip (what was keyed is what is detected), every tone found by
-    the peak scan at its bin, and determinism (two runs give identical bits)."""
+    """BASELINE config 3 geometry through size-independent properties - keying round trip (what was keyed is
+    what is detected), every tone found by the peak scan at its bin, determinism (two runs give identical bits).
+    (The bit-for-bit comparison with the oracle at this geometry and at the benchmarked batch sizes is
+    tests/test_gpu_parity_bench_sizes.py; the oracle needs about a second per 2048 frames.)"""
     import torch
 
     n, rate, tones, frames = 16384, 2000000, 256, 1024
