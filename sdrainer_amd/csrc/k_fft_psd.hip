@@ -359,7 +359,70 @@ __device__ __forceinline__ void store_psd(const double (&xr)[fft64::Plan<LOGN>::
 #if !defined(SDR_FFT_DMA_AT)
 #define SDR_FFT_DMA_AT 1
 #endif
+// Wave-private staging (SDR_FFT_PRIVATE_STAGE = 1: by LDS-DMA, 2: straight into registers; default 0 = off).  The
+// frame's 128 KB arrive over about 5 us (every CU of a generation asks at once: 6.4 TB/s while it lasts) and the waves'
+// rows land in the order the waves were started, four at a time - one per SIMD.  Staged co-operatively (every wave
+// reads from every 1 KB row: two workgroup barriers before the first butterfly) the whole workgroup sits that time
+// out.  The idea: each wave fetches exactly the samples its own lanes hold in pass 0 - 32-byte runs, the layout's wave
+// bits are sample bits 2-5 - into the 8 KB of LDS that are its own in the wave-local exchange that follows (or into
+// the registers pass 0 starts from), and starts as soon as ITS samples are there (its own vmcnt, no barrier): the
+// waves that land first run passes 0 and 1 while the others' samples are on their way.
+// MEASURED (round 4, tools/fft_bench, 2048 x 16384, profiles/r04_fft_experiments.txt): bit-identical and SLOWER - 0.170
+// (LDS-DMA) / 0.171 ms (registers; 0.181 with the nt policy) against 0.163 co-operative.  The pipelining is there (the
+// first waves have their samples after 5 200 clocks and are through pass 1 at 18 500, where the co-operative build
+// starts pass 0 at 13 100) but the last waves' samples land at 24 700 instead of 12 000: four waves share every 128-byte
+// line, each asks for it on its own, and the CU's inbound path delivers lines, not bytes (a stand-alone load loop,
+// tools/ubench_load, does not show this: there nothing else competes for the path).  A layout whose waves own whole
+// lines in pass 0 needs the cross-wave exchange right behind pass 0 - layout B below, which lost for other reasons.
+#if !defined(SDR_FFT_PRIVATE_STAGE)
+#define SDR_FFT_PRIVATE_STAGE 0
+#endif
+// logical id of the thread (which index bits its wave id stands for is fft_f64.h make_layout's business; which of the
+// workgroup's waves plays which logical wave is free)
+template <int LOGN>
+__device__ __forceinline__ int logical_thread(int tid)
+{
+    using PL = fft64::Plan<LOGN>;
+    if constexpr (SDR_FFT_PRIVATE_STAGE && PL::WB == 4 && !PL::LB) {
+        const int w = tid >> 6;
+        return (((w & 3) << 2 | (w >> 2)) << 6) | (tid & 63);
+    } else {
+        return tid;
+    }
+}
+// bytes of LDS a wave owns across the staging and the first (wave-local) exchange
+template <int LOGN>
+inline constexpr int kWaveBlockBytes = fft64::make_addr<LOGN>(0).block * 8;
+template <int LOGN>
+constexpr bool private_stage()
+{
+    using PL = fft64::Plan<LOGN>;
+    // the first exchange must be wave-local (layout A always) and the wave's block must hold its R x 64 samples
+    return SDR_FFT_PRIVATE_STAGE && !PL::LB && !(PL::WB > 0 && PL::cross_wave(0)) && kWaveBlockBytes<LOGN> >= PL::R * 512;
+}
 constexpr int kMaxLdsTap = 4096;  // listeners per band the LDS tap holds bins for (16 KB); more fall back to the drain
+// Cache warm-up of a LATER frame (one-frame workgroups; SDR_FFT_PF_DIST > 0, default 0 = off).  The chip runs the
+// frames in generations - 256 workgroups start together, fetch their 128 KB together and then leave the memory system
+// idle for the rest of the frame; a workgroup with 64 CUs running lives 14.2 us, one of 256 18.4 us (tools/fft_bench 64 /
+// 2048 frames, -DSDR_FFT_CLOCK).  The idea: each workgroup touches every 128-byte line of the frame SDR_FFT_PF_DIST
+// workgroups ahead - the one that follows it on its CU, same XCD - with ONE LDS-DMA dword per lane into a sink behind
+// the tap bins (no registers, nothing waits for it), right before exchange SDR_FFT_PF_AT, so that the lines sit in L2 /
+// the Infinity Cache when that workgroup's staging DMA asks for them.
+// MEASURED (round 4, profiles/r04_fft_experiments.txt): no gain before exchange 0 (0.162 against 0.162 ms), 0.205 -
+// 0.214 ms before exchanges 1 / 2, any distance, nt or not: the warm-up is itself a 32 MB burst of the whole chip, the
+// twiddle loads behind it return behind it, and what it leaves in the Infinity Cache comes back no faster than from HBM
+// through the same fabric (L2 cannot hold a generation: 32 CUs x 128 KB = its 4 MB).  The burst is the cost, and only
+// spreading the requests over the frame - which needs somewhere on the CU to put them - would remove it.
+#if !defined(SDR_FFT_PF_DIST)
+#define SDR_FFT_PF_DIST 0
+#endif
+#if !defined(SDR_FFT_PF_AT)
+#define SDR_FFT_PF_AT 1
+#endif
+#if !defined(SDR_FFT_PF_AUX)
+#define SDR_FFT_PF_AUX 0
+#endif
+constexpr int kPfSinkBytes = SDR_FFT_PF_DIST > 0 ? 4096 : 0;
 // (second launch bound = waves per SIMD the register allocation must leave room for: four, i.e. one 1024-thread
 // workgroup or two 512-thread ones per CU)
 template <int LOGN, bool MULTI>
@@ -369,6 +432,7 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
                                                                   int n_frames, int fpw, const int *__restrict__ tap_bins,
                                                                   float *__restrict__ tap_out, int n_tap, int tap_stride)
 {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass needs the signature only; with the body it drops the stub without a diagnostic)
     using PL = fft64::Plan<LOGN>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *lds = reinterpret_cast<double *>(smem);
@@ -390,10 +454,14 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
     const int frame0 = MULTI ? blockIdx.x * fpw : blockIdx.x;
     const int frame_end = MULTI ? min(frame0 + fpw, n_frames) : frame0 + 1;
     const size_t in_band = (size_t)blockIdx.y * in_stride, out_band = (size_t)blockIdx.y * out_stride;
-    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    constexpr bool PRIV = private_stage<LOGN>();
+    const int ltid = logical_thread<LOGN>((int)threadIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane(ltid >> 6);
 
-    // Frame -> LDS by LDS-DMA, one contiguous 1 KB row per wave instruction, shaped through the source address
-    // (fft_f64.h "Input staging").  The staging image lives in the exchange area.
+    // Frame -> LDS by LDS-DMA.  Co-operative: one contiguous 1 KB row per wave instruction, shaped through the source
+    // address (fft_f64.h "Input staging"), the image lives in the exchange area.  Wave-private (see above): instruction j
+    // fills the wave's slots 2j (lanes 0-31) and 2j+1 (lanes 32-63), 16 bytes = two consecutive samples = two
+    // neighbouring lanes' values per DMA lane; block layout [slot][lane], 8 bytes each.
     auto stage_frame = [&](int frame, int tid, int part = 0) {
 #if defined(SDR_ABLATE) && (SDR_ABLATE == 15 || SDR_ABLATE == 16)
         if (frame >= 0)  // timing-only build: no input DMA at all - what a perfectly hidden input would leave
@@ -408,6 +476,18 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
 #endif
         // buffer form: row in the scalar offset, granule in one 32-bit VGPR - no 64-bit per-lane addresses
         const rsrc_t xrs = make_rsrc(iq + fr * PL::N * 2, PL::N * 8u);
+        if constexpr (PRIV) {
+            const unsigned voff = (unsigned)(fft64::input_sample<LOGN>((tid & ~63) | (2 * (lane & 31)), 0) +
+                                             ((lane >> 5) ? fft64::input_slot_sample<LOGN>(1) : 0)) * 8u;
+#pragma unroll
+            for (int j = 0; j < ROWS_PER_WAVE; j++) {
+                if ((part == 1 && j >= ROWS_PER_WAVE / 2) || (part == 2 && j < ROWS_PER_WAVE / 2))
+                    continue;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void *)(smem + wave * kWaveBlockBytes<LOGN> + j * 1024), 16,
+                                                         voff, fft64::input_slot_sample<LOGN>(2 * j) * 8, 0, SDR_FFT_DMA_AUX);
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < ROWS_PER_WAVE; j++) {
             if ((part == 1 && j >= ROWS_PER_WAVE / 2) || (part == 2 && j < ROWS_PER_WAVE / 2))
@@ -428,10 +508,14 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
             out[l] = bin >= 0 ? row[bin] : 0.0f;
         }
     };
-    stage_frame(frame0, threadIdx.x);
+    constexpr bool REGS = PRIV && !MULTI && SDR_FFT_PRIVATE_STAGE == 2;  // one-frame workgroup: straight into the registers pass 0 starts from
+    if constexpr (!REGS)
+        stage_frame(frame0, ltid);
     // one-frame workgroup: its listeners' bins into LDS (behind the exchange area) while the frame is on its way
     int *lds_bins = reinterpret_cast<int *>(smem + fft64::kLdsBytes<LOGN>);
     const bool lds_tap = !MULTI && n_tap > 0 && n_tap <= kMaxLdsTap;
+    unsigned char *pf_sink = smem + fft64::kLdsBytes<LOGN> + (lds_tap ? ((n_tap * 4 + 255) & ~255) : 0);
+    (void)pf_sink;
     if (lds_tap)
         for (int l = threadIdx.x; l < n_tap; l += PL::T)
             lds_bins[l] = tap_bins[(size_t)blockIdx.y * tap_stride + l];
@@ -440,38 +524,59 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
     for (int frame = frame0; frame < frame_end; frame++) {
         // (with more than one frame per workgroup everything derived from the thread id is loop-invariant and the
         // compiler would hoist - and spill - it: make the thread id opaque per frame)
-        int t = threadIdx.x;
+        int t = ltid;
         if constexpr (MULTI)
             asm volatile("" : "+v"(t));
         // The first frame's DMA is the wave's only traffic: full drain.  A later frame's DMA is older than the
         // previous frame's R psd stores (MI355X_MICROARCH.md: loads, stores and LDS-DMA count together, in issue
         // order), so "all but the R youngest" covers it (tap traffic behind the stores only makes the wait cover
         // some of the stores too).
+        double xr[PL::R], xi[PL::R];
+        if constexpr (REGS) {
+            // dsp/fft.go:59-69 setSamplesFromIQ: slot m <- sample input_sample(t, m): the thread's part of the sample
+            // number in the per-lane offset, the slot's in the scalar offset; 8 bytes per lane, four lanes per 32-byte run
+            const rsrc_t xrs = make_rsrc(iq + (in_band + frame) * PL::N * 2, PL::N * 8u);
+            const unsigned voff = (unsigned)fft64::input_sample<LOGN>(t, 0) * 8u;
+            u32x2 raw[PL::R];
+#pragma unroll
+            for (int m = 0; m < PL::R; m++)
+                raw[m] = __builtin_amdgcn_raw_buffer_load_b64(xrs, voff, fft64::input_slot_sample<LOGN>(m) * 8, SDR_FFT_DMA_AUX);
+#pragma unroll
+            for (int m = 0; m < PL::R; m++) {
+                xr[m] = (double)__uint_as_float(raw[m].x);
+                xi[m] = (double)__uint_as_float(raw[m].y);
+            }
+            SDR_STAMP(st, ST_LANDED);
+        } else {
         if (!MULTI || frame == frame0)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else
             SDR_WAIT_ALL_BUT(PL::R);
         SDR_STAMP(st, ST_LANDED);  // this wave's rows have landed
-        __syncthreads();
+        if constexpr (!PRIV)
+            __syncthreads();
         SDR_STAMP(st, ST_ALL_LANDED);  // everybody's have
 
-        double xr[PL::R], xi[PL::R];
         const int n_thread = fft64::input_sample<LOGN>(t, 0);
-        const int thread_byte = fft64::in_lds_byte<LOGN>(n_thread);
+        const int thread_byte = PRIV ? wave * kWaveBlockBytes<LOGN> + (t & 63) * 8 : fft64::in_lds_byte<LOGN>(n_thread);
 #pragma unroll
         for (int m = 0; m < PL::R; m++) {
 #if defined(SDR_ABLATE) && (SDR_ABLATE == 1 || SDR_ABLATE == 7)
             const float2 v = make_float2(1e-3f * (float)(t + m), 0.5f);  // timing-only build: no input
 #else
-            // sample number -> image address is linear over GF(2): thread part and slot part combine by XOR,
-            // and the slot part is a compile-time constant
-            const int slot_byte = fft64::in_lds_byte<LOGN>(fft64::input_sample<LOGN>(0, m));
-            const float2 v = *reinterpret_cast<const float2 *>(smem + (thread_byte ^ slot_byte));
+            // co-operative image: sample number -> image address is linear over GF(2): thread part and slot part
+            // combine by XOR, and the slot part is a compile-time constant; wave-private block: [slot][lane]
+            const int slot_byte = PRIV ? m * 512 : fft64::in_lds_byte<LOGN>(fft64::input_sample<LOGN>(0, m));
+            const float2 v = *reinterpret_cast<const float2 *>(smem + (PRIV ? thread_byte + slot_byte : (thread_byte ^ slot_byte)));
 #endif
             xr[m] = (double)v.x;
             xi[m] = (double)v.y;
         }
-        __syncthreads();  // everyone has its samples: the exchange area may be written again
+        if constexpr (PRIV)
+            wave_sync();  // the wave has its samples: its block belongs to its first exchange now
+        else
+            __syncthreads();  // everyone has its samples: the exchange area may be written again
+        }
         SDR_STAMP(st, ST_LOADED);
         const bool more = MULTI && frame + 1 < frame_end;
         // (no scheduling pin around the DMA: the compiler keeps it behind the exchanges' LDS accesses and behind the
@@ -483,7 +588,15 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
             if constexpr (MULTI && (SDR_FFT_DMA_AT == 0 || SDR_FFT_DMA_AT == 2))
                 if (more)
                     stage_frame(frame + 1, t, SDR_FFT_DMA_AT == 2 ? 1 : 0);
-        }, no_pre, st);
+        }, no_pre, st, [&](int e, bool after) {
+            if constexpr (!MULTI && SDR_FFT_PF_DIST > 0) {
+                if (e == SDR_FFT_PF_AT && !after && frame + SDR_FFT_PF_DIST < n_frames) {
+                    const rsrc_t nrs = make_rsrc(iq + (in_band + frame + SDR_FFT_PF_DIST) * PL::N * 2, PL::N * 8u);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(nrs, (__attribute__((address_space(3))) void *)(pf_sink + wave * 256), 4,
+                                                             (unsigned)(t & 63) * 128u, wave * 8192, 0, SDR_FFT_PF_AUX);
+                }
+            }
+        });
         if constexpr (MULTI && (SDR_FFT_DMA_AT == 1 || SDR_FFT_DMA_AT == 2))
             if (more)
                 stage_frame(frame + 1, t, SDR_FFT_DMA_AT == 2 ? 2 : 0);
@@ -539,6 +652,7 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
         atomicMax(&g_fft_wg[blockIdx.x][2], now);
     }
 #endif
+#endif  // __HIP_DEVICE_COMPILE__
 }
 
 // Epilogue of layout B (dsp/fft.go:54-57 fftshift, :71-73 PSD[float32]).  Wave w holds the bins = w (mod 16): stored
@@ -853,7 +967,7 @@ static hipError_t launch_fft_t(const float *iq, const BatchCursor *cur, const ff
     std::call_once(attr_once[dev], [&] {
         for (const void *k : {reinterpret_cast<const void *>(&k_fft_psd<LOGN, false>),
                               reinterpret_cast<const void *>(&k_fft_psd<LOGN, true>)}) {
-            const hipError_t ae = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, fft64::kLdsBytes<LOGN> + kMaxLdsTap * 4);
+            const hipError_t ae = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, fft64::kLdsBytes<LOGN> + kMaxLdsTap * 4 + kPfSinkBytes);
             if (ae != hipSuccess)
                 attr_err = ae;
         }
@@ -872,7 +986,7 @@ static hipError_t launch_fft_t(const float *iq, const BatchCursor *cur, const ff
                            iq, cur, tw, psd, in_stride, out_stride, n_frames, fpw, tap.bins, tap.out, tap.n, tap.stride);
     else
         launch_kernel((k_fft_psd<LOGN, false>), dim3(n_frames, n_bands), dim3(PL::T),
-                           fft64::kLdsBytes<LOGN> + (tap.n > 0 && tap.n <= kMaxLdsTap ? tap.n * 4 : 0), stream, iq, cur, tw, psd, in_stride,
+                           fft64::kLdsBytes<LOGN> + (tap.n > 0 && tap.n <= kMaxLdsTap ? ((tap.n * 4 + 255) & ~255) : 0) + kPfSinkBytes, stream, iq, cur, tw, psd, in_stride,
                            out_stride, n_frames, 1, tap.bins, tap.out, tap.n, tap.stride);
     return hipGetLastError();
     }
