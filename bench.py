@@ -176,32 +176,111 @@ def cpu_baseline(rate, n, tones, free_last, seconds):
     }
 
 
-def spawn_ranks(n: int) -> int:
+def spawn_ranks(n: int, deadline_s: float = 1500.0) -> int:
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this same script (one per GPU,
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, as torch.distributed.run would set them), BEFORE
     this process has touched the GPU - it never does.  Rank 0's stdout (the one JSON line) is relayed; the exit code
-    is non-zero if any rank failed."""
+    is non-zero if any rank failed.  The ranks are watched together: when one dies (a bad LOCAL_RANK on a box with fewer
+    GPUs, a failed rendezvous) the others - which would sit in init_process_group or a barrier for ever, holding their
+    GPUs - are terminated, then killed, and the tail of every rank's output goes into the error message; the whole wait
+    has a deadline."""
     import socket
     import subprocess
+    import tempfile
 
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
+    procs, logs = [], []
     for rank in range(n):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), SDR_BENCH_SPAWNED="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode(errors="replace"))
-    sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        out = tempfile.TemporaryFile()
+        err = tempfile.TemporaryFile()
+        logs.append((out, err))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out, stderr=err))
+
+    def tail(f, nbytes=1500):
+        f.seek(0, os.SEEK_END)
+        size = f.tell()
+        f.seek(max(0, size - nbytes))
+        return f.read().decode(errors="replace")
+
+    t_end = time.monotonic() + deadline_s
+    failed, timed_out = None, False
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = bad
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() > t_end:
+            timed_out = True
+            break
+        time.sleep(0.05)
+    if failed or timed_out:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_kill = time.monotonic() + 10.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        why = f"ranks failed (rank, exit code): {failed}" if failed else f"no result after {deadline_s:.0f} s"
+        print(f"bench.py: {why}; the other ranks were stopped", file=sys.stderr)
+        for r, (out, err) in enumerate(logs):
+            print(f"--- rank {r} (exit {procs[r].returncode}) stderr tail:\n{tail(err)}\n--- rank {r} stdout tail:\n{tail(out)}", file=sys.stderr)
         return 1
+    logs[0][0].seek(0)
+    sys.stdout.write(logs[0][0].read().decode(errors="replace"))
+    sys.stdout.flush()
+    sys.stderr.write(tail(logs[0][1], 4000))  # (rank 0's diagnostics, e.g. --kernel-breakdown)
     return 0
+
+
+def pin_to_gpu_numa_node(torch, local_rank: int, rank: int, world: int):
+    """Keep this rank's threads - the enqueueing main thread, the consumer thread in sdr_poll, the library's staging
+    copies - on the cores of its GPU's NUMA node (eight ranks x several threads otherwise wander over both sockets and
+    poll pinned memory across the link).  Falls back to an even split of the cores when the node is not exposed.
+    Returns what was done, for the result line."""
+    try:
+        all_cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return {"policy": "none (no sched_setaffinity)"}
+    cpus, policy = None, None
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        base = f"/sys/bus/pci/devices/{bdf}"
+        node = int(open(base + "/numa_node").read())
+        if node >= 0:
+            cl = open(f"/sys/devices/system/node/node{node}/cpulist").read().strip()
+            want = set()
+            for part in cl.split(","):
+                lo, _, hi = part.partition("-")
+                want.update(range(int(lo), int(hi or lo) + 1))
+            cpus = sorted(want & set(all_cpus))
+            policy = f"numa node {node} of {bdf}"
+    except (OSError, ValueError, AttributeError):
+        pass
+    if world > 1 and cpus:
+        # the ranks that share the node share its cores evenly (rank order)
+        share = max(1, len(cpus) // max(1, min(world, 4)))
+        k = rank % max(1, len(cpus) // share)
+        cpus = cpus[k * share:(k + 1) * share] or cpus
+    if not cpus and world > 1:
+        share = max(1, len(all_cpus) // world)
+        cpus = all_cpus[rank * share:(rank + 1) * share] or all_cpus
+        policy = "even split (GPU NUMA node not exposed)"
+    if not cpus:
+        return {"policy": "none (single rank, NUMA node not exposed)", "cpus": len(all_cpus)}
+    os.sched_setaffinity(0, cpus)
+    return {"policy": policy, "cpus": len(cpus), "first": cpus[0], "last": cpus[-1]}
 
 
 def main():
@@ -212,6 +291,11 @@ def main():
         raise SystemExit(spawn_ranks(args.gpus))
     if args.serial:
         os.environ["SDR_NO_OVERLAP"] = "1"
+    # (tests/test_bench_spawn.py: a rank that dies / a rank that hangs in front of the rendezvous, without a GPU)
+    if os.environ.get("SDR_BENCH_TEST_DIE_RANK") == os.environ.get("RANK", "0"):
+        raise SystemExit(3)
+    if os.environ.get("SDR_BENCH_TEST_HANG_RANK") == os.environ.get("RANK", "0"):
+        time.sleep(3600)
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -226,6 +310,7 @@ def main():
         local_rank = int(os.environ["SDR_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    affinity = pin_to_gpu_numa_node(torch, local_rank, rank, world)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
     dist = None
     if world > 1:
@@ -358,6 +443,7 @@ def main():
     torch.cuda.synchronize()
     if delivery:
         take(wait=True)  # the last batches' results, still inside the timed region
+    own_elapsed = time.perf_counter() - t0  # this rank alone: a straggling GPU shows here, not in the max below
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -370,6 +456,12 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    per_rank_s = [own_elapsed]
+    if dist is not None:
+        own = torch.tensor([own_elapsed], dtype=torch.float64, device=coll_dev)
+        every = [torch.zeros_like(own) for _ in range(world)]
+        dist.all_gather(every, own)
+        per_rank_s = [float(x.item()) for x in every]
 
     samples_per_step_rank = frames * n * bands_per_gpu
     total_samples = samples_per_step_rank * args.steps * world
@@ -459,9 +551,17 @@ def main():
             "sharding": f"{bands_per_gpu * world} independent bands, {bands_per_gpu} per GPU, no data-path collective",
             "distributed": ({"world_size": dist.get_world_size(), "backend": dist.get_backend(),
                              "collectives": "broadcast of the shared configuration struct from rank 0 before the timed "
-                                            "region; barrier + max-over-ranks of the elapsed time around it",
+                                            "region; barrier + max-over-ranks of the elapsed time around it; all-gather "
+                                            "of every rank's own elapsed time (per_rank)",
                              "launched_by": "bench.py itself" if os.environ.get("SDR_BENCH_SPAWNED") else "external launcher"}
                             if dist is not None else {"world_size": 1, "backend": None}),
+            # every rank's OWN time from the common start to its last delivered batch (the closing barrier excluded):
+            # `value` is computed from the max over ranks, so a straggling GPU would otherwise be invisible
+            "per_rank": {"ms_per_step": [round(t_ * 1e3 / args.steps, 4) for t_ in per_rank_s],
+                         "value": [round(samples_per_step_rank * args.steps / t_ / 1e6, 1) for t_ in per_rank_s],
+                         "value_min": round(samples_per_step_rank * args.steps / max(per_rank_s) / 1e6, 1),
+                         "value_max": round(samples_per_step_rank * args.steps / min(per_rank_s) / 1e6, 1)},
+            "cpu_affinity_rank0": affinity,
             "clock_settle_ms": args.settle_ms,
             "launch": (f"hipGraph: {bank.graph_batches} batches per replay (sdr_graph_launch)" if args.graph
                        else "eager: every kernel launched per step over the bank's four streams"),

@@ -86,7 +86,7 @@ _lib = None
 
 # every symbol include/sdrainer_hip.h declares (tests/test_capi_symbols.py checks the header against this)
 SYMBOLS = (
-    "sdr_last_error sdr_abi_version sdr_create sdr_destroy sdr_set_stream sdr_push_iq sdr_push_kiwi_snd sdr_staged_frames "
+    "sdr_last_error sdr_abi_version sdr_create sdr_destroy sdr_self_check sdr_set_stream sdr_push_iq sdr_push_kiwi_snd sdr_staged_frames "
     "sdr_process_staged sdr_process_staged_limit sdr_process_device sdr_sync sdr_attach sdr_detach sdr_listener_count sdr_listener_stop "
     "sdr_set_peak_threshold sdr_set_edge_width sdr_set_signal_debounce sdr_set_center_frequency sdr_set_find_peaks "
     "sdr_last_batch_frames sdr_total_frames sdr_last_batch_chunks sdr_read_peaks sdr_read_cumulation sdr_read_text "
@@ -126,6 +126,7 @@ def load():
     sig("sdr_last_error", C.c_char_p)
     sig("sdr_abi_version", C.c_int)
     sig("sdr_create", C.c_int, C.POINTER(Config), C.POINTER(vp))
+    sig("sdr_self_check", C.c_int, C.c_int)
     sig("sdr_destroy", C.c_int, vp)
     sig("sdr_set_stream", C.c_int, vp, vp)
     sig("sdr_push_iq", C.c_int, vp, C.c_int, C.c_int, fp, C.c_size_t)

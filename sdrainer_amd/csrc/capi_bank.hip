@@ -1,0 +1,597 @@
+// capi_bank.hip — the bank behind the C ABI (include/sdrainer_hip.h): creation and destruction of its HBM-resident
+// state, the control calls that touch state owned by a pipeline stage (attach / detach / setters: applied between
+// batches, as the reference applies them between frames, rx/receiver.go:166-172), profiling.  The scheduler is
+// capi_process.hip, delivery capi_results.hip, graph mode capi_graph.hip, reads capi_read.hip (see bank.h).
+#include "bank.h"
+#include "twiddles.h"
+
+using namespace sdrcapi;
+
+namespace sdr {
+int set_error(int code, const char *msg) { return fail(code, msg); }
+}  // namespace sdr
+
+namespace sdrcapi {
+std::unique_ptr<host::DeliveryBackend> make_results_backend(sdr_bank *b);  // capi_results.hip
+
+void resolve_profile(sdr_bank *b)
+{
+    for (auto &p : b->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.second.first, p.second.second) == hipSuccess) {
+            b->prof_ms[p.first] += ms;
+            b->prof_n[p.first] += 1;
+        }
+        (void)hipEventDestroy(p.second.first);
+        (void)hipEventDestroy(p.second.second);
+    }
+    b->pending.clear();
+}
+
+int sync_bank(sdr_bank *b)
+{
+    HIP_TRY(hipSetDevice(b->device));
+    {
+        const int frc = flush_late_attached(b);  // (whoever synchronises next may read or write slots)
+        if (frc)
+            return frc;
+    }
+    for (int s = 0; s < N_STAGES; s++)
+        HIP_TRY(hipStreamSynchronize(b->stream[s]));
+    resolve_profile(b);
+    return SDR_OK;
+}
+
+int check_band(sdr_bank *b, int band)
+{
+    if (!b)
+        return fail(SDR_ERR_BAD_ARG, "null bank");
+    if (band < 0 || band >= b->cfg.n_bands)
+        return fail(SDR_ERR_BAD_ARG, "band out of range");
+    return SDR_OK;
+}
+
+int check_listener(sdr_bank *b, int band, int lid)
+{
+    int rc = check_band(b, band);
+    if (rc)
+        return rc;
+    if (lid < 0 || lid >= b->n_slots[band])
+        return fail(SDR_ERR_BAD_ARG, "listener id out of range");
+    return SDR_OK;
+}
+
+
+// one batch's buffers, stage events and (if bulk delivery is on) its block of pinned host memory
+hipError_t alloc_set(sdr_bank *b, BatchSet &S)
+{
+    const sdr_config &c = b->cfg;
+    const size_t B = (size_t)c.n_bands, F = (size_t)c.max_batch_frames, L = (size_t)c.max_listeners, N = (size_t)c.block_size;
+    hipError_t e = hipSuccess;
+#define SET_ALLOC(buf, count)            \
+    do {                                 \
+        if (e == hipSuccess)             \
+            e = (buf).alloc(count);      \
+    } while (0)
+    SET_ALLOC(S.psd, B * F * N);
+    SET_ALLOC(S.tap, B * F * std::max<size_t>(L, 1));
+    SET_ALLOC(S.win_mean, B * F * 10);
+    SET_ALLOC(S.recs, B * F);
+    SET_ALLOC(S.raw_bits, B * L * (size_t)b->bit_words);
+    SET_ALLOC(S.bits, B * L * (size_t)b->bit_words);
+    SET_ALLOC(S.edges, B * L * (size_t)b->edge_cap);
+    SET_ALLOC(S.edge_counts, B * L);
+    if (c.trace) {
+        SET_ALLOC(S.tr_values, B * F * L);
+        SET_ALLOC(S.tr_raw, B * F * L);
+        SET_ALLOC(S.tr_deb, B * F * L);
+        SET_ALLOC(S.slots_before, B * L);
+    }
+    SET_ALLOC(S.cum_out, B * (size_t)b->max_chunks * N);
+    SET_ALLOC(S.dev_peaks, B * (size_t)b->max_chunks * (size_t)c.max_peaks);
+    SET_ALLOC(S.peak_counts, B * (size_t)b->max_chunks);
+#undef SET_ALLOC
+#ifndef SDR_STAGE_EVENT_FLAGS
+#define SDR_STAGE_EVENT_FLAGS hipEventDisableTiming
+#endif
+    for (auto &ev : S.done)
+        if (e == hipSuccess)
+            e = hipEventCreateWithFlags(&ev, SDR_STAGE_EVENT_FLAGS);
+    return e;
+}
+
+}  // namespace sdrcapi
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+const char *sdr_last_error(void) { return g_last_error.c_str(); }
+int sdr_abi_version(void) { return SDR_ABI_VERSION; }
+const char *sdr_kernel_name(int kernel) { return (kernel >= 0 && kernel < sdr::K_COUNT) ? kKernelNames[kernel] : ""; }
+
+int sdr_self_check(int device_id)
+{
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev)
+        return fail(SDR_ERR_BAD_ARG, "device_id out of range");
+    HIP_TRY(hipSetDevice(device_id));
+    unsigned *d = nullptr, h = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), sizeof(unsigned)));
+    hipError_t e = hipMemset(d, 0, sizeof(unsigned));
+    // (tests only: SDR_SELF_CHECK_ORDER=1 / 2 compares against an evaluation order the pipe must not have - the check has to fail)
+    const char *ord = getenv("SDR_SELF_CHECK_ORDER");
+    if (e == hipSuccess)
+        e = sdr::launch_mfma_order_probe(d, ord ? atoi(ord) : 0, nullptr);
+    if (e == hipSuccess)
+        e = hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost);  // (synchronises with the null stream)
+    (void)hipFree(d);
+    HIP_TRY(e);
+    if (h != 0)
+        return fail(SDR_ERR_HIP, "self-check failed: v_mfma_f64_4x4x4 does not add its terms as a sequential, individually rounded chain on this "
+                                 "device (" + std::to_string(h) + " of 4096 partial sums differ from the vector ALU's); the variance of "
+                                 "FindNoiseFloor would not be bit-exact - this part is not supported");
+    return SDR_OK;
+}
+
+namespace {
+// once per device and process; the verdict is kept (a failing part fails every creation)
+int self_check_once(int device_id)
+{
+    constexpr int kMax = 64;
+    static std::mutex mu;
+    static int verdict[kMax];
+    static bool done[kMax];
+    static std::string message[kMax];
+    if (device_id < 0 || device_id >= kMax)
+        return sdr_self_check(device_id);
+    std::lock_guard<std::mutex> g(mu);
+    if (!done[device_id]) {
+        verdict[device_id] = sdr_self_check(device_id);
+        message[device_id] = g_last_error;
+        done[device_id] = true;
+    }
+    if (verdict[device_id] != SDR_OK)
+        g_last_error = message[device_id];
+    return verdict[device_id];
+}
+}  // namespace
+
+int sdr_create(const sdr_config *cfg, sdr_bank **out)
+{
+    if (!cfg || !out)
+        return fail(SDR_ERR_BAD_ARG, "null argument");
+    if (cfg->struct_size != (int32_t)sizeof(sdr_config))
+        return fail(SDR_ERR_BAD_ARG, "sdr_config.struct_size mismatch (ABI)");
+    const int N = cfg->block_size;
+    if (N < 512 || N > 16384 || (N & (N - 1)))
+        return fail(SDR_ERR_BAD_SIZE, "block_size must be a power of two in [512, 16384]");
+    if (cfg->n_bands < 1 || cfg->sample_rate < 1 || cfg->max_batch_frames < 1 || cfg->max_listeners < 0 ||
+        cfg->max_peaks < 1)
+        return fail(SDR_ERR_BAD_ARG, "non-positive geometry");
+    if (cfg->edge_width < 0 || N - 2 * cfg->edge_width < 10)
+        return fail(SDR_ERR_BAD_ARG, "edge_width leaves fewer than 10 bins: the reference's windowSize would be 0 (NaN)");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (cfg->device_id < 0 || cfg->device_id >= ndev)
+        return fail(SDR_ERR_BAD_ARG, "device_id out of range");
+    HIP_TRY(hipSetDevice(cfg->device_id));
+    {
+        const int sc = self_check_once(cfg->device_id);  // the matrix pipe adds the way the variance chains need it to
+        if (sc != SDR_OK)
+            return sc;
+    }
+
+    sdr_bank *b = new sdr_bank();
+    b->cfg = *cfg;
+    b->device = cfg->device_id;
+    b->logn = ilog2(N);
+    b->edge_width = cfg->edge_width;
+    b->find_peaks = cfg->find_peaks;
+    const size_t B = (size_t)cfg->n_bands, L = (size_t)cfg->max_listeners;
+    b->max_chunks = cfg->max_batch_frames / SDR_CUMULATION_SIZE + 2;
+    b->edge_cap = cfg->max_batch_frames < 8192 ? cfg->max_batch_frames : 8192;
+    b->bit_words = (cfg->max_batch_frames + 63) / 64;
+
+#define ALLOC(buf, count)                                                                              \
+    do {                                                                                               \
+        hipError_t _e = (buf).alloc(count);                                                            \
+        if (_e != hipSuccess) {                                                                        \
+            sdr_destroy(b);                                                                            \
+            return fail(SDR_ERR_HIP, std::string("hipMalloc " #buf ": ") + hipGetErrorString(_e));     \
+        }                                                                                              \
+    } while (0)
+
+    // SDR_NO_OVERLAP=1 runs every stage on the caller's stream (kernel-by-kernel profiling)
+    const char *no_overlap = getenv("SDR_NO_OVERLAP");
+    for (int s = 1; s < N_STAGES && !(no_overlap && no_overlap[0] == '1'); s++) {
+        hipError_t e = hipStreamCreateWithFlags(&b->stream[s], hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            sdr_destroy(b);
+            return fail(SDR_ERR_HIP, "hipStreamCreate failed");
+        }
+        b->own_stream[s] = true;
+    }
+    // twiddles: go-dsp's table, re-laid-out per register pass
+    {
+        std::vector<double> wre, wim;
+        fft64::radix2_factors(N, wre, wim);
+        const size_t ntw = (size_t)sdr::twiddle_count(b->logn);
+        std::vector<fft64::cplx> h(ntw);
+        sdr::build_twiddles(b->logn, wre.data(), wim.data(), h.data());
+        ALLOC(b->tw, h.size());
+        hipError_t e = hipMemcpy(b->tw.p, h.data(), h.size() * sizeof(fft64::cplx), hipMemcpyHostToDevice);
+        // tables of the certified dB shortcut (they fold log2 N in)
+        std::vector<unsigned char> tab(gomath::kDbTabBytes);
+        gomath::build_db_tables(b->logn, tab.data());
+        ALLOC(b->db_tab, tab.size());
+        if (e == hipSuccess)
+            e = hipMemcpy(b->db_tab.p, tab.data(), tab.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            sdr_destroy(b);
+            return fail(SDR_ERR_HIP, "twiddle / table upload failed");
+        }
+    }
+    b->res_backend = make_results_backend(b);
+    b->results.reset(new host::Delivery(b->res_backend.get(), RING, GRAPH_PHASES * RING));
+    b->set.reserve((size_t)RING + (size_t)GRAPH_PHASES * RING);  // (graph mode adds its sets later: no reallocation, references stay valid)
+    b->set.resize(RING);
+    for (int r = 0; r < RING; r++) {
+        const hipError_t se = alloc_set(b, b->set[r]);
+        if (se != hipSuccess) {
+            sdr_destroy(b);
+            return fail(SDR_ERR_HIP, std::string("allocating a batch buffer set: ") + hipGetErrorString(se));
+        }
+    }
+    ALLOC(b->band_state, B);
+    ALLOC(b->drops, 1);
+    ALLOC(b->cursors, GRAPH_PHASES * RING);
+    ALLOC(b->spectrum_row, (size_t)N);
+    ALLOC(b->tap_bins, B * std::max<size_t>(L, 1));
+    {
+        std::vector<int32_t> free_bins(B * std::max<size_t>(L, 1), -1);
+        hipError_t he = hipMemcpy(b->tap_bins.p, free_bins.data(), free_bins.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+        if (he != hipSuccess) {
+            sdr_destroy(b);
+            return fail(SDR_ERR_HIP, "tap table upload failed");
+        }
+    }
+    ALLOC(b->slots, B * L);
+    ALLOC(b->morse, cw::kMorseTableSize);
+    ALLOC(b->text, B * L * (size_t)b->text_cap);
+    ALLOC(b->text_frames, B * L * (size_t)b->text_cap);
+    ALLOC(b->carry[0], B * N);
+    ALLOC(b->carry[1], B * N);
+#undef ALLOC
+
+    std::vector<uint16_t> h_morse(cw::kMorseTableSize);
+    cw::build_morse_table(h_morse.data());
+    hipError_t e = hipMemcpy(b->morse.p, h_morse.data(), sizeof(uint16_t) * cw::kMorseTableSize, hipMemcpyHostToDevice);
+    b->h_band_state.assign(B, sdr::BandState{});
+    for (auto &s : b->h_band_state)
+        s.peak_threshold = cfg->peak_threshold;
+    if (e == hipSuccess)
+        e = hipMemcpy(b->band_state.p, b->h_band_state.data(), sizeof(sdr::BandState) * B, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        sdr_destroy(b);
+        return fail(SDR_ERR_HIP, "state upload failed");
+    }
+    b->h_slots.assign(B * L, sdr::ListenerSlot{});
+    b->n_slots.assign(B, 0);
+    b->center_frequency.assign(B, 0);
+    b->staged.assign(B, 0);
+    b->staged_kind.assign(B, 0);
+    *out = b;
+    return SDR_OK;
+}
+
+int sdr_destroy(sdr_bank *b)
+{
+    if (!b)
+        return SDR_OK;
+    (void)hipSetDevice(b->device);
+    for (int s = 0; s < N_STAGES; s++)
+        (void)hipStreamSynchronize(b->stream[s]);
+    resolve_profile(b);
+    drop_graphs(b);
+    for (auto &ph : b->phase_done)
+        for (auto &ev : ph)
+            if (ev)
+                (void)hipEventDestroy(ev);
+    b->tw.release();
+    b->drops.release();
+    b->cursors.release();
+    b->db_tab.release();
+    b->tap_bins.release();
+    b->spectrum_row.release();
+    for (auto &S : b->set)
+        S.release();
+    if (b->results)
+        for (int i = 0; i < b->results->n_sets(); i++) {
+            host::ResultSet &rs = b->results->set(i);
+            if (rs.block)
+                (void)hipHostFree(rs.block);
+            if (rs.ev_listen)
+                (void)hipEventDestroy(static_cast<hipEvent_t>(rs.ev_listen));
+            if (rs.ev_peaks)
+                (void)hipEventDestroy(static_cast<hipEvent_t>(rs.ev_peaks));
+        }
+    b->band_state.release();
+    b->slots.release();
+    b->morse.release();
+    b->text.release();
+    b->text_frames.release();
+    b->carry[0].release();
+    b->carry[1].release();
+    for (int s = 0; s < N_STAGES; s++)
+        if (b->own_stream[s] && b->stream[s])
+            (void)hipStreamDestroy(b->stream[s]);
+    if (b->copy_stream) {
+        (void)hipStreamSynchronize(b->copy_stream);
+        (void)hipStreamDestroy(b->copy_stream);
+    }
+    for (auto &st : b->stage) {
+        if (st.h_f32)
+            (void)hipHostFree(st.h_f32);
+        if (st.h_raw)
+            (void)hipHostFree(st.h_raw);
+        st.d_f32.release();
+        st.d_raw.release();
+        if (st.uploaded)
+            (void)hipEventDestroy(st.uploaded);
+        if (st.consumed)
+            (void)hipEventDestroy(st.consumed);
+    }
+    delete b;
+    return SDR_OK;
+}
+
+int sdr_set_stream(sdr_bank *b, void *hip_stream)
+{
+    if (!b)
+        return fail(SDR_ERR_BAD_ARG, "null bank");
+    int rc = sync_bank(b);
+    if (rc)
+        return rc;
+    for (int s = 1; s < N_STAGES; s++)
+        if (!b->own_stream[s])
+            b->stream[s] = reinterpret_cast<hipStream_t>(hip_stream);  // SDR_NO_OVERLAP: one stream for all
+    b->stream[S_FFT] = reinterpret_cast<hipStream_t>(hip_stream);
+    return SDR_OK;
+}
+
+int sdr_sync(sdr_bank *b)
+{
+    if (!b)
+        return fail(SDR_ERR_BAD_ARG, "null bank");
+    return sync_bank(b);
+}
+
+// Control calls touch state owned by a pipeline stage: drain the pipeline first (they are rare, and
+// the reference also applies them between frames only, rx/receiver.go:166-172).
+int sdr_attach(sdr_bank *b, int band, int bin, int *listener_id)
+{
+    int rc = check_band(b, band);
+    if (rc)
+        return rc;
+    const sdr_config &c = b->cfg;
+    if (bin < 0 || bin >= c.block_size)
+        return fail(SDR_ERR_BAD_ARG, "bin out of range");
+    // reuse a released slot first, else grow (ListenerPool.BindNext, rx/listener.go:214-229)
+    int lid = -1;
+    for (int i = 0; i < b->n_slots[band]; i++)
+        if (!b->h_slots[(size_t)band * c.max_listeners + i].active) {
+            lid = i;
+            break;
+        }
+    if (lid < 0) {
+        if (b->n_slots[band] >= c.max_listeners)
+            return fail(SDR_ERR_NO_SLOT, "listener pool exhausted");
+        lid = b->n_slots[band]++;
+    }
+    sdr::ListenerSlot &s = b->h_slots[(size_t)band * c.max_listeners + lid];
+    memset(&s, 0, sizeof s);
+    s.active = 1;
+    s.bin = bin;
+    cw::debouncer_init(s.deb, c.signal_debounce);          // NewSpectralDemodulator, cw/spectral.go:25-33
+    cw::decoder_init(s.dec, c.sample_rate, c.block_size);  // NewDecoder, cw/decode.go:131-147
+    cw::decoder_reset(s.dec);                              // Listener.Attach -> demodulator.Reset, listener.go:88
+    s.start_frame = s.tapped_from = (uint32_t)b->total_frames;  // listens from the next frame processed
+    rc = sync_bank(b);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpy(b->slots.p + (size_t)band * c.max_listeners + lid, &s, sizeof s, hipMemcpyHostToDevice));
+    const int32_t tap_bin = bin;
+    HIP_TRY(hipMemcpy(b->tap_bins.p + (size_t)band * c.max_listeners + lid, &tap_bin, sizeof tap_bin, hipMemcpyHostToDevice));
+    b->attach_gen++;
+    if (listener_id)
+        *listener_id = lid;
+    return SDR_OK;
+}
+
+int sdr_detach(sdr_bank *b, int band, int lid)
+{
+    int rc = check_listener(b, band, lid);
+    if (rc)
+        return rc;
+    sdr::ListenerSlot &s = b->h_slots[(size_t)band * b->cfg.max_listeners + lid];
+    if (!s.active)
+        return fail(SDR_ERR_STATE, "listener not attached");
+    s.active = 0;
+    rc = sync_bank(b);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpy(&b->slots.p[(size_t)band * b->cfg.max_listeners + lid].active, &s.active, sizeof(int32_t),
+                      hipMemcpyHostToDevice));
+    const int32_t free_bin = -1;
+    HIP_TRY(hipMemcpy(b->tap_bins.p + (size_t)band * b->cfg.max_listeners + lid, &free_bin, sizeof free_bin,
+                      hipMemcpyHostToDevice));
+    b->attach_gen++;
+    return SDR_OK;
+}
+
+int sdr_attach_at(sdr_bank *b, int band, int bin, int64_t start_frame, int *listener_id)
+{
+    int rc = check_band(b, band);
+    if (rc)
+        return rc;
+    const sdr_config &c = b->cfg;
+    if (bin < 0 || bin >= c.block_size)
+        return fail(SDR_ERR_BAD_ARG, "bin out of range");
+    const int64_t lo = b->listen_pending ? b->pend.first_frame : b->total_frames;
+    if (start_frame < lo || start_frame > b->total_frames)
+        return fail(SDR_ERR_BAD_ARG, "start_frame must lie in the batch that waits for its listen half (or be the next frame)");
+    if (b->graph_ready)
+        return fail(SDR_ERR_STATE, "a graph is captured (sdr_graph_release first)");
+    HIP_TRY(hipSetDevice(b->device));
+    int lid = -1;
+    for (int i = 0; i < b->n_slots[band]; i++)
+        if (!b->h_slots[(size_t)band * c.max_listeners + i].active) {
+            lid = i;
+            break;
+        }
+    if (lid < 0) {
+        if (b->n_slots[band] >= c.max_listeners)
+            return fail(SDR_ERR_NO_SLOT, "listener pool exhausted");
+        lid = b->n_slots[band]++;
+    }
+    sdr::ListenerSlot &s = b->h_slots[(size_t)band * c.max_listeners + lid];
+    memset(&s, 0, sizeof s);
+    s.active = 1;
+    s.bin = bin;
+    cw::debouncer_init(s.deb, c.signal_debounce);
+    cw::decoder_init(s.dec, c.sample_rate, c.block_size);
+    cw::decoder_reset(s.dec);
+    s.start_frame = (uint32_t)start_frame;
+    s.tapped_from = (uint32_t)b->total_frames;  // the FFT of every frame before that has run without this listener
+    // (reaches the device with the next sdr_process_listen / process call: flush_late_attached)
+    b->late_attached.push_back(band * c.max_listeners + lid);
+    b->attach_gen++;
+    if (listener_id)
+        *listener_id = lid;
+    return SDR_OK;
+}
+
+int sdr_listener_count(sdr_bank *b, int band)
+{
+    if (check_band(b, band))
+        return -1;
+    int n = 0;
+    for (int i = 0; i < b->n_slots[band]; i++)
+        n += b->h_slots[(size_t)band * b->cfg.max_listeners + i].active;
+    return n;
+}
+
+int sdr_listener_stop(sdr_bank *b, int band, int lid)
+{
+    int rc = check_listener(b, band, lid);
+    if (rc)
+        return rc;
+    const size_t idx = (size_t)band * b->cfg.max_listeners + lid;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(sdr::launch_listener_stop(b->slots.p + idx, b->morse.p, b->text.p + idx * b->text_cap,
+                                      b->text_frames.p + idx * b->text_cap, b->text_cap,
+                                      (uint32_t)std::max<int64_t>(b->total_frames - 1, 0), b->drops.p, b->stream[S_LISTEN]));
+    return SDR_OK;
+}
+
+int sdr_set_peak_threshold(sdr_bank *b, int band, float threshold)
+{
+    int rc = check_band(b, band);
+    if (rc)
+        return rc;
+    b->h_band_state[band].peak_threshold = threshold;
+    rc = sync_bank(b);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpy(&b->band_state.p[band].peak_threshold, &b->h_band_state[band].peak_threshold, sizeof(float),
+                      hipMemcpyHostToDevice));
+    return SDR_OK;
+}
+
+int sdr_set_edge_width(sdr_bank *b, int edge_width)
+{
+    if (!b)
+        return fail(SDR_ERR_BAD_ARG, "null bank");
+    if (edge_width < 0 || b->cfg.block_size - 2 * edge_width < 10)
+        return fail(SDR_ERR_BAD_ARG, "edge_width leaves fewer than 10 bins");
+    b->edge_width = edge_width;  // a launch parameter: picked up by the next batch
+    return SDR_OK;
+}
+
+int sdr_set_signal_debounce(sdr_bank *b, int band, int debounce)
+{
+    int rc = check_band(b, band);
+    if (rc)
+        return rc;
+    if (b->n_slots[band] == 0)
+        return SDR_OK;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(sdr::launch_set_debounce(b->slots.p + (size_t)band * b->cfg.max_listeners, b->n_slots[band], debounce,
+                                     b->stream[S_LISTEN]));
+    return SDR_OK;
+}
+
+int sdr_set_center_frequency(sdr_bank *b, int band, int64_t frequency)
+{
+    int rc = check_band(b, band);
+    if (rc)
+        return rc;
+    std::lock_guard<std::mutex> guard(b->center_mu);  // (a batch takes its snapshot under it)
+    b->center_frequency[band] = frequency;
+    return SDR_OK;
+}
+
+int sdr_set_find_peaks(sdr_bank *b, int on)
+{
+    if (!b)
+        return fail(SDR_ERR_BAD_ARG, "null bank");
+    b->find_peaks = on ? 1 : 0;
+    return SDR_OK;
+}
+
+int sdr_last_batch_frames(sdr_bank *b) { return b ? b->last_frames : -1; }
+int64_t sdr_total_frames(sdr_bank *b) { return b ? b->total_frames : -1; }
+int sdr_last_batch_chunks(sdr_bank *b) { return b ? b->last_chunks : -1; }
+
+int sdr_profile_enable(sdr_bank *b, int on)
+{
+    if (!b)
+        return fail(SDR_ERR_BAD_ARG, "null bank");
+    int rc = sync_bank(b);
+    if (rc)
+        return rc;
+    b->profiling = on != 0;
+    return SDR_OK;
+}
+
+int sdr_profile_read(sdr_bank *b, int kernel, double *total_ms, int *launches)
+{
+    if (!b || kernel < 0 || kernel >= sdr::K_COUNT)
+        return fail(SDR_ERR_BAD_ARG, "bad kernel id");
+    int rc = sync_bank(b);
+    if (rc)
+        return rc;
+    if (total_ms)
+        *total_ms = b->prof_ms[kernel];
+    if (launches)
+        *launches = b->prof_n[kernel];
+    return SDR_OK;
+}
+
+int sdr_profile_reset(sdr_bank *b)
+{
+    if (!b)
+        return fail(SDR_ERR_BAD_ARG, "null bank");
+    int rc = sync_bank(b);
+    if (rc)
+        return rc;
+    for (int i = 0; i < sdr::K_COUNT; i++) {
+        b->prof_ms[i] = 0;
+        b->prof_n[i] = 0;
+    }
+    return SDR_OK;
+}
+
+#pragma GCC visibility pop
+}  // extern "C"

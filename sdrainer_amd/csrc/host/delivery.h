@@ -14,6 +14,8 @@
 //    into the parked queue - parked batches are always older than anything still in a set;
 //  * everything below `mu` is guarded by it; the mutex is never held across a wait for the device.
 #pragma once
+#include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdint>
@@ -49,7 +51,7 @@ struct DeliveryBackend {
     virtual std::unique_ptr<unsigned char[]> copy_used(const unsigned char *block, const BatchMeta &m) = 0;
     // a block's content into the caller's buffers; anything but SDR_OK leaves the batch undelivered
     virtual int deliver(const unsigned char *block, const BatchMeta &m, void *out) = 0;
-    virtual int fail(int code, const char *msg) = 0;  // records the message for sdr_last_error(), returns code
+    virtual int report(int code, const char *msg) = 0;  // records the message for sdr_last_error(), returns code
 };
 
 class Delivery {
@@ -83,7 +85,7 @@ public:
         on_ = on;
         deliver_next_ = batches_enqueued_ = batch_index;
     }
-    bool on() const { return on_; }
+    bool on() const { return on_.load(std::memory_order_relaxed); }
 
     // --- producer ---
     // the set of batch `batch` (call with the graph window as it is NOW: producer thread, or under the mutex)
@@ -113,7 +115,9 @@ public:
             if (!consumer)
                 break;
             const int64_t before = deliver_next_;
-            cv_.wait_for(guard, std::chrono::microseconds(500));
+            // (system_clock: pthread_cond_timedwait, which every ThreadSanitizer intercepts; the steady-clock wait is
+            // pthread_cond_clockwait, which older ones do not - they then miss the unlock inside the wait)
+            cv_.wait_until(guard, std::chrono::system_clock::now() + std::chrono::microseconds(500));
             if (deliver_next_ == before && S.meta.batch == batch && pollers_waiting_ == 0)
                 break;  // it went away
         }
@@ -125,7 +129,7 @@ public:
         // parked stays sorted by batch: whatever is parked is older than whatever still sits in a set, and the producer
         // parks in batch order - checked here because delivery silently stalls if it is ever violated
         if (!parked_.empty() && parked_.back().meta.batch >= p.meta.batch)
-            return be_->fail(SDR_ERR_STATE, "internal: results parked out of batch order");
+            return be_->report(SDR_ERR_STATE, "internal: results parked out of batch order");
         parked_.push_back(std::move(p));
         S.meta.batch = -1;
         return SDR_OK;
@@ -209,13 +213,13 @@ public:
             }
         } polling(this, wait);
         if (deliver_next_ >= batches_enqueued_)
-            return be_->fail(SDR_ERR_WOULD_BLOCK, "no batch waiting");
+            return be_->report(SDR_ERR_WOULD_BLOCK, "no batch waiting");
         // oldest first: parked batches are older than anything still in a set
         if (!parked_.empty() && parked_.front().meta.batch == deliver_next_)
             return poll_parked(out);
         ResultSet &S = sets_[(size_t)set_index(deliver_next_)];
         if (S.meta.batch != deliver_next_)
-            return be_->fail(SDR_ERR_STATE, "results of the next batch are not where they should be");
+            return be_->report(SDR_ERR_STATE, "results of the next batch are not where they should be");
         for (void *e : {S.ev_listen, S.ev_peaks}) {
             if (wait) {
                 // (the producer must not be held up while this thread waits for the device; the set cannot be reused
@@ -227,12 +231,12 @@ public:
                     return rc;
                 if (S.meta.batch != deliver_next_)  // the producer parked it (or another consumer took it) in the meantime
                     return (!parked_.empty() && parked_.front().meta.batch == deliver_next_) ? poll_parked(out)
-                           : deliver_next_ >= batches_enqueued_ ? be_->fail(SDR_ERR_WOULD_BLOCK, "no batch waiting")
-                                                                : be_->fail(SDR_ERR_WOULD_BLOCK, "the batch went to another consumer; poll again");
+                           : deliver_next_ >= batches_enqueued_ ? be_->report(SDR_ERR_WOULD_BLOCK, "no batch waiting")
+                                                                : be_->report(SDR_ERR_WOULD_BLOCK, "the batch went to another consumer; poll again");
             } else {
                 const int rc = be_->query(e);
                 if (rc == SDR_ERR_WOULD_BLOCK)
-                    return be_->fail(SDR_ERR_WOULD_BLOCK, "the oldest undelivered batch has not finished");
+                    return be_->report(SDR_ERR_WOULD_BLOCK, "the oldest undelivered batch has not finished");
                 if (rc != SDR_OK)
                     return rc;
             }
@@ -256,7 +260,7 @@ public:
         } else {
             const int rc = be_->query(S.ev_peaks);
             if (rc == SDR_ERR_WOULD_BLOCK)
-                return be_->fail(SDR_ERR_WOULD_BLOCK, "the batch's cumulations have not finished");
+                return be_->report(SDR_ERR_WOULD_BLOCK, "the batch's cumulations have not finished");
             if (rc != SDR_OK)
                 return rc;
         }
@@ -282,7 +286,7 @@ private:
     int poll_parked(void *out)  // mu_ held: the oldest undelivered batch sits at the front of the parked queue
     {
         if (parked_.empty() || parked_.front().meta.batch != deliver_next_)
-            return be_->fail(SDR_ERR_STATE, "results of the next batch are not where they should be");
+            return be_->report(SDR_ERR_STATE, "results of the next batch are not where they should be");
         const Parked &p = parked_.front();
         const int rc = be_->deliver(p.block.get(), p.meta, out);
         if (rc == SDR_OK) {
@@ -298,7 +302,7 @@ private:
     std::condition_variable cv_;  // a batch was delivered (a producer about to reuse a set may be waiting for that)
     std::deque<ResultSet> sets_;
     std::deque<Parked> parked_;
-    bool on_ = false;
+    std::atomic<bool> on_{false};
     bool graph_on_ = false;
     int64_t graph_base_ = 0;
     int64_t deliver_next_ = 0;      // batch index poll() hands out next

@@ -45,7 +45,7 @@ inline const std::regex &callsignExp()  // :23-25
 // callsignExp itself on millions of random windows (tests/host/test_rx_host.cpp "cpu").
 inline bool CallsignSearch(const char *s, int n, int *pos, int *len)
 {
-    auto space = [](char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r'; };
+    auto space = [](char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\f' || c == '\r'; };  // Go RE2's \\s is [\\t\\n\\f\\r ] (rx/text_processor.go:24): no \\v
     auto letter = [](char c) { return c >= 'a' && c <= 'z'; };
     auto digit = [](char c) { return c >= '0' && c <= '9'; };
     auto alnum = [&](char c) { return letter(c) || digit(c); };

@@ -261,6 +261,12 @@ __global__ __launch_bounds__(64 * DECODE_WAVES) void k_listen_decode(ListenerSlo
         return;
     slot->deb = deb;
     slot->dec = dec;
+    // Frame numbers are 32 bits and compared as differences: a listener that has started must not keep a start_frame that
+    // falls 2^31 frames behind (config 5 gets there in 100 days and a decode-mode listener has no time-out) - the
+    // difference would turn positive and the listener go deaf.  Once a batch has reached the listener's first frame, both
+    // marks move along with the batches (nothing per listener depends on the absolute number after that).
+    if (skip < n_frames)
+        slot->start_frame = slot->tapped_from = g.frame_base + (uint32_t)n_frames;
     slot->text_count = sink.count;
     // nothing is lost silently: what did not fit is counted bank-wide (rare; the host reads or polls the totals)
     if (sink.dropped != slot->text_dropped)

@@ -693,6 +693,67 @@ __global__ __launch_bounds__(256) void k_thresholds(sdr_frame_rec *__restrict__ 
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// Self-check of what the variance chains assume about the float64 matrix pipe (sdr_self_check, run by sdr_create once per
+// device and process).  variance_consumer_mfma is bit-exact only if v_mfma_f64_4x4x4 with B = 1 adds its four terms to the
+// accumulator one after the other, each step rounded to float64, in k order - established on MI355X silicon by
+// tools/ubench_mfma_f64.hip and written down in no ISA document.  A part, stepping or firmware that evaluates the chain
+// any other way (a tree, one rounding at the end, accumulator last) would shift variances by an ulp now and then and with
+// them thresholds and keying edges, silently.  So: one wave feeds the pipe 64 dependent instructions of sixteen chains
+// each (1024 quadruples) of wide-range terms - exponents spread over 2^-40 .. 2^40 and both signs, where every other
+// association rounds differently - and compares the accumulator after EVERY instruction with the same chain on the
+// vector ALU (v_add_f64, program order).  Any difference fails the creation of the bank: there is no second code path.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double probe_term(unsigned chain, unsigned round, unsigned k)
+{
+    unsigned long long h = ((unsigned long long)(round * 16u + chain) << 2 | k) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+    h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 32;
+    const int e = (int)((h >> 52) % 81u) - 40;                      // binary exponent
+    const unsigned long long mant = h & 0x000FFFFFFFFFFFFFull;       // 52 random mantissa bits
+    const unsigned long long sign = (h >> 51) & 1ull ? 0x8000000000000000ull : 0ull;
+    return __longlong_as_double((long long)(sign | ((unsigned long long)(1023 + e) << 52) | mant));
+}
+
+// order: 0 = the chain the library assumes; 1 / 2 = a pairwise tree / the accumulator added last - what the pipe must NOT
+// compute (SDR_SELF_CHECK_ORDER, tests only: the check has to fail against them, or it checks nothing)
+__global__ __launch_bounds__(64) void k_mfma_order_probe(unsigned *__restrict__ mismatches, int order)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    // operand layout (probed, see variance_consumer_mfma): lane L supplies term k = L >> 4 of chain L & 15; the sum of
+    // chain c sits in lanes 16 (c & 3) + 4 (c >> 2) + j, j = 0..3
+    const unsigned a_chain = lane & 15u, a_k = lane >> 4;
+    const unsigned my_chain = 4u * ((lane >> 2) & 3u) + (lane >> 4);
+    double acc = 0.0;
+    unsigned bad = 0;
+    for (unsigned r = 0; r < 64u; r++) {
+        const double before = acc;
+        acc = __builtin_amdgcn_mfma_f64_4x4x4f64(probe_term(a_chain, r, a_k), 1.0, acc, 0, 0, 0);
+        double t[4];
+        for (unsigned k = 0; k < 4u; k++) {
+            t[k] = probe_term(my_chain, r, k);
+            asm volatile("" : "+v"(t[k]));  // (the additions below stay as written)
+        }
+        double want;
+        if (order == 0)
+            want = (((before + t[0]) + t[1]) + t[2]) + t[3];  // dsp/fft.go:246-248: sum += term, one rounding per step
+        else if (order == 1)
+            want = before + ((t[0] + t[1]) + (t[2] + t[3]));
+        else
+            want = (((t[0] + t[1]) + t[2]) + t[3]) + before;
+        bad += __double_as_longlong(acc) != __double_as_longlong(want) ? 1u : 0u;
+    }
+    if (bad)
+        atomicAdd(mismatches, bad);
+}
+
+hipError_t launch_mfma_order_probe(unsigned *mismatches, int order, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_mfma_order_probe, dim3(1), dim3(64), 0, stream, mismatches, order);
+    return hipGetLastError();
+}
+
 hipError_t launch_window_means(const float *psd, double *win_mean, NoiseGeom g, int n_frames, int n_bands, int stride,
                                hipStream_t stream)
 {

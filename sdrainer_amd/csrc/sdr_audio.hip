@@ -14,7 +14,7 @@
 #include "gomath.h"
 
 namespace sdr {
-int set_error(int code, const char *msg);  // sdr_capi.hip: feeds sdr_last_error()
+int set_error(int code, const char *msg);  // capi_bank.hip: feeds sdr_last_error()
 }
 
 namespace {

@@ -132,6 +132,7 @@ hipError_t launch_window_means(const float *psd, double *win_mean, NoiseGeom g, 
                                hipStream_t stream);
 hipError_t launch_noise_stats(const float *psd, const double *win_mean, sdr_frame_rec *recs, NoiseGeom g, int n_frames,
                               int n_bands, int stride, hipStream_t stream);
+hipError_t launch_mfma_order_probe(unsigned *mismatches, int order, hipStream_t stream);  // k_noise.hip: sdr_self_check
 hipError_t launch_thresholds(sdr_frame_rec *recs, BandState *st, int n_frames, int n_bands, int stride,
                              hipStream_t stream);
 hipError_t launch_listen_gather(const float *tap, const float *psd, const sdr_frame_rec *recs, const ListenerSlot *slots, const void *db_tab,

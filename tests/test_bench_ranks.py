@@ -63,9 +63,33 @@ def test_bench_launches_its_own_ranks():
     assert res["n_gpus"] == 2 and res["steps"] == 5
     d = res["config"]["distributed"]
     assert d["world_size"] == 2 and d["backend"] == "gloo" and d["launched_by"] == "bench.py itself"
+    # every rank's own rate is in the line (value comes from the max over ranks: a straggler must be visible)
+    pr = res["config"]["per_rank"]
+    assert len(pr["ms_per_step"]) == 2 and len(pr["value"]) == 2 and pr["value_min"] <= pr["value_max"]
+    assert max(pr["ms_per_step"]) <= res["ms_per_step"] * 1.001
+    assert res["config"]["cpu_affinity_rank0"]["policy"]
     # a world that is not the one asked for is refused, never reported under another n_gpus
     env1 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                         "--no-cpu-baseline"], env=env1, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                        timeout=600)
     assert q.returncode != 0 and "WORLD_SIZE=1" in (q.stderr + q.stdout)
+
+
+def test_two_rank_bench_over_rccl():
+    """The real thing where there are two GPUs: `python bench.py --gpus 2` over the nccl (= RCCL) backend, one rank per
+    GPU - sharding.broadcast_config's collective travels over xGMI.  Skipped on a one-GPU box (the count is read in a
+    child process: this one must not touch the GPU before it starts its ranks)."""
+    n = int(subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True,
+                           timeout=600).stdout.strip() or 0)
+    if n < 2:
+        pytest.skip(f"{n} GPU(s) visible: RCCL needs one rank per GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "SDR_DIST_BACKEND",
+                                                              "SDR_FORCE_DEVICE")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--frames", "512", "--settle-ms", "0", "--no-cpu-baseline"], env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert res["n_gpus"] == 2 and res["config"]["distributed"]["backend"] == "nccl"
+    assert len(res["config"]["per_rank"]["value"]) == 2

@@ -981,7 +981,7 @@ def test_listeners_bound_inside_a_batch(capi):
 def test_many_batches_with_an_erratic_consumer(capi, mode):
     """Eleven replays of six batches (the four groups of buffer sets graph mode rotates through are each used three
     times; eager: 66 batches over the six ring sets) while a consumer thread polls in fits and starts - so the producer
-    finds unpolled batches in the sets it wants back and either yields to the consumer or parks them (sdr_capi.hip
+    finds unpolled batches in the sets it wants back and either yields to the consumer or parks them (host/delivery.h
     park_results).  Every batch must arrive once, in order, and be the oracle's, whichever way it went."""
     import random
     import threading

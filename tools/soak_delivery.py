@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development aid: a long run of the delivery machinery under an erratic consumer - thousands of batches, eager and as
 graph replays, the consumer polling in fits and starts so that the producer keeps finding unpolled batches in the sets it
-wants back (yield-or-park, sdr_capi.hip park_results).  No oracle at this length: the two modes must deliver the same
+wants back (yield-or-park, host/delivery.h Delivery::park).  No oracle at this length: the two modes must deliver the same
 stream (a running hash over every batch's edges, runes and peaks, in order) and nothing may be dropped or reordered.
   python tools/soak_delivery.py [replays]"""
 import hashlib
