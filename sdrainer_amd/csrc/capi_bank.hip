@@ -136,7 +136,7 @@ int sdr_self_check(int device_id)
 
 namespace {
 // once per device and process; the verdict is kept (a failing part fails every creation)
-int self_check_once(int device_id)
+static int self_check_once(int device_id)
 {
     constexpr int kMax = 64;
     static std::mutex mu;
