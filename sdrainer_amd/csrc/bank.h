@@ -179,6 +179,7 @@ struct sdr_bank {
     int64_t total_frames = 0;
     int64_t batch_index = 0;
     int last_set = 0, last_frames = 0, last_chunks = 0, last_count0 = 0;
+    int last_carry_in = 0;  // which carry buffer the last batch's first cumulation started from (exact rows on demand)
     int edge_width = 0;
     int find_peaks = 1;
     bool failed = false;  // a HIP call failed in the middle of a launch sequence: device state is unknown

@@ -333,6 +333,7 @@ int sdr_graph_launch(sdr_bank *b, const float *const *iq_dev)
         b->last_frames = n_frames;
         b->last_chunks = meta[k].chunks;
         b->last_count0 = meta[k].count0;
+        b->last_carry_in = pack.c[k].carry_in;
         b->batch_index++;
     }
     if (!b->results_on)

@@ -7,7 +7,7 @@
 //
 //   fft     k_fft_psd(i)                                          (the caller's stream)
 //   noise   k_window_means(i) -> k_noise_stats(i)
-//   peaks   k_thresholds(i) -> k_cumulate(i) -> k_find_peaks(i) (-> k_pack_peaks(i))
+//   peaks   k_thresholds(i) -> k_cum_bound(i), k_cumulate(i) -> k_find_peaks(i) (-> k_pack_peaks(i))
 //   listen  k_listen_gather(i) -> k_listen_decode(i) (-> k_pack_listen(i))
 //
 // Batch i's per-batch buffers (psd, tap, frame records, keying bits, peaks ...) live in set i % RING, and one event per
@@ -375,8 +375,11 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         SDR_AFTER(sdr::K_FIND_PEAKS, sdr::K_THRESHOLDS);  // needs the completing frame's peak threshold
         ProfScope ps(b, sdr::K_FIND_PEAKS, stream_of(sdr::K_FIND_PEAKS));
         sdr::PeakGeom pg{N, stride, count0, b->max_chunks, c.max_peaks};
-        SDR_LAUNCH(sdr::K_FIND_PEAKS, sdr::launch_find_peaks(S.cum_out.p, S.recs.p, S.dev_peaks.p, S.peak_counts.p, cur, pg, n_frames,
-                                                             n_chunks, B, stream_of(sdr::K_FIND_PEAKS)));
+        // (reads the carry buffer this batch's cumulation started from: the next batch's k_cumulate, which writes that
+        // buffer, follows on the same stream)
+        SDR_LAUNCH(sdr::K_FIND_PEAKS, sdr::launch_find_peaks(S.cum_out.p, S.psd.p, b->db_tab.p, b->carry[0].p, b->carry[1].p, b->carry_cur, S.recs.p,
+                                                             S.dev_peaks.p, S.peak_counts.p, cur, pg, n_frames, n_chunks, B,
+                                                             stream_of(sdr::K_FIND_PEAKS)));
     }
     if (b->results_on && SDR_ON(sdr::K_FIND_PEAKS)) {
         SDR_ARM(sdr::K_FIND_PEAKS);
@@ -410,6 +413,7 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     // every launch of the batch is enqueued: commit the host's view of the carried state in one go.
     // The carry buffer flips only when this batch wrote a new partial cumulation; if the batch ended
     // exactly on a chunk boundary the next batch starts from zero (count0 == 0 ignores the carry)
+    b->last_carry_in = b->carry_cur;
     if (new_count != 0)
         b->carry_cur ^= 1;
     b->cum_count = new_count;

@@ -22,6 +22,24 @@ size_t utf8_encode(uint32_t r, char *out)
     out[2] = (char)(0x80 | (r & 0x3F));
     return 3;
 }
+
+// Completed cumulation `chunk` of the last batch, exact in every bin.  The pipeline keeps a cumulation exact only where
+// FindPeaks reads it (k_peaks.hip: an upper bound elsewhere); a reader gets the whole row recomputed from the batch's
+// retained psd rows and the carry it started from - the same kernel that carries an open cumulation across batches.
+// (pipeline drained by the caller)
+int exact_cumulation_row(sdr_bank *b, int band, int chunk, float *out)
+{
+    const sdr_config &c = b->cfg;
+    const size_t N = (size_t)c.block_size;
+    const BatchSet &S = b->set[b->last_set];
+    HIP_TRY(hipSetDevice(b->device));
+    const sdr::CumGeom cg{c.block_size, c.max_batch_frames, b->last_frames, b->last_count0, b->max_chunks};
+    HIP_TRY(sdr::launch_cumulation_row(S.psd.p + (size_t)band * c.max_batch_frames * N, b->db_tab.p, b->carry[b->last_carry_in].p + (size_t)band * N,
+                                       b->spectrum_row.p, cg, chunk, b->stream[S_FFT]));
+    HIP_TRY(hipStreamSynchronize(b->stream[S_FFT]));
+    HIP_TRY(hipMemcpy(out, b->spectrum_row.p, sizeof(float) * N, hipMemcpyDeviceToHost));
+    return SDR_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -82,9 +100,7 @@ int sdr_read_cumulation(sdr_bank *b, int band, int chunk, float *out)
     rc = sync_bank(b);
     if (rc)
         return rc;
-    HIP_TRY(hipMemcpy(out, b->set[b->last_set].cum_out.p + ((size_t)band * b->max_chunks + chunk) * b->cfg.block_size,
-                      sizeof(float) * (size_t)b->cfg.block_size, hipMemcpyDeviceToHost));
-    return SDR_OK;
+    return exact_cumulation_row(b, band, chunk, out);
 }
 
 int sdr_read_text(sdr_bank *b, int band, int lid, char *out, int max_bytes, int *n_bytes)
@@ -293,8 +309,8 @@ int sdr_scope_read_spectral(sdr_bank *b, int band, int chunk, sdr_scope_spectral
     }
     if (values) {
         std::vector<float> cum((size_t)N);
-        HIP_TRY(hipMemcpy(cum.data(), S.cum_out.p + ((size_t)band * b->max_chunks + chunk) * N, sizeof(float) * (size_t)N,
-                          hipMemcpyDeviceToHost));
+        if ((rc = exact_cumulation_row(b, band, chunk, cum.data())))
+            return rc;
         const double scale = 1.0 / (double)SDR_CUMULATION_SIZE;  // scaledValuesForScope(cumulation, 1.0/float64(cumulationSize))
         for (int i = 0; i < std::min(N, max_values); i++)
             values[i] = (double)cum[i] * scale;

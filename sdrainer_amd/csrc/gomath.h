@@ -169,6 +169,48 @@ inline void build_db_tables(int logn, void *blob)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Upper bound of a cumulation (k_peaks.hip k_cum_bound; tests/emu/emu_cum_bound.cpp checks every claim below on the CPU).
+// A term of the cumulation is s = fl32(fl32(10 log10(20 psd / N^2)) + 120) (dsp/fft.go:79-81, rx/receiver.go:377).  For
+// psd = m 2^E, 1 <= m < 2:  log2(psd) = E + log2(m) <= E + (m - 1) + 0.0861, and the float32 bits of psd, shifted right
+// by 16, are (E + 127) 128 + floor(128 (m - 1)).  With units(psd) = max(bits >> 16, 128) + 1 (the max: zero and subnormal
+// psd count as 2^-126, which is larger):
+//     s <= A units / 128 + per_frame,   A = 10 log10 2,   per_frame = A (-127 + 0.0861) + 10 log10 20 - 20 log10 N + 120 + 2e-5
+// (2e-5: the two float32 roundings of a term - it is below 512 in magnitude - and the reference's own logarithm, 1e-13).
+// The ordered float32 sum of up to 100 such terms on top of a carry exceeds the real sum by less than 0.2 (|partial
+// sums| < 2^16 for any finite psd: a hundred additions, half an ulp of 2^-8 each); the bound is formed in float64 and
+// given 0.05 more before it is rounded to float32.  A column that holds an infinite or NaN psd (or a set sign bit: no sum
+// of squares has one) gets the bound +infinity: its exact evaluation decides, as the reference's would.
+// ---------------------------------------------------------------------------------------------
+SDR_HD inline uint32_t cum_bound_units(float psd)
+{
+    uint32_t bits;
+    __builtin_memcpy(&bits, &psd, sizeof bits);
+    const uint32_t hw = bits >> 16;
+    return (hw < 128u ? 128u : hw) + 1u;
+}
+SDR_HD inline bool cum_bound_special(float psd)  // infinity, NaN, sign bit: (bits >> 16) >= 0x7f80
+{
+    uint32_t bits;
+    __builtin_memcpy(&bits, &psd, sizeof bits);
+    return (bits >> 16) >= 0x7f80u;
+}
+// host: the constants for block size n, rounded so that the bound can only grow
+inline void cum_bound_constants(int n, double *a128, double *per_frame)
+{
+    const double A_up = 3.0102999566398121, A_down = 3.0102999566398116;  // 10 log10(2) = 3.010299956639811952...
+    const double log2_slack = 0.0861;  // > max over m in [1, 2) of log2(m) - (m - 1) = 0.086071...
+    const double K = 10.0 * ::log10(20.0) - 20.0 * ::log10((double)n);
+    *a128 = A_up / 128.0;
+    // (A multiplies a NEGATIVE number here: the smaller value keeps the product an upper bound)
+    *per_frame = A_down * (-127.0 + log2_slack) + K + 120.0 + 2e-5 + 1e-9;
+}
+// the bound of carry + (sum of `frames` terms whose units add up to `units`), as a float32
+SDR_HD inline float cum_bound(double carry, uint32_t units, int frames, double a128, double per_frame, bool special)
+{
+    return special ? __builtin_inff() : (float)(carry + a128 * (double)units + (double)frames * per_frame + 0.25);
+}
+
 // (host only)
 // math.Sincos (src/math/sincos.go), |x| < 2^29 branch.  Host only: twiddle tables are built once on
 // the host and uploaded, exactly as go-dsp caches them.

@@ -411,7 +411,9 @@ constexpr int kMaxLdsTap = 4096;  // listeners per band the LDS tap holds bins f
 // MEASURED (round 4, profiles/r04_fft_experiments.txt): no gain before exchange 0 (0.162 against 0.162 ms), 0.205 -
 // 0.214 ms before exchanges 1 / 2, any distance, nt or not: the warm-up is itself a 32 MB burst of the whole chip, the
 // twiddle loads behind it return behind it, and what it leaves in the Infinity Cache comes back no faster than from HBM
-// through the same fabric (L2 cannot hold a generation: 32 CUs x 128 KB = its 4 MB).  The burst is the cost, and only
+// through the same fabric (L2 cannot hold a generation: 32 CUs x 128 KB = its 4 MB); issued at the very end of the
+// workgroup (SDR_FFT_PF_AT=3: nothing of it waits behind the warm-up) 0.171 - 0.176 ms - the workgroup cannot leave before
+// its LDS-DMA has landed.  The burst is the cost, and only
 // spreading the requests over the frame - which needs somewhere on the CU to put them - would remove it.
 #if !defined(SDR_FFT_PF_DIST)
 #define SDR_FFT_PF_DIST 0
@@ -604,6 +606,14 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, (fft64::Plan<LOGN>::T >= 512 
             if (lds_tap)
                 __syncthreads();  // a wave-local last exchange fences only its own wave; the row goes everywhere
         store_psd<LOGN, !MULTI>(xr, xi, t, psd + (out_band + frame) * PL::N, smem, lds_tap);
+        if constexpr (!MULTI && SDR_FFT_PF_DIST > 0 && SDR_FFT_PF_AT == 3) {
+            // (behind the frame's last vector loads: nothing of this workgroup waits behind the warm-up any more)
+            if (frame + SDR_FFT_PF_DIST < n_frames) {
+                const rsrc_t nrs = make_rsrc(iq + (in_band + frame + SDR_FFT_PF_DIST) * PL::N * 2, PL::N * 8u);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(nrs, (__attribute__((address_space(3))) void *)(pf_sink + wave * 256), 4,
+                                                         (unsigned)(t & 63) * 128u, wave * 8192, 0, SDR_FFT_PF_AUX);
+            }
+        }
         // (behind the DMA and the stores, so that its two dependent loads delay neither: the oldest waves - the
         // ones that tap - reach the end of a frame microseconds before the youngest)
         if constexpr (MULTI) {

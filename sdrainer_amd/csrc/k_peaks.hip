@@ -2,6 +2,7 @@
 // completed cumulation.  Compiled with -ffp-contract=off (see gomath.h).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <mutex>
 
 #include "../../include/sdrainer_hip.h"
@@ -13,14 +14,30 @@
 namespace sdr {
 
 // ---------------------------------------------------------------------------------------------
-// k_cumulate — cumulation[i] += spectrum[i] (rx/receiver.go:404-407): a float32 sum in frame order, where
-// spectrum[i] = MagnitudeIndB(...) + dBmShift (dsp/fft.go:79-81, rx/receiver.go:377) is evaluated here from the
-// float32 psd the FFT kernel stored: the projection is a pure function of that value, and this is the only
-// place that needs it for every bin.  One thread per bin, lanes on neighbouring bins (coalesced 256-byte rows),
-// ten loads in flight, then ten ORDERED adds.  The certified table shortcut of gomath.h settles all but about
-// three values in 10^5; the rest take the literal Go algorithm in a (rare, divergent) branch.
-// Slot 0 continues the cumulation carried over from the previous batch; a slot that reaches 100
-// frames is written out for the peak scan, an incomplete last slot becomes the next carry.
+// The cumulation: cumulation[i] += spectrum[i] (rx/receiver.go:404-407), a float32 sum in frame order over 100 frames,
+// where spectrum[i] = MagnitudeIndB(...) + dBmShift (dsp/fft.go:79-81, rx/receiver.go:377) is evaluated from the float32
+// psd the FFT kernel stored (the projection is a pure function of that value).
+//
+// EXACT WHERE IT IS CONSUMED.  The only consumer of a completed cumulation on the hot path is FindPeaks (dsp/fft.go:
+// 254-285): which bins have cumulation / 100 > threshold, and the values inside those runs and right beside their maxima.
+// A noise bin sits 15 dB under that threshold.  Rounds 1-3 evaluated the certified logarithm for every bin of every
+// frame - 33.5 M of them per 2048-frame batch, 15 % of all CU time on the chip - to learn, for 98 % of the bins, that
+// they are not above the threshold.  Now:
+//   k_cum_bound   an UPPER BOUND of every completed cumulation from the psd words' top halves alone - for psd = m 2^E,
+//                 log2(psd) <= E + (m - 1) + 0.0861 and the float32 bits >> 16 ARE (E + 127) 128 + floor(128 (m - 1)):
+//                 one shift, one max, one add per value, 16-byte loads, nothing but the psd stream;
+//   k_find_peaks  compares bound / 100 with the threshold exactly as FindPeaks compares the cumulation (monotone
+//                 float32 operations: a bin whose BOUND is not above is not above), computes the literal ordered float32
+//                 sum of certified dB values for the bins that are - and their neighbours, which PeakCenterCorrection
+//                 reads - and scans the row with those in place: the same runs, maxima and centre values, bit for bit;
+//   k_cumulate    the exact kernel of rounds 1-3: the cumulation still open at the end of a batch (its carry into the
+//                 next batch is exact for every bin: which bins will matter is not known yet), and whole rows on demand
+//                 (sdr_read_cumulation, the scope tap).
+// The bound (proof in DESIGN.md section 5): each term is fl32(fl32(10 log10(20 psd / N^2)) + 120) <= A U + K + 120 + 2e-5
+// with U the linear bound of log2 above, A = 10 log10 2, K = 10 log10 20 - 20 log10 N; the ordered float32 sum of 100
+// such terms (|partial sums| < 2^16 for any finite psd) exceeds the real sum by less than 0.2; the bound is evaluated in
+// float64 with 0.05 to spare before it is rounded to float32.  Zero / subnormal psd count as 2^-126 (their dB is lower), infinities and
+// NaNs give a huge bound (candidates: the exact evaluation decides, as the reference's would).
 // ---------------------------------------------------------------------------------------------
 // the literal Go algorithm, out of line: it is rare, and inlined its float64 temporaries set the kernel's register count
 __device__ __attribute__((noinline)) float db_slow(float psd, double inv_n2) { return gomath::psd_value_in_db(psd, inv_n2); }
@@ -33,82 +50,45 @@ __device__ __forceinline__ float spectrum_value(float psd, gomath::DbTables t, d
     return db + (float)SDR_DBM_SHIFT;
 }
 
-// 256-thread workgroups, 20 KB of LDS (the tables), at most 64 VGPRs: eight waves per SIMD.  (A 32-VGPR build -
-// what a CU has left beside a resident k_fft_psd workgroup, so that the two could share a CU - measured the same
-// step, so the registers go to a software pipeline instead.)
 #if !defined(SDR_CUM_THREADS)
 #define SDR_CUM_THREADS 256
 #endif
 #if !defined(SDR_CUM_U)
 #define SDR_CUM_U 4
 #endif
+#if !defined(SDR_REFINE_U)
+#define SDR_REFINE_U 16
+#endif
 #if !defined(SDR_CUM_VGPR)
 #define SDR_CUM_VGPR 32
 #endif
-__global__ __launch_bounds__(SDR_CUM_THREADS) __attribute__((amdgpu_num_vgpr(SDR_CUM_VGPR))) void k_cumulate(const float *__restrict__ psd, const void *__restrict__ db_tab,
-                                                   float *__restrict__ carry0, float *__restrict__ carry1, int carry_in_arg,
-                                                   float *__restrict__ cum_out, const BatchCursor *__restrict__ cur, CumGeom g,
-                                                   double inv_n2)
+
+// acc + the ordered float32 sum of spectrum(psd[base + off + k n]) for k = 0 .. count-1 (one column of the psd array,
+// frame order): the certified table shortcut of gomath.h settles all but about three values in 10^5, the rest take
+// the literal Go algorithm in a rare, divergent branch.  U loads are in flight while the previous U values are projected
+// (independent float64 chains) and added in order.
+template <int U = SDR_CUM_U>
+__device__ __forceinline__ float cum_exact_column(const float *__restrict__ base, unsigned off, unsigned n, int count, float acc,
+                                                  gomath::DbTables tab, double inv_n2)
 {
-    int carry_sel = carry_in_arg;
-    if (cur) {  // graph replay: this batch's cumulation phase comes from device memory; the grid covers every slot a
-        g.count0 = cur->count0;  // batch of this length can have, surplus workgroups leave
-        carry_sel = cur->carry_in;
-        const int first = SDR_CUMULATION_SIZE - g.count0;
-        const int slots = g.n_frames <= first ? 1 : 1 + (g.n_frames - first + SDR_CUMULATION_SIZE - 1) / SDR_CUMULATION_SIZE;
-        if ((int)blockIdx.y >= slots)
-            return;
-    }
-    const float *__restrict__ carry_in = carry_sel ? carry1 : carry0;
-    float *__restrict__ carry_out = carry_sel ? carry0 : carry1;
-    __shared__ __attribute__((aligned(16))) unsigned char s_tab[gomath::kDbTabBytes];
-    {
-        const uint4 *src = static_cast<const uint4 *>(db_tab);
-        uint4 *dst = reinterpret_cast<uint4 *>(s_tab);
-        for (int i = threadIdx.x; i < gomath::kDbTabBytes / 16; i += blockDim.x)
-            dst[i] = src[i];
-    }
-    __syncthreads();
-    const gomath::DbTables tab = gomath::db_tables(s_tab);
-    const int bin = blockIdx.x * blockDim.x + threadIdx.x;
-    if (bin >= g.n)
-        return;
-    const int slot = blockIdx.y, band = blockIdx.z;
-    // frames of this slot: slot 0 takes (100 - count0) frames, later slots 100 each
-    const int first_len = SDR_CUMULATION_SIZE - g.count0;
-    const int begin = slot == 0 ? 0 : first_len + (slot - 1) * SDR_CUMULATION_SIZE;
-    const int len = slot == 0 ? first_len : SDR_CUMULATION_SIZE;
-    const int end = min(begin + len, g.n_frames);
-    float acc = 0.f;
-    if (slot == 0 && g.count0 > 0)
-        acc = carry_in[(size_t)band * g.n + bin];
-    // (wave-uniform base in SGPRs + one 32-bit per-lane offset)
-    const float *__restrict__ base = psd + (size_t)band * g.stride * g.n;
-    const unsigned n = (unsigned)g.n;
-    unsigned off = (unsigned)begin * n + (unsigned)bin;
-    constexpr int U = SDR_CUM_U;  // loads in flight, and independent dB evaluations between two ordered adds
-    int f = begin;
-    // software pipeline: the next U values are on their way while these U are projected and added
+    int f = 0;
     float v[U], nv[U];
-    const bool any = f + U <= end;
-    if (any) {
+    if (U <= count) {
 #pragma unroll
         for (int k = 0; k < U; k++)
             nv[k] = __builtin_nontemporal_load(base + (off + (unsigned)k * n));
     }
-    for (; f + U <= end; f += U) {
+    for (; f + U <= count; f += U) {
 #pragma unroll
         for (int k = 0; k < U; k++)
             v[k] = nv[k];
         off += U * n;
-        if (f + 2 * U <= end) {
+        if (f + 2 * U <= count) {
 #pragma unroll
             for (int k = 0; k < U; k++)
                 nv[k] = __builtin_nontemporal_load(base + (off + (unsigned)k * n));
         }
         float db[U];
-        // the shortcut for all of them, straight-line (independent float64 chains); the literal algorithm only
-        // where the certificate failed - about one iteration in a few hundred has such a lane
         bool bad = false;
 #pragma unroll
         for (int k = 0; k < U; k++)
@@ -125,14 +105,156 @@ __global__ __launch_bounds__(SDR_CUM_THREADS) __attribute__((amdgpu_num_vgpr(SDR
         for (int k = 0; k < U; k++)
             acc += db[k] + (float)SDR_DBM_SHIFT;  // MagnitudeIndB + dBmShift (float32 add), then the ordered sum
     }
-    for (; f < end; f++, off += n)
+    for (; f < count; f++, off += n)
         acc += spectrum_value(__builtin_nontemporal_load(base + off), tab, inv_n2);
+    return acc;
+}
+
+// frames [begin, begin + len) of slot `slot` of a batch that starts at cumulationCount count0: slot 0 takes the
+// (100 - count0) frames that complete the cumulation carried in, later slots 100 each
+__device__ __forceinline__ void cum_slot_frames(int slot, int count0, int *begin, int *len)
+{
+    const int first_len = SDR_CUMULATION_SIZE - count0;
+    *begin = slot == 0 ? 0 : first_len + (slot - 1) * SDR_CUMULATION_SIZE;
+    *len = slot == 0 ? first_len : SDR_CUMULATION_SIZE;
+}
+
+// k_cumulate - the exact cumulation, one thread per bin, lanes on neighbouring bins (coalesced 256-byte rows).
+//   only_open = 1: just the cumulation the batch leaves open (the carry into the next batch); grid.y = 1
+//   only_open = 0: slot = slot_base + blockIdx.y, complete slots to cum_out (or to row_out: sdr_read_cumulation, one band)
+// 256-thread workgroups, 20 KB of LDS (the tables), at most SDR_CUM_VGPR VGPRs.
+__global__ __launch_bounds__(SDR_CUM_THREADS) __attribute__((amdgpu_num_vgpr(SDR_CUM_VGPR))) void k_cumulate(const float *__restrict__ psd, const void *__restrict__ db_tab,
+                                                   float *__restrict__ carry0, float *__restrict__ carry1, int carry_in_arg,
+                                                   float *__restrict__ cum_out, float *__restrict__ row_out, const BatchCursor *__restrict__ cur, CumGeom g,
+                                                   int only_open, int slot_base, double inv_n2)
+{
+    int carry_sel = carry_in_arg;
+    if (cur) {  // graph replay: this batch's cumulation phase comes from device memory
+        g.count0 = cur->count0;
+        carry_sel = cur->carry_in;
+    }
+    const int first = SDR_CUMULATION_SIZE - g.count0;
+    const int slots = g.n_frames <= first ? 1 : 1 + (g.n_frames - first + SDR_CUMULATION_SIZE - 1) / SDR_CUMULATION_SIZE;
+    const int slot = only_open ? slots - 1 : slot_base + (int)blockIdx.y;
+    if (slot >= slots)
+        return;
+    int begin, len;
+    cum_slot_frames(slot, g.count0, &begin, &len);
     const bool complete = (begin + len) <= g.n_frames;
-    if (complete) {
-        // completed chunk index == slot (slot 0 completes first if it completes at all)
-        cum_out[((size_t)band * g.max_chunks + slot) * g.n + bin] = acc;
-    } else {
+    if (only_open && complete)
+        return;  // the batch ends on a boundary: nothing is carried
+    const float *__restrict__ carry_in = carry_sel ? carry1 : carry0;
+    float *__restrict__ carry_out = carry_sel ? carry0 : carry1;
+    __shared__ __attribute__((aligned(16))) unsigned char s_tab[gomath::kDbTabBytes];
+    {
+        const uint4 *src = static_cast<const uint4 *>(db_tab);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_tab);
+        for (int i = threadIdx.x; i < gomath::kDbTabBytes / 16; i += blockDim.x)
+            dst[i] = src[i];
+    }
+    __syncthreads();
+    const gomath::DbTables tab = gomath::db_tables(s_tab);
+    const int bin = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bin >= g.n)
+        return;
+    const int band = blockIdx.z;
+    const int end = min(begin + len, g.n_frames);
+    float acc = 0.f;
+    if (slot == 0 && g.count0 > 0)
+        acc = carry_in[(size_t)band * g.n + bin];
+    // (wave-uniform base in SGPRs + one 32-bit per-lane offset)
+    const float *__restrict__ base = psd + (size_t)band * g.stride * g.n;
+    acc = cum_exact_column(base, (unsigned)begin * (unsigned)g.n + (unsigned)bin, (unsigned)g.n, end - begin, acc, tab, inv_n2);
+    if (row_out)
+        row_out[bin] = acc;
+    else if (complete)
+        cum_out[((size_t)band * g.max_chunks + slot) * g.n + bin] = acc;  // completed chunk index == slot
+    else
         carry_out[(size_t)band * g.n + bin] = acc;
+}
+
+// k_cum_bound - an upper bound of every cumulation the batch completes (see the head of this section).  The kernel is
+// nothing but the psd stream - a shift, a max and an add per value - so what it costs the pipeline is the CU time it
+// holds while the stream goes by, and k_fft_psd needs whole CUs: spread over the chip the way a grid of small workgroups
+// is, it held all 256 CUs for as long as the exact kernel did (0.10 ms per 8192 frames, round 4's first version).  So it
+// runs as FEW, FAT, PERSISTENT workgroups: 1024 threads x four neighbouring bins (16-byte loads, a 16 KB row segment per
+// wave-instruction round) x U frames in flight = 128 KB per workgroup on its way, one workgroup per CU (its LDS
+// reservation keeps a second one and the FFT's off that CU, and the dispatcher deals workgroups to different CUs), about
+// a quarter of the chip - each of them at what one CU's memory pipeline delivers - while the other CUs stay with the FFT.
+// Work item = (band, slot, block of 4096 bins); workgroup w takes items w, w + grid, ...
+// a128 = 10 log10(2) / 128; per_frame = what every frame adds beyond its top-half sum (gomath.h cum_bound_constants).
+#if !defined(SDR_BOUND_U)
+#define SDR_BOUND_U 8
+#endif
+#if !defined(SDR_BOUND_WGS)
+#define SDR_BOUND_WGS 64
+#endif
+constexpr int kBoundThreads = 1024;
+constexpr int kBoundLdsBytes = 96 * 1024;  // (reserved, not used: one workgroup per CU)
+typedef unsigned bound_u4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(kBoundThreads) void k_cum_bound(const float *__restrict__ psd, const float *__restrict__ carry0, const float *__restrict__ carry1,
+                                                             int carry_in_arg, float *__restrict__ cum_out, const BatchCursor *__restrict__ cur, CumGeom g,
+                                                             int n_slots, int n_bands, double a128, double per_frame)
+{
+    int carry_sel = carry_in_arg;
+    if (cur) {
+        g.count0 = cur->count0;
+        carry_sel = cur->carry_in;
+    }
+    const float *__restrict__ carry_in = carry_sel ? carry1 : carry0;
+    const int blocks = (g.n / 4 + (int)blockDim.x - 1) / (int)blockDim.x;  // column blocks per row
+    const int items = n_bands * n_slots * blocks;
+    constexpr int U = SDR_BOUND_U;
+    const bound_u4 floor_hw = {128u, 128u, 128u, 128u};  // zero / subnormal psd count as 2^-126
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {  // (workgroup-uniform)
+        const int cb = item % blocks, slot = (item / blocks) % n_slots, band = item / (blocks * n_slots);
+        int begin, len;
+        cum_slot_frames(slot, g.count0, &begin, &len);
+        if (begin + len > g.n_frames)
+            continue;  // not completed by this batch (k_cumulate carries it) or beyond the batch
+        const int bin = (cb * (int)blockDim.x + (int)threadIdx.x) * 4;
+        if (bin >= g.n)
+            continue;
+        const unsigned n4 = (unsigned)g.n >> 2;
+        const bound_u4 *__restrict__ col = reinterpret_cast<const bound_u4 *>(psd + (size_t)band * g.stride * g.n) + ((unsigned)begin * n4 + ((unsigned)bin >> 2));
+        bound_u4 acc = {0u, 0u, 0u, 0u}, special = {0u, 0u, 0u, 0u};
+        auto add = [&](bound_u4 v) {  // gomath::cum_bound_units / cum_bound_special, four bins at a time
+            v = v >> 16;
+            acc += __builtin_elementwise_max(v, floor_hw) + 1u;
+            special |= v + 0x8080u;  // bit 16 set  <=>  v >= 0x7f80 (v < 2^16): infinity, NaN or a sign bit
+        };
+        int f = 0;
+        bound_u4 nv[U];
+        if (U <= len) {
+#pragma unroll
+            for (int k = 0; k < U; k++)
+                nv[k] = __builtin_nontemporal_load(col + (unsigned)k * n4);
+        }
+        for (; f + U <= len; f += U) {
+            bound_u4 v[U];
+#pragma unroll
+            for (int k = 0; k < U; k++)
+                v[k] = nv[k];
+            col += U * n4;
+            if (f + 2 * U <= len) {
+#pragma unroll
+                for (int k = 0; k < U; k++)
+                    nv[k] = __builtin_nontemporal_load(col + (unsigned)k * n4);
+            }
+#pragma unroll
+            for (int k = 0; k < U; k++)
+                add(v[k]);
+        }
+        for (; f < len; f++, col += n4)
+            add(__builtin_nontemporal_load(col));
+        float4 out;
+        float *o = &out.x;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const double c0 = (slot == 0 && g.count0 > 0) ? (double)carry_in[(size_t)band * g.n + bin + i] : 0.0;
+            o[i] = gomath::cum_bound(c0, acc[i], len, a128, per_frame, (special[i] >> 16) != 0u);
+        }
+        *reinterpret_cast<float4 *>(cum_out + ((size_t)band * g.max_chunks + slot) * g.n + bin) = out;
     }
 }
 
@@ -147,41 +269,94 @@ __global__ __launch_bounds__(256) void k_spectrum_row(const float *__restrict__ 
 
 // ---------------------------------------------------------------------------------------------
 // k_find_peaks — dsp.FindPeaks (dsp/fft.go:254-285) on one completed cumulation, one workgroup per cumulation.
-//  1. the row is read once, coalesced (lane = bin), divided by 100 (float32, :259) and kept in LDS; the 64 comparison
-//     results of a wave instruction are one ballot word of a bit array (bit b = `value[b] > threshold`, :260);
+//  0. the row k_cum_bound left - an upper bound of the cumulation in every bin - is read once, coalesced (lane = bin),
+//     divided by 100 (float32, :259) into LDS; the bins whose bound is above the threshold and their two neighbours are
+//     the only ones FindPeaks can look at (division and comparison are monotone): they are listed (ballot words, a popcount
+//     prefix) and each gets its exact cumulation - the carry, then the ordered float32 sum of the certified dB values of
+//     its 100 frames (cum_exact_column) - written back into the row and into LDS;
+//  1. the 64 comparison results of a wave instruction are one ballot word of a bit array (bit b = `value[b] > threshold`,
+//     :260), now from exact values wherever it can be set;
 //  2. run starts are bit operations on that array (a set bit whose predecessor is clear), counted with popcount and
 //     numbered by one wave's prefix sum over the words: the peak list comes out in bin order, as the reference's;
 //  3. the thread that owns a word walks the runs starting in it: the run's end is found in the bit array (count of
 //     trailing ones), its maximum in the LDS row, first maximum wins (strict `<`, :270); a run still open at the last
 //     bin ends there (:276-282).
-// (Round 2's kernel gave each thread 64 consecutive bins - lanes 256 bytes apart - scanned the starts through 16
-// barriers and walked runs in global memory: 0.040 ms standalone, 0.08 inside the pipeline.)
 // ---------------------------------------------------------------------------------------------
 constexpr int kPeakThreadsMax = 1024;
 __device__ __forceinline__ int peak_words(int n) { return n >> 6; }
+// dynamic LDS: val [n] float, list [n] uint16, flags / starts / rflags [words] u64 each, offs [words + 1] int, dB tables
+__host__ __device__ inline size_t peak_lds_bytes(int n)
+{
+    const size_t words = (size_t)(n >> 6);
+    return (size_t)n * 4 + (size_t)n * 2 + words * 24 + (words + 1) * 4 + 16 + gomath::kDbTabBytes;
+}
 
-__global__ __launch_bounds__(kPeakThreadsMax) void k_find_peaks(const float *__restrict__ cum, const sdr_frame_rec *__restrict__ recs,
-                                                                 DevPeak *__restrict__ peaks, int *__restrict__ counts,
-                                                                 const BatchCursor *__restrict__ cur, PeakGeom g, int n_frames)
+// exclusive prefix of per-word bit counts (wave 0: each lane takes `per` consecutive words); returns the total in every
+// lane of wave 0
+__device__ __forceinline__ int word_prefix(const unsigned long long *bits, int *offs, int words, int tid)
+{
+    const int per = (words + 63) >> 6;
+    int local = 0;
+    for (int k = 0; k < per; k++) {
+        const int w = tid * per + k;
+        if (w < words)
+            local += __popcll(bits[w]);
+    }
+    int incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (tid >= o)
+            incl += up;
+    }
+    int run = incl - local;
+    for (int k = 0; k < per; k++) {
+        const int w = tid * per + k;
+        if (w < words) {
+            offs[w] = run;
+            run += __popcll(bits[w]);
+        }
+    }
+    const int total = __shfl(incl, 63);
+    if (tid == 63)
+        offs[words] = total;
+    return total;
+}
+
+__global__ __launch_bounds__(kPeakThreadsMax) void k_find_peaks(float *__restrict__ cum, const float *__restrict__ psd, const void *__restrict__ db_tab,
+                                                                 const float *__restrict__ carry0, const float *__restrict__ carry1, int carry_in_arg,
+                                                                 const sdr_frame_rec *__restrict__ recs, DevPeak *__restrict__ peaks, int *__restrict__ counts,
+                                                                 const BatchCursor *__restrict__ cur, PeakGeom g, int n_frames, double inv_n2)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_peaks[];
     const int chunk = blockIdx.x, band = blockIdx.y, tid = threadIdx.x, lane = threadIdx.x & 63;
+    int carry_sel = carry_in_arg;
     if (cur) {
         g.count0 = cur->count0;
+        carry_sel = cur->carry_in;
         if (chunk >= chunks_completed(g.count0, n_frames))
             return;
     }
     const int n = g.n, words = peak_words(n), T = blockDim.x;
-    float *val = reinterpret_cast<float *>(smem_peaks);                                      // [n]
-    unsigned long long *flags = reinterpret_cast<unsigned long long *>(smem_peaks + (size_t)n * 4);  // [words]
-    unsigned long long *starts = flags + words;                                              // [words]
-    int *offs = reinterpret_cast<int *>(starts + words);                                     // [words + 1]
+    float *val = reinterpret_cast<float *>(smem_peaks);                                               // [n]
+    unsigned short *list = reinterpret_cast<unsigned short *>(smem_peaks + (size_t)n * 4);            // [n]
+    unsigned long long *flags = reinterpret_cast<unsigned long long *>(smem_peaks + (size_t)n * 6);   // [words]
+    unsigned long long *starts = flags + words;                                                       // [words]
+    unsigned long long *rflags = starts + words;                                                      // [words]
+    int *offs = reinterpret_cast<int *>(rflags + words);                                              // [words + 1]
+    unsigned char *s_tab = smem_peaks + (((size_t)n * 6 + (size_t)words * 24 + (size_t)(words + 1) * 4 + 15) & ~(size_t)15);
+    {
+        const uint4 *src = static_cast<const uint4 *>(db_tab);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_tab);
+        for (int i = tid; i < gomath::kDbTabBytes / 16; i += T)
+            dst[i] = src[i];
+    }
     const int first_len = SDR_CUMULATION_SIZE - g.count0;
     const int end_frame = first_len + chunk * SDR_CUMULATION_SIZE - 1;  // frame that completes this chunk
     const float thr = recs[(size_t)band * g.stride + end_frame].peak_thr;
-    const float *c = cum + ((size_t)band * g.max_chunks + chunk) * n;
+    float *c = cum + ((size_t)band * g.max_chunks + chunk) * n;
     const float size = (float)SDR_CUMULATION_SIZE;
-    // 1. values and flag words (n is a multiple of T, T a multiple of 64: every wave instruction covers 64 whole bins)
+    // 0. bounds and their flag words (n is a multiple of T, T a multiple of 64: every wave instruction covers 64 whole bins)
 #pragma unroll 8
     for (int b = tid; b < n; b += T) {
         const float v = __fdiv_rn(c[b], size);
@@ -191,39 +366,70 @@ __global__ __launch_bounds__(kPeakThreadsMax) void k_find_peaks(const float *__r
             flags[b >> 6] = m;
     }
     __syncthreads();
-    // 2. run starts per word, numbered by a prefix sum (wave 0: each lane takes `per` consecutive words)
+    // the bins to evaluate exactly: flagged by their bound, or next to one that is
+    for (int w = tid; w < words; w += T) {
+        const unsigned long long f = flags[w];
+        rflags[w] = f | (f << 1) | (f >> 1) | (w > 0 ? flags[w - 1] >> 63 : 0ull) | (w + 1 < words ? flags[w + 1] << 63 : 0ull);
+    }
+    __syncthreads();
+    if (tid < 64)
+        word_prefix(rflags, offs, words, tid);
+    __syncthreads();
+    const int n_exact = offs[words];
+    for (int w = tid; w < words; w += T) {
+        unsigned long long r = rflags[w];
+        int at = offs[w];
+        while (r) {
+            list[at++] = (unsigned short)((w << 6) + __builtin_ctzll(r));
+            r &= r - 1;
+        }
+    }
+    __syncthreads();
+    if (n_exact > 0) {  // (workgroup-uniform)
+        const gomath::DbTables tab = gomath::db_tables(s_tab);
+        int begin, len;
+        cum_slot_frames(chunk, g.count0, &begin, &len);
+        const float *__restrict__ carry_in = carry_sel ? carry1 : carry0;
+        const float *__restrict__ base = psd + (size_t)band * g.stride * n;
+        // dense lanes: entry k of the list goes to thread k (neighbouring bins of a run sit in neighbouring lanes)
+        for (int k0 = 0; k0 < n_exact; k0 += T) {
+            const int k = k0 + tid;
+            const bool mine = k < n_exact;
+            const int bin = list[mine ? k : n_exact - 1];
+            float acc = 0.f;
+            if (chunk == 0 && g.count0 > 0)
+                acc = carry_in[(size_t)band * n + bin];
+            // (every lane of a wave that has an entry runs the column loop - the rare literal-log branch inside it is
+            // a wave-wide vote - lanes without one repeat the last entry and store nothing)
+            if (k0 + (tid & ~63) < n_exact) {
+                // (scattered columns, one 64-byte sector per cluster of candidates and frame: latency-bound, many loads in flight)
+                acc = cum_exact_column<SDR_REFINE_U>(base, (unsigned)begin * (unsigned)n + (unsigned)bin, (unsigned)n, len, acc, tab, inv_n2);
+                if (mine) {
+                    c[bin] = acc;  // the row holds the exact cumulation wherever FindPeaks reads it
+                    val[bin] = __fdiv_rn(acc, size);
+                }
+            }
+        }
+        __syncthreads();
+        // 1. the flag words again, from exact values wherever a bit can be set
+        for (int b = tid; b < n; b += T) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(val[b] > thr);
+            if (lane == 0)
+                flags[b >> 6] = m;
+        }
+        __syncthreads();
+    }
+    // 2. run starts per word, numbered by a prefix sum
+    for (int w = tid; w < words; w += T) {
+        const unsigned long long f = flags[w];
+        const unsigned long long before = (f << 1) | (w > 0 ? flags[w - 1] >> 63 : 0ull);
+        starts[w] = f & ~before;
+    }
+    __syncthreads();
     if (tid < 64) {
-        const int per = (words + 63) >> 6;
-        int local = 0;
-        for (int k = 0; k < per; k++) {
-            const int w = tid * per + k;
-            if (w < words) {
-                const unsigned long long f = flags[w];
-                const unsigned long long before = (f << 1) | (w > 0 ? flags[w - 1] >> 63 : 0ull);
-                const unsigned long long st = f & ~before;
-                starts[w] = st;
-                local += __popcll(st);
-            }
-        }
-        int incl = local;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int up = __shfl_up(incl, o);
-            if (tid >= o)
-                incl += up;
-        }
-        int run = incl - local;
-        for (int k = 0; k < per; k++) {
-            const int w = tid * per + k;
-            if (w < words) {
-                offs[w] = run;
-                run += __popcll(starts[w]);
-            }
-        }
-        if (tid == 63) {
-            offs[words] = incl;
-            counts[(size_t)band * g.max_chunks + chunk] = incl;
-        }
+        const int total = word_prefix(starts, offs, words, tid);
+        if (tid == 63)
+            counts[(size_t)band * g.max_chunks + chunk] = total;
     }
     __syncthreads();
     // 3. the runs that start in word w
@@ -272,6 +478,7 @@ __global__ __launch_bounds__(kPeakThreadsMax) void k_find_peaks(const float *__r
                 p.to = to;
                 p.signal_bin = best_bin;
                 p.signal_value = best;
+                // (exact: neighbours of a flagged bin were evaluated above; written by this workgroup, behind barriers)
                 p.y1 = best_bin > 0 ? c[best_bin - 1] : 0.f;
                 p.y2 = c[best_bin];
                 p.y3 = best_bin < n - 1 ? c[best_bin + 1] : 0.f;
@@ -282,13 +489,53 @@ __global__ __launch_bounds__(kPeakThreadsMax) void k_find_peaks(const float *__r
     }
 }
 
+// One batch's cumulation work, on `stream`: bounds of the cumulations it completes, the exact carry of the one it leaves
+// open.  (A stage event armed by the caller rides on the last launch.)
 hipError_t launch_cumulate(const float *psd, const void *db_tab, float *carry0, float *carry1, int carry_in, float *cum_out,
                            const BatchCursor *cur, CumGeom g, int n_slots, int n_bands, hipStream_t stream)
 {
-    const int threads = g.n < SDR_CUM_THREADS ? g.n : SDR_CUM_THREADS;
     const double inv_n2 = 1.0 / ((double)g.n * (double)g.n);
-    launch_kernel(k_cumulate, dim3((g.n + threads - 1) / threads, n_slots, n_bands), dim3(threads), 0, stream, psd, db_tab,
-                       carry0, carry1, carry_in, cum_out, cur, g, inv_n2);
+    double a128, per_frame;
+    gomath::cum_bound_constants(g.n, &a128, &per_frame);
+    const hipEvent_t done = t_done_event;
+    t_done_event = nullptr;
+    {
+        static std::once_flag attr_once[64];
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess)
+            return e;
+        if (dev < 0 || dev >= 64)
+            return hipErrorInvalidDevice;
+        hipError_t attr_err = hipSuccess;
+        std::call_once(attr_once[dev], [&] {
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cum_bound), hipFuncAttributeMaxDynamicSharedMemorySize, kBoundLdsBytes);
+        });
+        if (attr_err != hipSuccess)
+            return attr_err;
+        static const int wgs_env = getenv("SDR_BOUND_WGS") ? atoi(getenv("SDR_BOUND_WGS")) : SDR_BOUND_WGS;  // (development)
+        const int threads = (g.n / 4) < kBoundThreads ? g.n / 4 : kBoundThreads;
+        const int blocks = (g.n / 4 + threads - 1) / threads, items = n_bands * n_slots * blocks;
+        const int wgs = items < wgs_env ? items : wgs_env;
+        hipLaunchKernelGGL(k_cum_bound, dim3(wgs), dim3(threads), kBoundLdsBytes, stream, psd, carry0, carry1, carry_in, cum_out, cur, g, n_slots,
+                           n_bands, a128, per_frame);
+    }
+    const int threads = g.n < SDR_CUM_THREADS ? g.n : SDR_CUM_THREADS;
+    t_done_event = done;
+    launch_kernel(k_cumulate, dim3((g.n + threads - 1) / threads, 1, n_bands), dim3(threads), 0, stream, psd, db_tab, carry0, carry1, carry_in,
+                  cum_out, static_cast<float *>(nullptr), cur, g, 1, 0, inv_n2);
+    return hipGetLastError();
+}
+
+// the exact cumulation `slot` of one band, on demand (sdr_read_cumulation, the scope tap): psd / carry_in point at the band
+hipError_t launch_cumulation_row(const float *psd_band, const void *db_tab, const float *carry_in_band, float *row_out, CumGeom g, int slot,
+                                 hipStream_t stream)
+{
+    const double inv_n2 = 1.0 / ((double)g.n * (double)g.n);
+    const int threads = g.n < SDR_CUM_THREADS ? g.n : SDR_CUM_THREADS;
+    float *ci = const_cast<float *>(carry_in_band);
+    hipLaunchKernelGGL(k_cumulate, dim3((g.n + threads - 1) / threads, 1, 1), dim3(threads), 0, stream, psd_band, db_tab, ci, ci, 0,
+                       static_cast<float *>(nullptr), row_out, static_cast<const BatchCursor *>(nullptr), g, 0, slot, inv_n2);
     return hipGetLastError();
 }
 
@@ -299,13 +546,13 @@ hipError_t launch_spectrum_row(const float *psd_row, float *out, int n, hipStrea
     return hipGetLastError();
 }
 
-hipError_t launch_find_peaks(const float *cum, const sdr_frame_rec *recs, DevPeak *peaks, int *counts, const BatchCursor *cur,
-                             PeakGeom g, int n_frames, int n_chunks, int n_bands, hipStream_t stream)
+hipError_t launch_find_peaks(float *cum, const float *psd, const void *db_tab, const float *carry0, const float *carry1, int carry_in,
+                             const sdr_frame_rec *recs, DevPeak *peaks, int *counts, const BatchCursor *cur, PeakGeom g, int n_frames,
+                             int n_chunks, int n_bands, hipStream_t stream)
 {
     if (n_chunks == 0)
         return hipSuccess;
-    const int words = g.n >> 6;
-    const unsigned lds = (unsigned)((size_t)g.n * 4 + (size_t)words * 16 + (size_t)(words + 1) * 4);
+    const unsigned lds = (unsigned)peak_lds_bytes(g.n);
     // more than 64 KB of dynamic LDS needs the attribute, once per device
     static std::once_flag attr_once[64];
     int dev = 0;
@@ -317,12 +564,14 @@ hipError_t launch_find_peaks(const float *cum, const sdr_frame_rec *recs, DevPea
     hipError_t attr_err = hipSuccess;
     std::call_once(attr_once[dev], [&] {
         attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_find_peaks), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       16384 * 4 + 256 * 16 + 257 * 4);
+                                       (int)peak_lds_bytes(16384));
     });
     if (attr_err != hipSuccess)
         return attr_err;
     const int threads = g.n < kPeakThreadsMax ? g.n : kPeakThreadsMax;
-    launch_kernel(k_find_peaks, dim3(n_chunks, n_bands), dim3(threads), lds, stream, cum, recs, peaks, counts, cur, g, n_frames);
+    const double inv_n2 = 1.0 / ((double)g.n * (double)g.n);
+    launch_kernel(k_find_peaks, dim3(n_chunks, n_bands), dim3(threads), lds, stream, cum, psd, db_tab, carry0, carry1, carry_in, recs, peaks,
+                  counts, cur, g, n_frames, inv_n2);
     return hipGetLastError();
 }
 

@@ -160,7 +160,10 @@ __host__ __device__ inline int chunks_completed(int count0, int n_frames)
     return n_frames >= first_len ? 1 + (n_frames - first_len) / SDR_CUMULATION_SIZE : 0;
 }
 hipError_t launch_unpack_be16(const uint8_t *raw, float *out, size_t n_values, hipStream_t stream);
-hipError_t launch_find_peaks(const float *cum, const sdr_frame_rec *recs, DevPeak *peaks, int *counts, const BatchCursor *cur,
-                             PeakGeom g, int n_frames, int n_chunks, int n_bands, hipStream_t stream);
+hipError_t launch_find_peaks(float *cum, const float *psd, const void *db_tab, const float *carry0, const float *carry1, int carry_in,
+                             const sdr_frame_rec *recs, DevPeak *peaks, int *counts, const BatchCursor *cur, PeakGeom g, int n_frames,
+                             int n_chunks, int n_bands, hipStream_t stream);
+hipError_t launch_cumulation_row(const float *psd_band, const void *db_tab, const float *carry_in_band, float *row_out, CumGeom g, int slot,
+                                 hipStream_t stream);
 
 }  // namespace sdr

@@ -354,6 +354,20 @@ def test_kernel_decoder_loop_matches_literal_ticks(tmp_path):
     assert "mismatches 0" in out.stdout and " 0 runes" not in out.stdout
 
 
+def test_cumulation_bound_is_an_upper_bound(tmp_path):
+    """k_cum_bound's claim (gomath.h cum_bound_*): from the top halves of the psd words alone, an upper bound of every
+    term of a cumulation (every exponent, dense and random mantissas, zero / subnormal / infinite / NaN), of the ordered
+    float32 sum of 100 of them on top of a carry, and of what FindPeaks decides from it - for every block size, with the
+    literal Go arithmetic on the CPU."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "emu_cum_bound")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe, os.path.join(root, "tests", "emu", "emu_cum_bound.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and " 0 violations" in out.stdout, out.stdout + out.stderr
+
+
 @pytest.mark.parametrize("layout_b_from", [15, 14])
 def test_fft_phase_functions_match_oracle_bit_for_bit(tmp_path, layout_b_from):
     """The register/LDS index math and per-pass twiddle layout of the FFT kernel (fft_f64.h), emulated
