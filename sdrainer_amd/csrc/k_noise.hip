@@ -11,6 +11,8 @@
 // part is one v_add_f64 per term.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/sdrainer_hip.h"
 #include "gomath.h"
 #include "sdr_device.h"
@@ -59,7 +61,7 @@ using VarianceRing = ChainShared<6, float, 2>;
 
 #if defined(SDR_NOISE_TRACE)
 // diagnostic builds (tools/abl): where does the consumer of workgroup 0 spend its time?
-__device__ unsigned long long g_noise_trace[8];  // [0] total, [1] waiting for tiles, [2] tiles, [3] spins, [4] total in shader clocks
+__device__ unsigned long long g_noise_trace[16];  // variance consumer 0 of workgroup 7: [0] total, [1] waiting for tiles, [2] tiles, [3] spins, [4] total in shader clocks; [8..12] the same for the window sums' consumer of group 0
 extern "C" __attribute__((visibility("default"))) int sdr_debug_noise_trace(unsigned long long *out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_noise_trace), sizeof(g_noise_trace));
@@ -294,12 +296,12 @@ __device__ __attribute__((noinline)) double chain_consumer(int n_tiles_any_lane,
     }
     __builtin_amdgcn_s_setprio(0);
 #if defined(SDR_NOISE_TRACE)
-    if (sizeof(T) == 8 && blockIdx.x == 7 && lane == 0) {
-        g_noise_trace[0] = wall_clock64() - tr_start;
-        g_noise_trace[1] = tr_wait;
-        g_noise_trace[2] = (unsigned long long)n_tiles;
-        g_noise_trace[3] = tr_spins;
-        g_noise_trace[4] = clock64() - tr_clk0;
+    if (blockIdx.x == 7 && blockIdx.y == 0 && lane == 0 && __builtin_amdgcn_readfirstlane(group_any_lane) == 0) {
+        g_noise_trace[8] = wall_clock64() - tr_start;
+        g_noise_trace[9] = tr_wait;
+        g_noise_trace[10] = (unsigned long long)n_tiles;
+        g_noise_trace[11] = tr_spins;
+        g_noise_trace[12] = clock64() - tr_clk0;
     }
 #endif
     return sum;
@@ -394,10 +396,25 @@ __device__ __attribute__((noinline)) void variance_consumer_mfma(int n_tiles_any
     const int n_terms = sh.n_terms[row];  // ... and how many leading terms count
     double acc = 0.0;
     __builtin_amdgcn_s_setprio(3);
+#if defined(SDR_NOISE_TRACE)
+    unsigned long long tr_wait = 0, tr_spins = 0;
+    const unsigned long long tr_start = wall_clock64();
+    const unsigned long long tr_clk0 = clock64();
+#endif
     for (int t = 0; t < n_tiles; t++) {
         const int slot = t % RING_SLOTS;
-        while (lds_flag_load(&sh.ready[slot][0]) != t + 1 || lds_flag_load(&sh.ready[slot][1]) != t + 1)
+#if defined(SDR_NOISE_TRACE)
+        const unsigned long long w0 = wall_clock64();
+#endif
+        while (lds_flag_load(&sh.ready[slot][0]) != t + 1 || lds_flag_load(&sh.ready[slot][1]) != t + 1) {
             __builtin_amdgcn_s_sleep(1);
+#if defined(SDR_NOISE_TRACE)
+            tr_spins++;
+#endif
+        }
+#if defined(SDR_NOISE_TRACE)
+        tr_wait += wall_clock64() - w0;
+#endif
         lds_order();
         float x[TILE / 4];
 #pragma unroll
@@ -433,6 +450,15 @@ __device__ __attribute__((noinline)) void variance_consumer_mfma(int n_tiles_any
             lds_flag_store(&sh.consumed_by[g], t + 1);
     }
     __builtin_amdgcn_s_setprio(0);
+#if defined(SDR_NOISE_TRACE)
+    if (blockIdx.x == 7 && g == 0 && lane == 0) {
+        g_noise_trace[0] = wall_clock64() - tr_start;
+        g_noise_trace[1] = tr_wait;
+        g_noise_trace[2] = (unsigned long long)n_tiles;
+        g_noise_trace[3] = tr_spins;
+        g_noise_trace[4] = clock64() - tr_clk0;
+    }
+#endif
     // chain c of this consumer: lanes 16 (c & 3) + 4 (c >> 2) + j hold its sum; j = 0 writes it
     if ((lane & 3) == 0) {
         const int c = 4 * ((lane >> 2) & 3) + (lane >> 4);
@@ -760,10 +786,16 @@ hipError_t launch_window_means(const float *psd, double *win_mean, NoiseGeom g, 
     // a workgroup fills its CU: enough of them to cover the chip, but no more than two rounds.  (Config 3: 160
     // workgroups of one window each.  Two windows back to back per workgroup, 80 workgroups: 0.050 instead of
     // 0.030 ms standalone and 0.226-0.238 instead of 0.222-0.225 ms per pipelined step - the noise stream is as long
-    // as the others by now; four windows: 0.093 ms, 0.253.)
+    // as the others by now; four windows: 0.093 ms, 0.253.  Round 4, SDR_WM_WPB on one box each: config 3 at 8192 frames
+    // per batch, 1 / 2 / 5 / 10 windows per workgroup 158.4 / 159.0 / 161.4 / 160.5 GS/s - fewer, longer-lived workgroups
+    // hold less CU time, within the noise of a run; config 5's share, whose noise stream is the longest of its four,
+    // 184.1 with one window against 174.2 with two.  One window stays.)
     const int per_band = ((n_frames + TILE - 1) / TILE + WM_GROUPS - 1) / WM_GROUPS;
     int wpb = (per_band * n_bands * g.n_windows) / 512;
     wpb = wpb < 1 ? 1 : (wpb > g.n_windows ? g.n_windows : wpb);
+    static const int wpb_env = getenv("SDR_WM_WPB") ? atoi(getenv("SDR_WM_WPB")) : 0;  // (development)
+    if (wpb_env > 0)
+        wpb = wpb_env > g.n_windows ? g.n_windows : wpb_env;
 
     launch_kernel(k_window_means, dim3(per_band, (g.n_windows + wpb - 1) / wpb, n_bands), dim3(CHAIN_THREADS), 0, stream, psd,
                        win_mean, g, n_frames, stride, wpb);

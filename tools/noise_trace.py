@@ -11,11 +11,15 @@ for b in bins: bank.attach(0, int(b))
 for i in range(4):
     bank.process_device(iq.data_ptr(), frames)
     bank.sync()
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 16)()
 L = capi._lib
 L.sdr_debug_noise_trace.restype = C.c_int
 assert L.sdr_debug_noise_trace(out) == 0
-total, wait, tiles, spins = out[0], out[1], out[2], out[3]
-print("consumer: total %d ticks (100 MHz) = %.1f us, waiting for tiles %.1f us (%.0f%%), %d tiles, %.3f us per tile, %d spins"
-      % (total, total / 100.0, wait / 100.0, 100.0 * wait / max(total, 1), tiles, total / 100.0 / max(tiles, 1), spins))
-print("shader clock during the chain: %.2f GHz; %.1f clocks per term outside the waits" % (out[4] / (total * 10.0), (out[4] * (1 - wait / total)) / (tiles * 64.0)))
+for name, o in (("variance consumer 0 (matrix pipe)", 0), ("window-sum consumer of group 0", 8)):
+    total, wait, tiles, spins, clk = out[o], out[o + 1], out[o + 2], out[o + 3], out[o + 4]
+    if not total or not tiles:
+        print(name + ": no trace")
+        continue
+    print("%s: total %.1f us, waiting for tiles %.1f us (%.0f%%), %d tiles, %.3f us per tile, %d spins; %.2f GHz, %.1f clocks per term outside the waits"
+          % (name, total / 100.0, wait / 100.0, 100.0 * wait / total, tiles, total / 100.0 / tiles, spins, clk / (total * 10.0),
+             (clk * (1 - wait / total)) / (tiles * 64.0)))
