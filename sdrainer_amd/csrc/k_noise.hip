@@ -61,7 +61,7 @@ using VarianceRing = ChainShared<6, float, 2>;
 
 #if defined(SDR_NOISE_TRACE)
 // diagnostic builds (tools/abl): where does the consumer of workgroup 0 spend its time?
-__device__ unsigned long long g_noise_trace[16];  // variance consumer 0 of workgroup 7: [0] total, [1] waiting for tiles, [2] tiles, [3] spins, [4] total in shader clocks; [8..12] the same for the window sums' consumer of group 0
+__device__ unsigned long long g_noise_trace[32];  // variance consumer 0 of workgroup 7: [0] total, [1] waiting for tiles, [2] tiles, [3] spins, [4] total in shader clocks; [8..12] the same for the window sums' consumer of group 0
 extern "C" __attribute__((visibility("default"))) int sdr_debug_noise_trace(unsigned long long *out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_noise_trace), sizeof(g_noise_trace));
@@ -296,12 +296,17 @@ __device__ __attribute__((noinline)) double chain_consumer(int n_tiles_any_lane,
     }
     __builtin_amdgcn_s_setprio(0);
 #if defined(SDR_NOISE_TRACE)
-    if (blockIdx.x == 7 && blockIdx.y == 0 && lane == 0 && __builtin_amdgcn_readfirstlane(group_any_lane) == 0) {
-        g_noise_trace[8] = wall_clock64() - tr_start;
-        g_noise_trace[9] = tr_wait;
-        g_noise_trace[10] = (unsigned long long)n_tiles;
-        g_noise_trace[11] = tr_spins;
-        g_noise_trace[12] = clock64() - tr_clk0;
+    if (blockIdx.x == 7 && blockIdx.y == 0 && lane == 0) {
+        const int grp = __builtin_amdgcn_readfirstlane(group_any_lane);
+        if (grp == 0) {
+            g_noise_trace[8] = wall_clock64() - tr_start;
+            g_noise_trace[9] = tr_wait;
+            g_noise_trace[10] = (unsigned long long)n_tiles;
+            g_noise_trace[11] = tr_spins;
+            g_noise_trace[12] = clock64() - tr_clk0;
+        }
+        g_noise_trace[16 + 2 * grp] = wall_clock64() - tr_start;  // every group of the workgroup: chain time, waiting
+        g_noise_trace[17 + 2 * grp] = tr_wait;
     }
 #endif
     return sum;
@@ -391,22 +396,28 @@ __device__ __attribute__((noinline)) void variance_consumer_mfma(int n_tiles_any
     const int min_terms = __builtin_amdgcn_readfirstlane(min_terms_any_lane);
     VarianceRing &sh = g_ring_ns[0];
     constexpr int RING_SLOTS = VarianceRing::RING_SLOTS;
+    constexpr int Q = TILE / 4;  // matrix instructions per tile
     const int row = 16 * g + (lane & 15), k = lane >> 4;
     const double mean = sh.mean[row];     // this lane's chain: the value subtracted before squaring
     const int n_terms = sh.n_terms[row];  // ... and how many leading terms count
     double acc = 0.0;
+    if (n_tiles <= 0)
+        return;
     __builtin_amdgcn_s_setprio(3);
 #if defined(SDR_NOISE_TRACE)
     unsigned long long tr_wait = 0, tr_spins = 0;
     const unsigned long long tr_start = wall_clock64();
     const unsigned long long tr_clk0 = clock64();
 #endif
-    for (int t = 0; t < n_tiles; t++) {
+    auto ready = [&](int t) {
         const int slot = t % RING_SLOTS;
+        return lds_flag_load(&sh.ready[slot][0]) == t + 1 && lds_flag_load(&sh.ready[slot][1]) == t + 1;
+    };
+    auto wait_tile = [&](int t) {
 #if defined(SDR_NOISE_TRACE)
         const unsigned long long w0 = wall_clock64();
 #endif
-        while (lds_flag_load(&sh.ready[slot][0]) != t + 1 || lds_flag_load(&sh.ready[slot][1]) != t + 1) {
+        while (!ready(t)) {
             __builtin_amdgcn_s_sleep(1);
 #if defined(SDR_NOISE_TRACE)
             tr_spins++;
@@ -416,27 +427,56 @@ __device__ __attribute__((noinline)) void variance_consumer_mfma(int n_tiles_any
         tr_wait += wall_clock64() - w0;
 #endif
         lds_order();
-        float x[TILE / 4];
+    };
+    // terms 4q .. 4q+3 of sixteen chains per ds_read_b32
+    auto load = [&](float (&x)[Q], int t) {
+        const int slot = t % RING_SLOTS;
 #pragma unroll
-        for (int q = 0; q < TILE / 4; q++)
-            x[q] = sh.term[slot][row][4 * q + k];  // ds_read_b32: terms 4q .. 4q+3 of sixteen chains per instruction
+        for (int q = 0; q < Q; q++)
+            x[q] = sh.term[slot][row][4 * q + k];
+    };
+    // A tile's sixteen reads are issued a whole tile AHEAD of the matrix instructions that consume them: round 3 read a
+    // tile and then waited out the LDS - shared with twelve producers' writes - before its first instruction, every tile
+    // (16 clocks per term measured, tools/noise_trace.py, against the pipe's 5.4).  Now tile t+1 is requested - if its
+    // flags are already up, the usual case: the producers run ahead - before tile t's chain starts, and its slot is handed
+    // back to the producers as soon as those reads have been issued and waited for once, at the top of the next round.
+    // One straight path per tile (no branch between the reads and the chain: at a join the compiler must assume the
+    // youngest LDS reads are the ones it needs and waits for all of them - which is what it did to the first version of
+    // this loop): tile t+1's flags are waited for, its reads issued, THEN tile t's chain runs; the two register sets
+    // alternate (a copy would wait for the reads it copies).
+    auto chain = [&](const float (&x)[Q], int t) {
         // term = (psd - mean)^2, math.Pow(d, 2) (dsp/fft.go:247), widened, subtracted and squared in float64 here, in
         // the shadow of the previous instruction on the matrix pipe; terms past the chain's end count as +0 (only in
         // the tiles where some chain of the workgroup ends: a scalar branch)
         if ((t + 1) * TILE <= min_terms) {
+#if defined(SDR_VAR_PRE)
+            double p[Q];
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const double d = (double)x[q] - mean;
+                p[q] = d * d;
+            }
+#pragma unroll
+            for (int q = 0; q < Q; q++)
+                asm volatile("" : "+v"(p[q]));  // (all squares first, then nothing but the chain)
+#pragma unroll
+            for (int q = 0; q < Q; q++)
+                acc = __builtin_amdgcn_mfma_f64_4x4x4f64(p[q], 1.0, acc, 0, 0, 0);
+#else
             double p_next = ((double)x[0] - mean) * ((double)x[0] - mean);
 #pragma unroll
-            for (int q = 0; q < TILE / 4; q++) {
+            for (int q = 0; q < Q; q++) {
                 const double p = p_next;
                 acc = __builtin_amdgcn_mfma_f64_4x4x4f64(p, 1.0, acc, 0, 0, 0);
-                if (q + 1 < TILE / 4) {
+                if (q + 1 < Q) {
                     const double d = (double)x[q + 1] - mean;
                     p_next = d * d;
                 }
             }
+#endif
         } else {
 #pragma unroll
-            for (int q = 0; q < TILE / 4; q++) {
+            for (int q = 0; q < Q; q++) {
                 const double d = (double)x[q] - mean;
                 double p = d * d;
                 if (t * TILE + 4 * q + k >= n_terms)
@@ -445,10 +485,39 @@ __device__ __attribute__((noinline)) void variance_consumer_mfma(int n_tiles_any
             }
         }
         asm volatile("" : "+v"(acc)::"memory");
+        // tile t's values are in registers (and used): its slot may be refilled
         lds_order();
         if (lane == 0)
             lds_flag_store(&sh.consumed_by[g], t + 1);
+    };
+    // (the values a tile's reads deliver are first TOUCHED behind the chain of the tile before - an empty asm per
+    // register, ordered after the chain's own: otherwise the scheduler hoists their conversions above that chain, and
+    // with them the wait for the reads)
+    auto landed = [](float (&x)[Q]) {
+#pragma unroll
+        for (int q = 0; q < Q; q++)
+            asm volatile("" : "+v"(x[q]));
+    };
+    float xa[Q], xb[Q];
+    wait_tile(0);
+    load(xa, 0);
+    landed(xa);
+    int t = 0;
+    for (; t + 1 < n_tiles; t += 2) {
+        wait_tile(t + 1);
+        load(xb, t + 1);
+        chain(xa, t);
+        landed(xb);
+        if (t + 2 < n_tiles) {
+            wait_tile(t + 2);
+            load(xa, t + 2);
+        }
+        chain(xb, t + 1);
+        if (t + 2 < n_tiles)
+            landed(xa);
     }
+    if (t < n_tiles)
+        chain(xa, t);
     __builtin_amdgcn_s_setprio(0);
 #if defined(SDR_NOISE_TRACE)
     if (blockIdx.x == 7 && g == 0 && lane == 0) {
@@ -563,12 +632,19 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_window_means(const float *__r
     const int rows = max(0, min(TILE, n_frames - f0));  // (0: the odd group out at the end of a band sums nothing)
     const size_t frame0 = (size_t)band * stride + f0;
     const int w_end = min(g.n_windows, (int)(blockIdx.y + 1) * windows_per_block);
+#if defined(SDR_NOISE_TRACE)
+    const unsigned long long wg_t0 = wall_clock64();
+#endif
     for (int w = blockIdx.y * windows_per_block; w < w_end; w++) {
         const float *base = psd + frame0 * g.n + g.edge + (size_t)w * g.window;
         const double sum = chain_run<false, WM_GROUPS>(sh, group, wig, base, g.n, rows, g.window, lane < rows ? g.window : 0, 0.0);
         if (wig == 0 && lane < rows)
             win_mean[(frame0 + lane) * 10 + w] = sum / (double)g.window;
     }
+#if defined(SDR_NOISE_TRACE)
+    if (blockIdx.x == 7 && blockIdx.y == 0 && threadIdx.x == 0)
+        g_noise_trace[24] = wall_clock64() - wg_t0;  // the workgroup's wave 0, first instruction to last
+#endif
 }
 
 // pass 2: pick the minimum window in the reference's order, then the variance chain over

@@ -121,6 +121,12 @@ int main(int argc, char **argv)
         std::vector<float> out(total * N);
         CK(hipMemcpy(out.data(), pd, out.size() * 4, hipMemcpyDeviceToHost));
         printf("psd hash %016llx", fnv(out.data(), out.size() * 4));
+        if (const char *dump = getenv("SDR_FB_DUMP")) {  // the psd array as raw float32 (variants are compared word by word)
+            if (FILE *f = fopen(dump, "wb")) {
+                fwrite(out.data(), 4, out.size(), f);
+                fclose(f);
+            }
+        }
         if (dout) {
             std::vector<float> t(total * n_tap);
             CK(hipMemcpy(t.data(), dout, t.size() * 4, hipMemcpyDeviceToHost));

@@ -11,7 +11,7 @@ for b in bins: bank.attach(0, int(b))
 for i in range(4):
     bank.process_device(iq.data_ptr(), frames)
     bank.sync()
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 32)()
 L = capi._lib
 L.sdr_debug_noise_trace.restype = C.c_int
 assert L.sdr_debug_noise_trace(out) == 0
@@ -23,3 +23,4 @@ for name, o in (("variance consumer 0 (matrix pipe)", 0), ("window-sum consumer 
     print("%s: total %.1f us, waiting for tiles %.1f us (%.0f%%), %d tiles, %.3f us per tile, %d spins; %.2f GHz, %.1f clocks per term outside the waits"
           % (name, total / 100.0, wait / 100.0, 100.0 * wait / total, tiles, total / 100.0 / tiles, spins, clk / (total * 10.0),
              (clk * (1 - wait / total)) / (tiles * 64.0)))
+print("window sums, workgroup 7: chain time / waiting per group (us): " + ", ".join("%.1f / %.1f" % (out[16 + 2 * g] / 100.0, out[17 + 2 * g] / 100.0) for g in range(4)) + "; wave 0 of the workgroup lived %.1f us" % (out[24] / 100.0))
