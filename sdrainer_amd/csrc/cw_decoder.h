@@ -411,6 +411,33 @@ SDR_HD inline void decoder_run(DecoderState &d, int k, uint32_t run_base, Emissi
     d.ticks = end;
 }
 
+// AdaptiveThreshold.Put (cw/decode.go:392-411) as straight-line code: both candidate updates are formed, the one the
+// reference's branches would take is selected (a select returns one of its operands unchanged, so every value is the
+// one the branching code computes), and `gate` false leaves the threshold untouched (the edge was shorter than
+// minDitTime: Put is not called).  One lane per signal walks its edges; with several signals per wave every branch any
+// lane takes is paid by all of them, and with one signal per wave a taken branch still costs its exec-mask bookkeeping on
+// the serial path: the round-3 ablations put two thirds of an edge's ~1100 clocks in this structure, not in the
+// square root or the division.
+SDR_HD inline void at_put_select(AdaptiveThreshold &t, double duration, bool gate)
+{
+    const double highFactor = 2;
+    const double avgWeight = 0.75;
+    const double currentWeight = 1.0 - avgWeight;
+    const bool use = gate && !(duration >= t.low * t.upperBound);
+    const bool down = t.last >= duration * highFactor;                // this one shorter: it is the new low sample
+    const bool up = !down && duration >= t.last * highFactor;         // this one longer: the new high sample
+    const bool moved = use && (down || up);
+    const double lo_sample = down ? duration : t.last, hi_sample = down ? t.last : duration;
+    const double low = avgWeight * t.low + currentWeight * lo_sample;
+    const double high = avgWeight * t.high + currentWeight * hi_sample;
+    t.low = moved ? low : t.low;
+    t.high = moved ? high : t.high;
+    t.last = use ? duration : t.last;
+    // updateThreshold() recomputes sqrt(low*high) on every Put; when neither moved, the stored value IS that square root
+    const double thr = ::sqrt(t.low * t.high);
+    t.threshold = moved ? thr : t.threshold;
+}
+
 // decoder_edge: the tick (frame `frame`) at which the debounced state changes to `state`
 SDR_HD inline void decoder_edge_deferred(DecoderState &d, bool state, uint32_t frame, Emission &em)
 {
@@ -419,34 +446,46 @@ SDR_HD inline void decoder_edge_deferred(DecoderState &d, bool state, uint32_t f
     const double duration = now - (state ? d.offStart : d.onStart);
     d.onStart = state ? now : d.onStart;
     d.offStart = state ? d.offStart : now;
-    if (duration >= kMinDitTime) {
-        AdaptiveThreshold t = state ? d.offThreshold : d.onThreshold;
-        at_put(t, duration);
-        if (state)
-            d.offThreshold = t;
-        else
-            d.onThreshold = t;
-        uint32_t key = 0;
-        if (state) {  // onRisingEdge
-            const bool word_gap = duration >= 4.5 * t.low;
-            if (word_gap || duration >= t.threshold)
-                key = take_char(d);
-            em.space = word_gap;
-        } else if (duration >= 2 * t.high) {  // onFallingEdge
-            d.currentCharInvalid = 1;
-        } else {
-            const bool da = duration >= t.threshold;
-            if (d.charLen == kMaxSymbolCount)  // (rare)
-                key = take_char(d);
-            d.charBits = (d.charBits << 1) | (da ? 1u : 0u);
-            d.charLen++;
-            if (da)
-                d.wpm = (d.wpm + dit_to_wpm(d, t.low)) / 2.0;
-        }
-        if (key) {  // (if the abort check of this iteration's run took the character, there is none left here)
-            em.key = key;
-            em.frame = frame;
-        }
+    const bool gate = duration >= kMinDitTime;  // :254, :279: shorter runs are ignored
+    // a rising edge feeds the gap threshold, a falling edge the mark threshold: the four fields that change are picked
+    // from the one, updated once, and put back into the one they came from (preset and upperBound never change here)
+    AdaptiveThreshold t;
+    t.preset = 0;
+    t.upperBound = state ? d.offThreshold.upperBound : d.onThreshold.upperBound;
+    t.low = state ? d.offThreshold.low : d.onThreshold.low;
+    t.high = state ? d.offThreshold.high : d.onThreshold.high;
+    t.last = state ? d.offThreshold.last : d.onThreshold.last;
+    t.threshold = state ? d.offThreshold.threshold : d.onThreshold.threshold;
+    at_put_select(t, duration, gate);
+    d.offThreshold.low = state ? t.low : d.offThreshold.low;
+    d.offThreshold.high = state ? t.high : d.offThreshold.high;
+    d.offThreshold.last = state ? t.last : d.offThreshold.last;
+    d.offThreshold.threshold = state ? t.threshold : d.offThreshold.threshold;
+    d.onThreshold.low = state ? d.onThreshold.low : t.low;
+    d.onThreshold.high = state ? d.onThreshold.high : t.high;
+    d.onThreshold.last = state ? d.onThreshold.last : t.last;
+    d.onThreshold.threshold = state ? d.onThreshold.threshold : t.threshold;
+    uint32_t key = 0;
+    if (state) {  // onRisingEdge :260-274
+        const bool word_gap = duration >= 4.5 * d.offThreshold.low;
+        if (gate && (word_gap || duration >= d.offThreshold.threshold))
+            key = take_char(d);
+        em.space = gate && word_gap;
+    } else {  // onFallingEdge :285-297
+        const bool invalid = gate && duration >= 2 * d.onThreshold.high;
+        const bool symbol = gate && !invalid;
+        const bool da = duration >= d.onThreshold.threshold;
+        d.currentCharInvalid = invalid ? 1 : d.currentCharInvalid;
+        if (symbol && d.charLen == kMaxSymbolCount)  // (rare)
+            key = take_char(d);
+        d.charBits = symbol ? ((d.charBits << 1) | (da ? 1u : 0u)) : d.charBits;
+        d.charLen += symbol ? 1 : 0;
+        const double wpm = (d.wpm + dit_to_wpm(d, d.onThreshold.low)) / 2.0;
+        d.wpm = (symbol && da) ? wpm : d.wpm;
+    }
+    if (key) {  // (if the abort check of this iteration's run took the character, there is none left here)
+        em.key = key;
+        em.frame = frame;
     }
     d.decoding = 1;
     d.lastState = state;
