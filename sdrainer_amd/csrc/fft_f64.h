@@ -494,6 +494,16 @@ SDR_HD constexpr RegPlan make_reg_plan(int E)
 {
     using PL = Plan<LOGN>;
     RegPlan R{0, {}};
+#if defined(SDR_FFT_B_LDS_EXCH)
+    // (experiment, round 4: layout B with its two wave-local exchanges through the wave's own LDS block instead of
+    // v_permlane / ds_bpermute.  VALID FOR ONE-FRAME WORKGROUPS ONLY (SDR_FFT_FPW=1): the blocks overlap the next frame's
+    // staging image.  Measured, 2048 x 16384 standalone: 0.169 ms (registers: 0.185 at one frame per workgroup, 0.168 at
+    // eight) against layout A's 0.162 - the cross-wave exchange right behind pass 0 still waits for the last wave's
+    // samples, and the transposed epilogue costs what the barrier-free second half gains.  With the next frame's DMA
+    // issued as if LDS were free (wrong results, timing only) 0.155: the price of that LDS is what separates the two.)
+    if (PL::LB)
+        return R;
+#endif
     if (PL::LB) {
         if (E == 1) {
             R.n = 3;

@@ -865,6 +865,9 @@ __global__ __launch_bounds__(fft64::Plan<LOGN>::T, 4) void k_fft_psd_b(const flo
                     }
                 }
             });
+#if defined(SDR_FFT_B_LDS_EXCH)
+        __syncthreads();  // (the epilogue's tile overlaps the tail of the padded exchange area: every wave is out of its last exchange)
+#endif
         store_psd_b<LOGN>(xr, xi, t, psd + (out_band + frame) * PL::N, smem + kStageBytes);
         if (tap_prev && !reg_tap)
             tap_frame_slow(frame - 1);
