@@ -33,8 +33,18 @@ constexpr int MAX_WAVES = 16;  // a workgroup is 1024 threads: one to four chain
 #define SDR_WM_GROUPS 4
 #endif
 constexpr int WM_GROUPS = SDR_WM_GROUPS;
-constexpr int NS_GROUPS = 1;  // variance chains: the producers' float64 work is the limit, all fifteen serve one chain
-                              // (two groups per workgroup: 0.324 ms instead of 0.115)
+// Variance chains (SDR_VAR_MFMA=0, the default from round 4 on): TWO chain groups of eight waves per workgroup, vector-ALU
+// consumers that square for themselves (chain_consumer<VAR>).  Round 3 ran them on the float64 matrix pipe, one group of
+// 64 chains per workgroup over four consumer waves: 5.4 clocks per term for ONE wave alone on a CU (tools/ubench_mfma_f64)
+// - but traced inside the kernel (tools/noise_trace.py) each consumer's dependent matrix instruction took 64 clocks, not
+// 21.5: four consumers on four SIMDs do not get four pipes' worth, and 16 clocks per term is what a single vector-ALU
+// consumer delivers as well (cvt, sub, mul, add: issue-bound).  Two such consumers on two SIMDs double the rate per CU,
+// at which point the producers (LDS ring capacity over memory latency) are the limit.
+// Both are built; the launch picks (launch_noise_stats): the two-group kernel where the CU time it holds is what counts
+// (long batches: config 3 at 8192 frames 161.4 against 156.7 GS/s), the matrix-pipe kernel - half the frames per
+// workgroup, twice the workgroups, 0.115 against 0.18 ms - where the noise stream's LATENCY bounds the step (config 5's
+// share 183 against 176 GS/s, config 3 at 2048 frames 143 against 135).  SDR_VAR_MFMA=0 / 1 forces one (development).
+constexpr int NS_GROUPS_VALU = 2;
 constexpr int CHAIN_THREADS = 64 * MAX_WAVES;
 // SLOTS = LDS tiles between producers and consumer: 4 float64 tiles (133 KB) for the long variance chains, 2 float32
 // tiles per group (4 x 35 KB) for the short window sums.
@@ -57,7 +67,8 @@ struct ChainShared {
     double chain_sum[TILE];                   // ... and where they leave their chains' sums
 };
 using WindowRing = ChainShared<2, float>;
-using VarianceRing = ChainShared<6, float, 2>;
+using VarianceRing = ChainShared<6, float, 2>;  // (matrix-pipe variant)
+using NoiseRing = ChainShared<4, float>;        // variance chains on the vector ALU: two groups x four float32 tiles
 
 #if defined(SDR_NOISE_TRACE)
 // diagnostic builds (tools/abl): where does the consumer of workgroup 0 spend its time?
@@ -70,14 +81,17 @@ extern "C" __attribute__((visibility("default"))) int sdr_debug_noise_trace(unsi
 
 // The rings live at file scope so that the consumer can be a function of its own (see chain_consumer).
 __shared__ WindowRing g_ring_wm[WM_GROUPS];
-__shared__ VarianceRing g_ring_ns[NS_GROUPS];
+__shared__ VarianceRing g_ring_ns[1];
+__shared__ NoiseRing g_ring_var[NS_GROUPS_VALU];
 template <class Shared>
 __device__ __forceinline__ Shared &ring(int group)
 {
     if constexpr (Shared::RING_SLOTS == WindowRing::RING_SLOTS)
         return g_ring_wm[group];
-    else
+    else if constexpr (Shared::RING_SLOTS == VarianceRing::RING_SLOTS)
         return g_ring_ns[group];
+    else
+        return g_ring_var[group];
 }
 
 // Ordering between a wave's LDS accesses and its flag accesses.  A wave's DS instructions execute in issue
@@ -163,7 +177,7 @@ __device__ __forceinline__ void chain_producer(Shared &sh, const float *__restri
 #pragma unroll
             for (int i = 0; i < HALF; i++) {
                 double x = (double)v[i];
-                if (VARIANCE) {
+                if (VARIANCE && sizeof(typename Shared::term_t) == 8) {  // (float64 tiles only: a float32 ring takes the values as they are)
                     const double d = x - readlane_f64(mean_of_lane, i);
                     x = d * d;  // math.Pow(d, 2)
                 }
@@ -175,7 +189,7 @@ __device__ __forceinline__ void chain_producer(Shared &sh, const float *__restri
 #pragma unroll
             for (int i = 0; i < HALF; i++) {
                 double x = (double)v[i];
-                if (VARIANCE) {
+                if (VARIANCE && sizeof(typename Shared::term_t) == 8) {
                     const double d = x - readlane_f64(mean_of_lane, HALF + i);
                     x = d * d;
                 }
@@ -190,10 +204,27 @@ __device__ __forceinline__ void chain_producer(Shared &sh, const float *__restri
     };
     // (Two units in flight per producer - the next unit's loads issued before this one is published - were
     // measured after the fences were gone too: window means 0.058 instead of 0.047 ms, variance chain equal.)
-    float v[HALF];
-    for (int u = p; u < n_units; u += np) {
-        fetch(v, u);
-        publish(v, u);
+    if constexpr (Shared::RING_SLOTS >= 4) {
+        // a ring of four tiles lets the producers run ahead: the next unit's reads are in flight while this one is written
+        // (what is on its way per CU is producers x units x 8 KB, and that over the memory latency is the kernel's rate:
+        // one unit each gave the two-group variance chains 33 GB/s per CU, tools/noise_trace.py)
+        float v[HALF], nv[HALF];
+        if (p < n_units)
+            fetch(nv, p);
+        for (int u = p; u < n_units; u += np) {
+#pragma unroll
+            for (int i = 0; i < HALF; i++)
+                v[i] = nv[i];
+            if (u + np < n_units)
+                fetch(nv, u + np);
+            publish(v, u);
+        }
+    } else {
+        float v[HALF];
+        for (int u = p; u < n_units; u += np) {
+            fetch(v, u);
+            publish(v, u);
+        }
     }
 }
 
@@ -204,10 +235,17 @@ __device__ __forceinline__ void chain_producer(Shared &sh, const float *__restri
 // Not inlined on purpose: inside the kernel the register allocator has the producers' half-tile of loads
 // and conversions in the same function and ends up spilling the chain's operands; as a function of its
 // own the consumer gets a clean allocation (about 70 VGPRs, nothing spilled).
-template <class Shared>
-__device__ __attribute__((noinline)) double chain_consumer(int n_tiles_any_lane, int lane, int group_any_lane)
+// VAR: the chain is a variance chain - term = (x - mean)^2 (math.Pow(d, 2), dsp/fft.go:247), widened, subtracted and squared
+// here from the ring's float32 values (three float64 operations per term beside the serial addition: the consumer becomes
+// issue-bound at 16 clocks per term, which two consumers on two SIMDs of the CU still deliver at twice the rate the matrix
+// pipe did for four); terms past the lane's chain end count as +0 (only in the tiles where some chain of the group ends:
+// a scalar branch).
+template <class Shared, bool VAR = false>
+__device__ __attribute__((noinline)) double chain_consumer(int n_tiles_any_lane, int lane, int group_any_lane, double mean = 0.0, int n_terms = 0,
+                                                           int min_terms_any_lane = 0)
 {
     using T = typename Shared::term_t;
+    const int min_terms = __builtin_amdgcn_readfirstlane(min_terms_any_lane);
     const int n_tiles = __builtin_amdgcn_readfirstlane(n_tiles_any_lane);  // wave-uniform: scalar loop control
     Shared &sh = ring<Shared>(__builtin_amdgcn_readfirstlane(group_any_lane));
     constexpr int RING_SLOTS = Shared::RING_SLOTS;
@@ -253,10 +291,33 @@ __device__ __attribute__((noinline)) double chain_consumer(int n_tiles_any_lane,
                 b[PER_READ * j + k] = v[k];
         }
     };
-    auto add = [&](const T (&b)[CH]) {
+    auto add = [&](const T (&b)[CH], int t, int c) {
+        if constexpr (!VAR) {
 #pragma unroll
-        for (int j = 0; j < CH; j++)
-            sum += (double)b[j];
+            for (int j = 0; j < CH; j++)
+                sum += (double)b[j];
+        } else {
+            // all eight squares first (24 independent operations), then the eight ordered additions: written term by
+            // term the compiler keeps each term's cvt - sub - mul - add together, four dependent operations deep
+            // (35 clocks per term measured instead of 16)
+            double p[CH];
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                const double d = (double)b[j] - mean;
+                p[j] = d * d;
+            }
+            if ((t + 1) * TILE > min_terms) {  // (wave-uniform: some chain of the group ends in this tile or before it)
+#pragma unroll
+                for (int j = 0; j < CH; j++)
+                    p[j] = (t * TILE + c * CH + j < n_terms) ? p[j] : 0.0;  // (+0.0 leaves a non-negative sum bit-identical)
+            }
+#pragma unroll
+            for (int j = 0; j < CH; j++)
+                asm volatile("" : "+v"(p[j]));
+#pragma unroll
+            for (int j = 0; j < CH; j++)
+                sum += p[j];
+        }
     };
     // Four 8-term buffers, each chunk read four chunks (32 terms, > 200 clocks of additions) before it is
     // added: chunk c of a tile lives in buffer c % 4.  Entering tile t, its chunks 0-3 are already on
@@ -274,21 +335,21 @@ __device__ __attribute__((noinline)) double chain_consumer(int n_tiles_any_lane,
         // ahead of the additions they overlap - and stops the scheduler from sinking additions below later
         // reads, which keeps a whole tile of operands alive and spills them)
 #define SDR_PIN asm volatile("" : "+v"(sum)::"memory")
-        add(q0); SDR_PIN; load(q0, t, 4); SDR_PIN;
-        add(q1); SDR_PIN; load(q1, t, 5); SDR_PIN;
+        add(q0, t, 0); SDR_PIN; load(q0, t, 4); SDR_PIN;
+        add(q1, t, 1); SDR_PIN; load(q1, t, 5); SDR_PIN;
         int f0 = 0, f1 = 0;
         if (more) {
             f0 = lds_flag_load(&sh.ready[nslot][0]);
             f1 = lds_flag_load(&sh.ready[nslot][1]);
         }
-        add(q2); SDR_PIN; load(q2, t, 6); SDR_PIN;
-        add(q3); SDR_PIN; load(q3, t, 7); SDR_PIN;
+        add(q2, t, 2); SDR_PIN; load(q2, t, 6); SDR_PIN;
+        add(q3, t, 3); SDR_PIN; load(q3, t, 7); SDR_PIN;
         if (more)
             wait_tile(t + 1, f0, f1);
-        add(q0); SDR_PIN; if (more) load(q0, t + 1, 0); SDR_PIN;
-        add(q1); SDR_PIN; if (more) load(q1, t + 1, 1); SDR_PIN;
-        add(q2); SDR_PIN; if (more) load(q2, t + 1, 2); SDR_PIN;
-        add(q3); SDR_PIN; if (more) load(q3, t + 1, 3); SDR_PIN;
+        add(q0, t, 4); SDR_PIN; if (more) load(q0, t + 1, 0); SDR_PIN;
+        add(q1, t, 5); SDR_PIN; if (more) load(q1, t + 1, 1); SDR_PIN;
+        add(q2, t, 6); SDR_PIN; if (more) load(q2, t + 1, 2); SDR_PIN;
+        add(q3, t, 7); SDR_PIN; if (more) load(q3, t + 1, 3); SDR_PIN;
 #undef SDR_PIN
         lds_order();
         if (lane == 0)
@@ -365,7 +426,7 @@ __device__ __forceinline__ double chain_run(Shared &sh, int group, int wig, cons
     }
     double sum = 0;
     if (wig == 0)
-        sum = chain_consumer<Shared>(n_tiles, lane, group);
+        sum = chain_consumer<Shared, VARIANCE && sizeof(typename Shared::term_t) == 4>(n_tiles, lane, group, my_mean, my_terms, min_terms);
     else if (!sits_out)
         chain_producer<VARIANCE>(sh, base, (unsigned)row_stride, rows, n_cols, n_tiles, min_terms, p, np, lane);
     __syncthreads();  // everyone is done with the rings before a caller re-initialises them
@@ -650,11 +711,13 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_window_means(const float *__r
 // pass 2: pick the minimum window in the reference's order, then the variance chain over
 // psd[edge .. resultTo] (inclusive) about that mean, divided by windowSize (:244-249, App. C1);
 // finally the two dB inputs of the rolling means (rx/receiver.go:383-384).
+template <bool MFMA>
 __global__ __launch_bounds__(CHAIN_THREADS) void k_noise_stats(const float *__restrict__ psd,
                                                                const double *__restrict__ win_mean,
                                                                sdr_frame_rec *__restrict__ recs, NoiseGeom g,
                                                                int n_frames, int stride)
 {
+    constexpr int NS_GROUPS = MFMA ? 1 : NS_GROUPS_VALU;
     constexpr int WPG = MAX_WAVES / NS_GROUPS;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int group = wave / WPG;
@@ -686,7 +749,11 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_noise_stats(const float *__re
     }
     // sdr_create guarantees n_windows >= 9, so every chain starts at `edge`
     const float *base = psd + frame0 * g.n + g.edge;
-    const double sum = variance_run(wave, base, g.n, rows, g.n - g.edge, n_terms, resultMean);
+    double sum;
+    if constexpr (MFMA)
+        sum = variance_run(wave, base, g.n, rows, g.n - g.edge, n_terms, resultMean);
+    else
+        sum = chain_run<true, NS_GROUPS>(ring<NoiseRing>(group), group, wig, base, g.n, rows, g.n - g.edge, n_terms, resultMean);
     if (!valid)
         return;
     const double variance = sum / (double)g.window;
@@ -881,8 +948,16 @@ hipError_t launch_window_means(const float *psd, double *win_mean, NoiseGeom g, 
 hipError_t launch_noise_stats(const float *psd, const double *win_mean, sdr_frame_rec *recs, NoiseGeom g, int n_frames,
                               int n_bands, int stride, hipStream_t stream)
 {
-    launch_kernel(k_noise_stats, dim3(((n_frames + TILE - 1) / TILE + NS_GROUPS - 1) / NS_GROUPS, n_bands), dim3(CHAIN_THREADS), 0, stream, psd, win_mean,
-                       recs, g, n_frames, stride);
+    // long batches: two vector-ALU chain groups per workgroup (less CU time); short ones: the matrix-pipe kernel (less
+    // latency) - see NS_GROUPS_VALU
+    static const int force = getenv("SDR_VAR_MFMA") ? atoi(getenv("SDR_VAR_MFMA")) : -1;  // (development)
+    const bool mfma = force >= 0 ? force != 0 : n_frames < 4096;
+    const int groups_of_64 = (n_frames + TILE - 1) / TILE;
+    if (mfma)
+        launch_kernel(k_noise_stats<true>, dim3(groups_of_64, n_bands), dim3(CHAIN_THREADS), 0, stream, psd, win_mean, recs, g, n_frames, stride);
+    else
+        launch_kernel(k_noise_stats<false>, dim3((groups_of_64 + NS_GROUPS_VALU - 1) / NS_GROUPS_VALU, n_bands), dim3(CHAIN_THREADS), 0, stream, psd,
+                      win_mean, recs, g, n_frames, stride);
     return hipGetLastError();
 }
 

@@ -26,10 +26,11 @@ namespace sdr {
 //   k_cum_bound   an UPPER BOUND of every completed cumulation from the psd words' top halves alone - for psd = m 2^E,
 //                 log2(psd) <= E + (m - 1) + 0.0861 and the float32 bits >> 16 ARE (E + 127) 128 + floor(128 (m - 1)):
 //                 one shift, one max, one add per value, 16-byte loads, nothing but the psd stream;
-//   k_find_peaks  compares bound / 100 with the threshold exactly as FindPeaks compares the cumulation (monotone
-//                 float32 operations: a bin whose BOUND is not above is not above), computes the literal ordered float32
-//                 sum of certified dB values for the bins that are - and their neighbours, which PeakCenterCorrection
-//                 reads - and scans the row with those in place: the same runs, maxima and centre values, bit for bit;
+//   k_cum_refine  compares bound / 100 with the threshold exactly as FindPeaks compares the cumulation (monotone
+//                 float32 operations: a bin whose BOUND is not above is not above) and writes the literal ordered float32
+//                 sum of certified dB values over the bound of the bins that are - and of their neighbours, which
+//                 PeakCenterCorrection reads; k_find_peaks scans the row with those in place: the same runs, maxima and
+//                 centre values, bit for bit;
 //   k_cumulate    the exact kernel of rounds 1-3: the cumulation still open at the end of a batch (its carry into the
 //                 next batch is exact for every bin: which bins will matter is not known yet), and whole rows on demand
 //                 (sdr_read_cumulation, the scope tap).
@@ -268,37 +269,30 @@ __global__ __launch_bounds__(256) void k_spectrum_row(const float *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_find_peaks — dsp.FindPeaks (dsp/fft.go:254-285) on one completed cumulation, one workgroup per cumulation.
-//  0. the row k_cum_bound left - an upper bound of the cumulation in every bin - is read once, coalesced (lane = bin),
-//     divided by 100 (float32, :259) into LDS; the bins whose bound is above the threshold and their two neighbours are
-//     the only ones FindPeaks can look at (division and comparison are monotone): they are listed (ballot words, a popcount
-//     prefix) and each gets its exact cumulation - the carry, then the ordered float32 sum of the certified dB values of
-//     its 100 frames (cum_exact_column) - written back into the row and into LDS;
-//  1. the 64 comparison results of a wave instruction are one ballot word of a bit array (bit b = `value[b] > threshold`,
-//     :260), now from exact values wherever it can be set;
-//  2. run starts are bit operations on that array (a set bit whose predecessor is clear), counted with popcount and
-//     numbered by one wave's prefix sum over the words: the peak list comes out in bin order, as the reference's;
-//  3. the thread that owns a word walks the runs starting in it: the run's end is found in the bit array (count of
-//     trailing ones), its maximum in the LDS row, first maximum wins (strict `<`, :270); a run still open at the last
-//     bin ends there (:276-282).
+// k_cum_refine — the exact cumulation where FindPeaks will look (see the head of the cumulation section): for one
+// completed cumulation and one span of 4096 bins, the bins whose bound / 100 is above the threshold (the comparison
+// FindPeaks makes, dsp/fft.go:259-260: a bin whose BOUND is not above is not above) and their two neighbours (the
+// centre correction reads them) are listed - ballot words, a popcount prefix - and each gets the carry plus the ordered
+// float32 sum of the certified dB values of its frames (cum_exact_column), written over its bound in the row.  Dense
+// lanes: entry k of the list goes to thread k (neighbouring bins of a run sit in neighbouring lanes).  Four workgroups
+// per row rather than the row's peak scan doing it itself: a cumulation's refinement is a latency chain (a hundred
+// scattered 64-byte sectors per candidate cluster) and at 2048 frames per batch the peaks stream had become the longest
+// of the four with it (134 instead of 150 GS/s).
+// A neighbour span may be rewriting the halo bin this workgroup classifies while it reads it: it then sees either the
+// bound or the exact value, and both classify every bin that is above as above - the list can only differ in bins that
+// need not have been refined.
 // ---------------------------------------------------------------------------------------------
-constexpr int kPeakThreadsMax = 1024;
+constexpr int kRefineSpan = 4096, kRefineThreads = 256;
 __device__ __forceinline__ int peak_words(int n) { return n >> 6; }
-// dynamic LDS: val [n] float, list [n] uint16, flags / starts / rflags [words] u64 each, offs [words + 1] int, dB tables
-__host__ __device__ inline size_t peak_lds_bytes(int n)
-{
-    const size_t words = (size_t)(n >> 6);
-    return (size_t)n * 4 + (size_t)n * 2 + words * 24 + (words + 1) * 4 + 16 + gomath::kDbTabBytes;
-}
 
-// exclusive prefix of per-word bit counts (wave 0: each lane takes `per` consecutive words); returns the total in every
-// lane of wave 0
-__device__ __forceinline__ int word_prefix(const unsigned long long *bits, int *offs, int words, int tid)
+// exclusive prefix of per-word bit counts over `words` words (one wave: each lane takes `per` consecutive words);
+// offs[words] = the total, also returned in every lane
+__device__ __forceinline__ int word_prefix(const unsigned long long *bits, int *offs, int words, int lane)
 {
     const int per = (words + 63) >> 6;
     int local = 0;
     for (int k = 0; k < per; k++) {
-        const int w = tid * per + k;
+        const int w = lane * per + k;
         if (w < words)
             local += __popcll(bits[w]);
     }
@@ -306,30 +300,35 @@ __device__ __forceinline__ int word_prefix(const unsigned long long *bits, int *
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const int up = __shfl_up(incl, o);
-        if (tid >= o)
+        if (lane >= o)
             incl += up;
     }
     int run = incl - local;
     for (int k = 0; k < per; k++) {
-        const int w = tid * per + k;
+        const int w = lane * per + k;
         if (w < words) {
             offs[w] = run;
             run += __popcll(bits[w]);
         }
     }
     const int total = __shfl(incl, 63);
-    if (tid == 63)
+    if (lane == 63)
         offs[words] = total;
     return total;
 }
 
-__global__ __launch_bounds__(kPeakThreadsMax) void k_find_peaks(float *__restrict__ cum, const float *__restrict__ psd, const void *__restrict__ db_tab,
-                                                                 const float *__restrict__ carry0, const float *__restrict__ carry1, int carry_in_arg,
-                                                                 const sdr_frame_rec *__restrict__ recs, DevPeak *__restrict__ peaks, int *__restrict__ counts,
-                                                                 const BatchCursor *__restrict__ cur, PeakGeom g, int n_frames, double inv_n2)
+__global__ __launch_bounds__(kRefineThreads) void k_cum_refine(float *__restrict__ cum, const float *__restrict__ psd, const void *__restrict__ db_tab,
+                                                               const float *__restrict__ carry0, const float *__restrict__ carry1, int carry_in_arg,
+                                                               const sdr_frame_rec *__restrict__ recs, const BatchCursor *__restrict__ cur, PeakGeom g,
+                                                               int n_frames, double inv_n2)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_peaks[];
-    const int chunk = blockIdx.x, band = blockIdx.y, tid = threadIdx.x, lane = threadIdx.x & 63;
+    constexpr int SW = kRefineSpan / 64;  // words per span
+    __shared__ __attribute__((aligned(16))) unsigned char s_tab[gomath::kDbTabBytes];
+    __shared__ unsigned long long s_flags[SW + 2];  // [0] / [SW + 1]: the neighbours' edge words
+    __shared__ unsigned long long s_rflags[SW];
+    __shared__ int s_offs[SW + 1];
+    __shared__ unsigned short s_list[kRefineSpan];
+    const int chunk = blockIdx.x, span = blockIdx.y, band = blockIdx.z, tid = threadIdx.x, lane = threadIdx.x & 63;
     int carry_sel = carry_in_arg;
     if (cur) {
         g.count0 = cur->count0;
@@ -337,14 +336,9 @@ __global__ __launch_bounds__(kPeakThreadsMax) void k_find_peaks(float *__restric
         if (chunk >= chunks_completed(g.count0, n_frames))
             return;
     }
-    const int n = g.n, words = peak_words(n), T = blockDim.x;
-    float *val = reinterpret_cast<float *>(smem_peaks);                                               // [n]
-    unsigned short *list = reinterpret_cast<unsigned short *>(smem_peaks + (size_t)n * 4);            // [n]
-    unsigned long long *flags = reinterpret_cast<unsigned long long *>(smem_peaks + (size_t)n * 6);   // [words]
-    unsigned long long *starts = flags + words;                                                       // [words]
-    unsigned long long *rflags = starts + words;                                                      // [words]
-    int *offs = reinterpret_cast<int *>(rflags + words);                                              // [words + 1]
-    unsigned char *s_tab = smem_peaks + (((size_t)n * 6 + (size_t)words * 24 + (size_t)(words + 1) * 4 + 15) & ~(size_t)15);
+    const int n = g.n, T = blockDim.x;
+    const int bin0 = span * kRefineSpan;
+    const int span_bins = min(kRefineSpan, n - bin0), words = span_bins >> 6;  // (n is a multiple of 64)
     {
         const uint4 *src = static_cast<const uint4 *>(db_tab);
         uint4 *dst = reinterpret_cast<uint4 *>(s_tab);
@@ -356,7 +350,94 @@ __global__ __launch_bounds__(kPeakThreadsMax) void k_find_peaks(float *__restric
     const float thr = recs[(size_t)band * g.stride + end_frame].peak_thr;
     float *c = cum + ((size_t)band * g.max_chunks + chunk) * n;
     const float size = (float)SDR_CUMULATION_SIZE;
-    // 0. bounds and their flag words (n is a multiple of T, T a multiple of 64: every wave instruction covers 64 whole bins)
+    // flag words of the span and of the word on either side of it (zero beyond the row)
+    for (int w = (tid >> 6); w < words + 2; w += (T >> 6)) {  // (one wave per word: 64 whole bins per wave instruction)
+        const int b = bin0 + (w - 1) * 64 + lane;
+        const bool above = b >= 0 && b < n && __fdiv_rn(c[b], size) > thr;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(above);
+        if (lane == 0)
+            s_flags[w] = m;
+    }
+    __syncthreads();
+    for (int w = tid; w < words; w += T) {
+        const unsigned long long f = s_flags[w + 1];
+        s_rflags[w] = f | (f << 1) | (f >> 1) | (s_flags[w] >> 63) | (s_flags[w + 2] << 63);
+    }
+    __syncthreads();
+    if (tid < 64)
+        word_prefix(s_rflags, s_offs, words, tid);
+    __syncthreads();
+    const int n_exact = s_offs[words];
+    if (n_exact == 0)  // (workgroup-uniform)
+        return;
+    for (int w = tid; w < words; w += T) {
+        unsigned long long r = s_rflags[w];
+        int at = s_offs[w];
+        while (r) {
+            s_list[at++] = (unsigned short)((w << 6) + __builtin_ctzll(r));
+            r &= r - 1;
+        }
+    }
+    __syncthreads();
+    const gomath::DbTables tab = gomath::db_tables(s_tab);
+    int begin, len;
+    cum_slot_frames(chunk, g.count0, &begin, &len);
+    const float *__restrict__ carry_in = carry_sel ? carry1 : carry0;
+    const float *__restrict__ base = psd + (size_t)band * g.stride * n;
+    for (int k0 = 0; k0 < n_exact; k0 += T) {
+        const int k = k0 + tid;
+        const bool mine = k < n_exact;
+        const int bin = bin0 + (int)s_list[mine ? k : n_exact - 1];
+        float acc = 0.f;
+        if (chunk == 0 && g.count0 > 0)
+            acc = carry_in[(size_t)band * n + bin];
+        // (every lane of a wave that has an entry runs the column loop - the rare literal-log branch inside it is a
+        // wave-wide vote - lanes without one repeat the last entry and store nothing)
+        if (k0 + (tid & ~63) < n_exact) {
+            // (scattered columns, one 64-byte sector per cluster of candidates and frame: latency-bound, many loads in flight)
+            acc = cum_exact_column<SDR_REFINE_U>(base, (unsigned)begin * (unsigned)n + (unsigned)bin, (unsigned)n, len, acc, tab, inv_n2);
+            if (mine)
+                c[bin] = acc;  // the row holds the exact cumulation wherever FindPeaks reads it
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_find_peaks — dsp.FindPeaks (dsp/fft.go:254-285) on one completed cumulation, one workgroup per cumulation.  The row
+// holds the exact cumulation wherever a bin can be above the threshold and beside such bins (k_cum_refine), an upper
+// bound elsewhere: every comparison, maximum and centre value below is the reference's.
+//  1. the row is read once, coalesced (lane = bin), divided by 100 (float32, :259) and kept in LDS; the 64 comparison
+//     results of a wave instruction are one ballot word of a bit array (bit b = `value[b] > threshold`, :260);
+//  2. run starts are bit operations on that array (a set bit whose predecessor is clear), counted with popcount and
+//     numbered by one wave's prefix sum over the words: the peak list comes out in bin order, as the reference's;
+//  3. the thread that owns a word walks the runs starting in it: the run's end is found in the bit array (count of
+//     trailing ones), its maximum in the LDS row, first maximum wins (strict `<`, :270); a run still open at the last
+//     bin ends there (:276-282).
+// ---------------------------------------------------------------------------------------------
+constexpr int kPeakThreadsMax = 1024;
+
+__global__ __launch_bounds__(kPeakThreadsMax) void k_find_peaks(const float *__restrict__ cum, const sdr_frame_rec *__restrict__ recs,
+                                                                 DevPeak *__restrict__ peaks, int *__restrict__ counts,
+                                                                 const BatchCursor *__restrict__ cur, PeakGeom g, int n_frames)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_peaks[];
+    const int chunk = blockIdx.x, band = blockIdx.y, tid = threadIdx.x, lane = threadIdx.x & 63;
+    if (cur) {
+        g.count0 = cur->count0;
+        if (chunk >= chunks_completed(g.count0, n_frames))
+            return;
+    }
+    const int n = g.n, words = peak_words(n), T = blockDim.x;
+    float *val = reinterpret_cast<float *>(smem_peaks);                                      // [n]
+    unsigned long long *flags = reinterpret_cast<unsigned long long *>(smem_peaks + (size_t)n * 4);  // [words]
+    unsigned long long *starts = flags + words;                                              // [words]
+    int *offs = reinterpret_cast<int *>(starts + words);                                     // [words + 1]
+    const int first_len = SDR_CUMULATION_SIZE - g.count0;
+    const int end_frame = first_len + chunk * SDR_CUMULATION_SIZE - 1;  // frame that completes this chunk
+    const float thr = recs[(size_t)band * g.stride + end_frame].peak_thr;
+    const float *c = cum + ((size_t)band * g.max_chunks + chunk) * n;
+    const float size = (float)SDR_CUMULATION_SIZE;
+    // 1. values and flag words (n is a multiple of T, T a multiple of 64: every wave instruction covers 64 whole bins)
 #pragma unroll 8
     for (int b = tid; b < n; b += T) {
         const float v = __fdiv_rn(c[b], size);
@@ -366,59 +447,6 @@ __global__ __launch_bounds__(kPeakThreadsMax) void k_find_peaks(float *__restric
             flags[b >> 6] = m;
     }
     __syncthreads();
-    // the bins to evaluate exactly: flagged by their bound, or next to one that is
-    for (int w = tid; w < words; w += T) {
-        const unsigned long long f = flags[w];
-        rflags[w] = f | (f << 1) | (f >> 1) | (w > 0 ? flags[w - 1] >> 63 : 0ull) | (w + 1 < words ? flags[w + 1] << 63 : 0ull);
-    }
-    __syncthreads();
-    if (tid < 64)
-        word_prefix(rflags, offs, words, tid);
-    __syncthreads();
-    const int n_exact = offs[words];
-    for (int w = tid; w < words; w += T) {
-        unsigned long long r = rflags[w];
-        int at = offs[w];
-        while (r) {
-            list[at++] = (unsigned short)((w << 6) + __builtin_ctzll(r));
-            r &= r - 1;
-        }
-    }
-    __syncthreads();
-    if (n_exact > 0) {  // (workgroup-uniform)
-        const gomath::DbTables tab = gomath::db_tables(s_tab);
-        int begin, len;
-        cum_slot_frames(chunk, g.count0, &begin, &len);
-        const float *__restrict__ carry_in = carry_sel ? carry1 : carry0;
-        const float *__restrict__ base = psd + (size_t)band * g.stride * n;
-        // dense lanes: entry k of the list goes to thread k (neighbouring bins of a run sit in neighbouring lanes)
-        for (int k0 = 0; k0 < n_exact; k0 += T) {
-            const int k = k0 + tid;
-            const bool mine = k < n_exact;
-            const int bin = list[mine ? k : n_exact - 1];
-            float acc = 0.f;
-            if (chunk == 0 && g.count0 > 0)
-                acc = carry_in[(size_t)band * n + bin];
-            // (every lane of a wave that has an entry runs the column loop - the rare literal-log branch inside it is
-            // a wave-wide vote - lanes without one repeat the last entry and store nothing)
-            if (k0 + (tid & ~63) < n_exact) {
-                // (scattered columns, one 64-byte sector per cluster of candidates and frame: latency-bound, many loads in flight)
-                acc = cum_exact_column<SDR_REFINE_U>(base, (unsigned)begin * (unsigned)n + (unsigned)bin, (unsigned)n, len, acc, tab, inv_n2);
-                if (mine) {
-                    c[bin] = acc;  // the row holds the exact cumulation wherever FindPeaks reads it
-                    val[bin] = __fdiv_rn(acc, size);
-                }
-            }
-        }
-        __syncthreads();
-        // 1. the flag words again, from exact values wherever a bit can be set
-        for (int b = tid; b < n; b += T) {
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(val[b] > thr);
-            if (lane == 0)
-                flags[b >> 6] = m;
-        }
-        __syncthreads();
-    }
     // 2. run starts per word, numbered by a prefix sum
     for (int w = tid; w < words; w += T) {
         const unsigned long long f = flags[w];
@@ -478,8 +506,7 @@ __global__ __launch_bounds__(kPeakThreadsMax) void k_find_peaks(float *__restric
                 p.to = to;
                 p.signal_bin = best_bin;
                 p.signal_value = best;
-                // (exact: neighbours of a flagged bin were evaluated above; written by this workgroup, behind barriers)
-                p.y1 = best_bin > 0 ? c[best_bin - 1] : 0.f;
+                p.y1 = best_bin > 0 ? c[best_bin - 1] : 0.f;  // (exact: neighbours of a flagged bin were refined)
                 p.y2 = c[best_bin];
                 p.y3 = best_bin < n - 1 ? c[best_bin + 1] : 0.f;
                 peaks[((size_t)band * g.max_chunks + chunk) * g.max_peaks + idx] = p;
@@ -489,12 +516,31 @@ __global__ __launch_bounds__(kPeakThreadsMax) void k_find_peaks(float *__restric
     }
 }
 
+// Bound-and-refine replaces the exact kernel's work with three launches on the peaks stream; on a short batch their fixed
+// latencies (a refinement is a chain of a hundred scattered sector reads per candidate, whatever the batch) make that
+// stream the longest of the four: config 3 at 2048 frames per batch 135-143 GS/s against 150 with every slot exact.  From
+// 64 M samples per batch on it pays (config 3 at 8192 frames, config 5's share of 8 x 2048 x 8192).  SDR_CUM_BOUND=0 / 1
+// forces one (development).
+static bool cum_bound_pays(int n_frames, int n_bands, int n)
+{
+    static const int force = getenv("SDR_CUM_BOUND") ? atoi(getenv("SDR_CUM_BOUND")) : -1;
+    if (force >= 0)
+        return force != 0;
+    return (double)n_frames * (double)n_bands * (double)n >= 64.0 * 1024.0 * 1024.0;
+}
+
 // One batch's cumulation work, on `stream`: bounds of the cumulations it completes, the exact carry of the one it leaves
 // open.  (A stage event armed by the caller rides on the last launch.)
 hipError_t launch_cumulate(const float *psd, const void *db_tab, float *carry0, float *carry1, int carry_in, float *cum_out,
                            const BatchCursor *cur, CumGeom g, int n_slots, int n_bands, hipStream_t stream)
 {
     const double inv_n2 = 1.0 / ((double)g.n * (double)g.n);
+    const int threads = g.n < SDR_CUM_THREADS ? g.n : SDR_CUM_THREADS;
+    if (!cum_bound_pays(g.n_frames, n_bands, g.n)) {  // short batches: every slot exact, one launch (as rounds 1-3)
+        launch_kernel(k_cumulate, dim3((g.n + threads - 1) / threads, n_slots, n_bands), dim3(threads), 0, stream, psd, db_tab, carry0, carry1,
+                      carry_in, cum_out, static_cast<float *>(nullptr), cur, g, 0, 0, inv_n2);
+        return hipGetLastError();
+    }
     double a128, per_frame;
     gomath::cum_bound_constants(g.n, &a128, &per_frame);
     const hipEvent_t done = t_done_event;
@@ -516,11 +562,19 @@ hipError_t launch_cumulate(const float *psd, const void *db_tab, float *carry0, 
         static const int wgs_env = getenv("SDR_BOUND_WGS") ? atoi(getenv("SDR_BOUND_WGS")) : SDR_BOUND_WGS;  // (development)
         const int threads = (g.n / 4) < kBoundThreads ? g.n / 4 : kBoundThreads;
         const int blocks = (g.n / 4 + threads - 1) / threads, items = n_bands * n_slots * blocks;
-        const int wgs = items < wgs_env ? items : wgs_env;
+        // as few workgroups as keep the kernel a fraction of the batch's FFT time (the peaks stream must not become the
+        // longest of the four): one item per workgroup for a 2048 x 16384 batch (84 items, round 4: 64 workgroups took two
+        // rounds there and bound the step - 127 instead of 150 GS/s), about four for four times the samples
+        const double batch_samples = (double)g.n_frames * (double)n_bands * (double)g.n;
+        int rounds = (int)(batch_samples / (2048.0 * 16384.0) + 0.5);
+        rounds = rounds < 1 ? 1 : (rounds > 5 ? 5 : rounds);
+        int wgs = (items + rounds - 1) / rounds;
+        if (getenv("SDR_BOUND_WGS"))
+            wgs = wgs_env;
+        wgs = wgs < 1 ? 1 : (wgs > items ? items : wgs);
         hipLaunchKernelGGL(k_cum_bound, dim3(wgs), dim3(threads), kBoundLdsBytes, stream, psd, carry0, carry1, carry_in, cum_out, cur, g, n_slots,
                            n_bands, a128, per_frame);
     }
-    const int threads = g.n < SDR_CUM_THREADS ? g.n : SDR_CUM_THREADS;
     t_done_event = done;
     launch_kernel(k_cumulate, dim3((g.n + threads - 1) / threads, 1, n_bands), dim3(threads), 0, stream, psd, db_tab, carry0, carry1, carry_in,
                   cum_out, static_cast<float *>(nullptr), cur, g, 1, 0, inv_n2);
@@ -552,7 +606,8 @@ hipError_t launch_find_peaks(float *cum, const float *psd, const void *db_tab, c
 {
     if (n_chunks == 0)
         return hipSuccess;
-    const unsigned lds = (unsigned)peak_lds_bytes(g.n);
+    const int words = g.n >> 6;
+    const unsigned lds = (unsigned)((size_t)g.n * 4 + (size_t)words * 16 + (size_t)(words + 1) * 4);
     // more than 64 KB of dynamic LDS needs the attribute, once per device
     static std::once_flag attr_once[64];
     int dev = 0;
@@ -564,14 +619,21 @@ hipError_t launch_find_peaks(float *cum, const float *psd, const void *db_tab, c
     hipError_t attr_err = hipSuccess;
     std::call_once(attr_once[dev], [&] {
         attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_find_peaks), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)peak_lds_bytes(16384));
+                                       16384 * 4 + 256 * 16 + 257 * 4);
     });
     if (attr_err != hipSuccess)
         return attr_err;
-    const int threads = g.n < kPeakThreadsMax ? g.n : kPeakThreadsMax;
+    // the exact cumulation where the scan will look, then the scan (a stage event armed by the caller rides on the scan)
+    const hipEvent_t done = t_done_event;
+    t_done_event = nullptr;
     const double inv_n2 = 1.0 / ((double)g.n * (double)g.n);
-    launch_kernel(k_find_peaks, dim3(n_chunks, n_bands), dim3(threads), lds, stream, cum, psd, db_tab, carry0, carry1, carry_in, recs, peaks,
-                  counts, cur, g, n_frames, inv_n2);
+    if (cum_bound_pays(n_frames, n_bands, g.n))  // (otherwise k_cumulate left every row exact)
+        hipLaunchKernelGGL(k_cum_refine, dim3(n_chunks, (g.n + kRefineSpan - 1) / kRefineSpan, n_bands), dim3(kRefineThreads), 0, stream, cum, psd,
+                           db_tab, carry0, carry1, carry_in, recs, cur, g, n_frames, inv_n2);
+    t_done_event = done;
+    const int threads = g.n < kPeakThreadsMax ? g.n : kPeakThreadsMax;
+    launch_kernel(k_find_peaks, dim3(n_chunks, n_bands), dim3(threads), lds, stream, static_cast<const float *>(cum), recs, peaks, counts, cur, g,
+                  n_frames);
     return hipGetLastError();
 }
 

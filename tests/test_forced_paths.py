@@ -1,0 +1,27 @@
+"""Two stages have two implementations and the launch picks by batch geometry: the cumulation (every slot exact for short
+batches; an upper bound of every completed cumulation + the exact value only where FindPeaks looks, from 64 M samples per
+batch on: k_peaks.hip) and FindNoiseFloor's variance chains (the float64 matrix pipe for short batches, two vector-ALU
+chain groups per workgroup for long ones: k_noise.hip).  The parity tests run each at the sizes that pick it; here each is
+FORCED onto the sizes that would not (SDR_CUM_BOUND / SDR_VAR_MFMA), in a process of its own, so that carries, partial
+slots, nine-window geometries, batch splits and the bench-size batches all go through both."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = "test_receiver_run_bit_exact or test_nine_window_geometry or test_config5_geometry or test_batch_split_invariance_and_carry"
+
+
+@pytest.mark.parametrize("env, files, sel", [
+    ({"SDR_CUM_BOUND": "1", "SDR_VAR_MFMA": "0"}, ["tests/test_gpu_parity.py", "tests/test_dsp_golden.py"], SMALL + " or golden"),
+    ({"SDR_CUM_BOUND": "0", "SDR_VAR_MFMA": "1"}, ["tests/test_gpu_parity_bench_sizes.py"], "config3 or config5 or config2"),
+])
+def test_parity_with_the_other_implementation_forced(env, files, sel):
+    p = subprocess.run([sys.executable, "-m", "pytest", *[os.path.join(ROOT, f) for f in files], "-q", "-x", "-m", "gpu", "-k", sel,
+                        "-p", "no:cacheprovider"], env=dict(os.environ, **env), cwd=ROOT, capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert " passed" in p.stdout and "failed" not in p.stdout
