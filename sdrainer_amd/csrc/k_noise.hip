@@ -173,6 +173,20 @@ __device__ __forceinline__ void chain_producer(Shared &sh, const float *__restri
                 __builtin_amdgcn_s_sleep(1);
         lds_order();
         const bool full = (t + 1) * TILE <= min_terms;  // every chain still covers the whole tile
+        if constexpr (sizeof(typename Shared::term_t) == 4) {
+            // float32 ring: the values as they are - and in a full tile nothing but the stores (the producers' vector-ALU
+            // work lands on SIMDs that other groups' consumers chain on: with a conversion, a lane read, a compare and a
+            // select per element the two-group variance consumers ran at 32 clocks per term instead of their own 16)
+            if (full) {
+#pragma unroll
+                for (int i = 0; i < HALF; i++)
+                    sh.term[slot][h * HALF + i][lane] = v[i];
+                lds_order();
+                if (lane == 0)
+                    lds_flag_store(&sh.ready[slot][h], t + 1);
+                return;
+            }
+        }
         if (h == 0) {
 #pragma unroll
             for (int i = 0; i < HALF; i++) {
@@ -291,32 +305,45 @@ __device__ __attribute__((noinline)) double chain_consumer(int n_tiles_any_lane,
                 b[PER_READ * j + k] = v[k];
         }
     };
-    auto add = [&](const T (&b)[CH], int t, int c) {
+    // VAR: the squares of the chunk that is added next (carried from step to step)
+    double pc[CH] = {};
+    auto squares = [&](double (&p)[CH], const T (&b)[CH], int t, int c) {
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            const double d = (double)b[j] - mean;
+            p[j] = d * d;
+        }
+        if ((t + 1) * TILE > min_terms) {  // (wave-uniform: some chain of the group ends in this tile or before it)
+#pragma unroll
+            for (int j = 0; j < CH; j++)
+                p[j] = (t * TILE + c * CH + j < n_terms) ? p[j] : 0.0;  // (+0.0 leaves a non-negative sum bit-identical)
+        }
+    };
+    // one step = the eight ordered additions of chunk (t, c).  VAR: its squares were formed a step ago; the NEXT chunk's
+    // (`bn`, chunk (tn, cn), read three steps ago) are formed here, in the same straight-line block, so that their 24
+    // independent operations fill the issue slots each dependent addition leaves open (squares first, then additions:
+    // 32 clocks per term measured; term by term: 35; the pipe's own rate for four operations per term is 16).
+    auto add = [&](const T (&b)[CH], int t, int c, const T (&bn)[CH], int tn, int cn, bool have_next) {
         if constexpr (!VAR) {
 #pragma unroll
             for (int j = 0; j < CH; j++)
                 sum += (double)b[j];
         } else {
-            // all eight squares first (24 independent operations), then the eight ordered additions: written term by
-            // term the compiler keeps each term's cvt - sub - mul - add together, four dependent operations deep
-            // (35 clocks per term measured instead of 16)
-            double p[CH];
+            double pn[CH];
 #pragma unroll
             for (int j = 0; j < CH; j++) {
-                const double d = (double)b[j] - mean;
-                p[j] = d * d;
+                sum += pc[j];
+                const double d = (double)bn[j] - mean;
+                pn[j] = d * d;
             }
-            if ((t + 1) * TILE > min_terms) {  // (wave-uniform: some chain of the group ends in this tile or before it)
+            if (have_next && (tn + 1) * TILE > min_terms) {
 #pragma unroll
                 for (int j = 0; j < CH; j++)
-                    p[j] = (t * TILE + c * CH + j < n_terms) ? p[j] : 0.0;  // (+0.0 leaves a non-negative sum bit-identical)
+                    pn[j] = (tn * TILE + cn * CH + j < n_terms) ? pn[j] : 0.0;
             }
 #pragma unroll
             for (int j = 0; j < CH; j++)
-                asm volatile("" : "+v"(p[j]));
-#pragma unroll
-            for (int j = 0; j < CH; j++)
-                sum += p[j];
+                pc[j] = pn[j];
         }
     };
     // Four 8-term buffers, each chunk read four chunks (32 terms, > 200 clocks of additions) before it is
@@ -328,6 +355,8 @@ __device__ __attribute__((noinline)) double chain_consumer(int n_tiles_any_lane,
     load(q1, 0, 1);
     load(q2, 0, 2);
     load(q3, 0, 3);
+    if constexpr (VAR)
+        squares(pc, q0, 0, 0);
     for (int t = 0; t < n_tiles; t++) {
         const bool more = t + 1 < n_tiles;
         const int nslot = (t + 1) % RING_SLOTS;
@@ -335,21 +364,21 @@ __device__ __attribute__((noinline)) double chain_consumer(int n_tiles_any_lane,
         // ahead of the additions they overlap - and stops the scheduler from sinking additions below later
         // reads, which keeps a whole tile of operands alive and spills them)
 #define SDR_PIN asm volatile("" : "+v"(sum)::"memory")
-        add(q0, t, 0); SDR_PIN; load(q0, t, 4); SDR_PIN;
-        add(q1, t, 1); SDR_PIN; load(q1, t, 5); SDR_PIN;
+        add(q0, t, 0, q1, t, 1, true); SDR_PIN; load(q0, t, 4); SDR_PIN;
+        add(q1, t, 1, q2, t, 2, true); SDR_PIN; load(q1, t, 5); SDR_PIN;
         int f0 = 0, f1 = 0;
         if (more) {
             f0 = lds_flag_load(&sh.ready[nslot][0]);
             f1 = lds_flag_load(&sh.ready[nslot][1]);
         }
-        add(q2, t, 2); SDR_PIN; load(q2, t, 6); SDR_PIN;
-        add(q3, t, 3); SDR_PIN; load(q3, t, 7); SDR_PIN;
+        add(q2, t, 2, q3, t, 3, true); SDR_PIN; load(q2, t, 6); SDR_PIN;
+        add(q3, t, 3, q0, t, 4, true); SDR_PIN; load(q3, t, 7); SDR_PIN;
         if (more)
             wait_tile(t + 1, f0, f1);
-        add(q0, t, 4); SDR_PIN; if (more) load(q0, t + 1, 0); SDR_PIN;
-        add(q1, t, 5); SDR_PIN; if (more) load(q1, t + 1, 1); SDR_PIN;
-        add(q2, t, 6); SDR_PIN; if (more) load(q2, t + 1, 2); SDR_PIN;
-        add(q3, t, 7); SDR_PIN; if (more) load(q3, t + 1, 3); SDR_PIN;
+        add(q0, t, 4, q1, t, 5, true); SDR_PIN; if (more) load(q0, t + 1, 0); SDR_PIN;
+        add(q1, t, 5, q2, t, 6, true); SDR_PIN; if (more) load(q1, t + 1, 1); SDR_PIN;
+        add(q2, t, 6, q3, t, 7, true); SDR_PIN; if (more) load(q2, t + 1, 2); SDR_PIN;
+        add(q3, t, 7, q0, t + 1, 0, more); SDR_PIN; if (more) load(q3, t + 1, 3); SDR_PIN;
 #undef SDR_PIN
         lds_order();
         if (lane == 0)
