@@ -589,6 +589,9 @@ def main():
         tops = ops_fft * samples_per_step_rank / (fft_avg_ms * 1e-3) / 1e12
         result["roofline"]["compute"] = {
             "bound": "f64_valu", "ops_per_sample": ops_fft, "achieved_Tops": round(tops, 2), "peak_Tops": F64_PEAK_TOPS,
+            # (the spec clock; inside k_fft_psd the shader clock reads 2.25 GHz - profiles/*_fft_standalone.txt - where the
+            # same count gives 36.9: fractions of the peak below are about 6 % higher against that)
+            "peak_Tops_at_measured_clock": round(F64_PEAK_TOPS * 2.25 / 2.4, 1),
             "frac": round(tops / F64_PEAK_TOPS, 4),
             "ceiling_hbm_frac": round(F64_PEAK_TOPS * 1e12 / ops_fft * BYTES_PER_SAMPLE / (HBM_PEAK_GBS * 1e9), 4),
             "whole_path_ops_per_sample": ops_path,

@@ -123,9 +123,11 @@ struct BatchSet {
         cum_out.release();
         dev_peaks.release();
         peak_counts.release();
-        for (auto &e : done)
+        for (auto &e : done) {
             if (e)
                 (void)hipEventDestroy(e);
+            e = nullptr;
+        }
     }
 };
 

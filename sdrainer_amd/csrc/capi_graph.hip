@@ -65,10 +65,10 @@ extern "C" {
 // while a replay runs.
 int sdr_graph_batches(sdr_bank *b) { return b ? RING : 0; }
 
-int sdr_graph_release(sdr_bank *b)
+namespace {
+// keep_sets: the replays' buffer sets stay allocated (a re-capture follows: sdr_graph_capture releases first)
+static int graph_release(sdr_bank *b, bool keep_sets)
 {
-    if (!b)
-        return fail(SDR_ERR_BAD_ARG, "null bank");
     int rc = sync_bank(b);
     if (rc)
         return rc;
@@ -78,7 +78,34 @@ int sdr_graph_release(sdr_bank *b)
         return rc;
     drop_graphs(b);
     b->graph_ready = false;
+    if (!keep_sets && b->set.size() > (size_t)RING) {
+        // Graph mode's GRAPH_PHASES * RING buffer sets go back (3.4 GB at config 3's 2048-frame batches, 13 GB at its
+        // 8192-frame ones or at config 5's share): a bank that tried graph mode once does not keep paying for it.  Every
+        // undelivered batch of theirs has just been parked; the eager ring never indexes them.
+        HIP_TRY(hipSetDevice(b->device));
+        for (size_t i = RING; i < b->set.size(); i++) {
+            b->set[i].release();
+            host::ResultSet &rs = b->results->set((int)i);
+            if (rs.block)
+                (void)hipHostFree(rs.block);
+            if (rs.ev_listen)
+                (void)hipEventDestroy(static_cast<hipEvent_t>(rs.ev_listen));
+            if (rs.ev_peaks)
+                (void)hipEventDestroy(static_cast<hipEvent_t>(rs.ev_peaks));
+            rs.block = nullptr;
+            rs.ev_listen = rs.ev_peaks = nullptr;
+        }
+        b->set.resize(RING);
+    }
     return SDR_OK;
+}
+}  // namespace
+
+int sdr_graph_release(sdr_bank *b)
+{
+    if (!b)
+        return fail(SDR_ERR_BAD_ARG, "null bank");
+    return graph_release(b, false);
 }
 
 int sdr_graph_capture(sdr_bank *b, int n_frames)
@@ -95,7 +122,7 @@ int sdr_graph_capture(sdr_bank *b, int n_frames)
         return fail(SDR_ERR_STATE, "graph mode and the deferred listen half exclude each other (sdr_process_listen / sdr_defer_listen(0) first)");
     if (!b->own_stream[S_NOISE])
         return fail(SDR_ERR_STATE, "graph mode needs the bank's own side streams (SDR_NO_OVERLAP is set)");
-    int rc = sdr_graph_release(b);  // (also drains the pipeline)
+    int rc = graph_release(b, true);  // (also drains the pipeline; the sets of an earlier capture are reused)
     if (rc)
         return rc;
     if (b->results_on)

@@ -733,6 +733,62 @@ def test_graph_mode_bit_exact(capi):
     bank.close()
 
 
+def test_graph_release_with_many_unpolled_replays(capi):
+    """Round 3's review: more than GRAPH_PHASES * RING (24) undelivered batches at sdr_graph_release used to be parked out of
+    order (the set index wraps) and delivery stalled with 'results ... not where they should be'.  Five replays (30
+    batches) without a single poll, the release (which also gives the replays' buffer sets back), then every batch polled
+    in order against the oracle; six eager batches; a second capture - the sets come back - and two more replays."""
+    import torch
+
+    n, rate, tones, per = 1024, 96000, 4, 120
+    edge = synth.default_edge_width(n)
+    bank = capi.Bank(rate, n, edge_width=edge, max_batch_frames=per, max_listeners=tones, max_peaks=128)
+    K = bank.graph_batches
+    reps1, reps2 = 5, 2
+    frames = (reps1 + 1 + reps2) * K * per
+    iq, bins, _ = synth.make_band(frames, rate, n, tones, seed=4242)
+    ref = orc.Receiver(rate, n, edge)
+    stream = torch.cuda.Stream()
+    bank.set_stream(stream.cuda_stream)
+    for b in bins:
+        assert bank.attach(0, int(b)) == ref.attach(int(b))
+    out = ref.process(iq)
+    bank.enable_results(True)
+    dev = torch.from_numpy(iq).cuda()
+    torch.cuda.synchronize()
+    text = ["" for _ in range(tones)]
+    bank.graph_capture(per)
+    batch = 0
+    for rep in range(reps1):
+        bank.graph_launch([dev[(batch + k) * per].data_ptr() for k in range(K)])
+        batch += K
+    assert bank.results_pending == reps1 * K
+    bank.graph_release()
+    for i in range(reps1 * K):  # oldest first, nothing lost, nothing out of order
+        res = bank.poll(wait=True)
+        assert res["batch_index"] == i
+        _check_delivery(res, out, i * per, (i + 1) * per, tones, text)
+    for k in range(K):  # the eager ring takes over (a capture needs a multiple of K batches behind it)
+        bank.process_device(dev[batch * per].data_ptr(), per)
+        res = bank.poll(wait=True)
+        assert res["batch_index"] == batch
+        _check_delivery(res, out, batch * per, (batch + 1) * per, tones, text)
+        batch += 1
+    bank.graph_capture(per)
+    for rep in range(reps2):
+        bank.graph_launch([dev[(batch + k) * per].data_ptr() for k in range(K)])
+        for k in range(K):
+            res = bank.poll(wait=True)
+            assert res["batch_index"] == batch + k
+            _check_delivery(res, out, (batch + k) * per, (batch + k + 1) * per, tones, text)
+        batch += K
+    bank.sync()
+    assert bank.total_frames == frames
+    for lid in range(tones):
+        assert text[lid] == ref.text(lid) and len(text[lid]) > 0
+    bank.close()
+
+
 def test_poll_from_a_consumer_thread(capi):
     """sdr_poll on a thread of its own while the producer thread keeps processing (the reference's Reporter and
     TextProcessor run on goroutines of their own): every batch arrives exactly once, in order, nothing is dropped,

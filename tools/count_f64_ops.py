@@ -5,7 +5,10 @@ executes per IQ sample, for every block size, and writes profiles/f64_ops.json (
 workgroup instantiation IS the dynamic count per thread; a thread handles R samples.
 
 whole_path adds what the other kernels do per sample in float64:
-  * dB projection in k_cumulate (gomath.h db_fast_y + certificate): 5 fma + 3 add = 8
+  * dB projection (gomath.h db_fast_y + certificate: 5 fma + 3 add = 8 per evaluation).  Rounds 1-3 evaluated it for
+    every bin of every frame (8 per sample); from round 4 on only for the bins FindPeaks looks at and the cumulation a
+    batch leaves open (k_peaks.hip: about 6 % + 1 % of the bin-frames at config 3's 256 carriers and 8192-frame batches,
+    every one of them for short batches, which take the exact kernel): 0.6 per sample at the benchmarked batch
   * FindNoiseFloor chains (k_noise.hip): one add per psd value inside the ten windows (0.73 of a frame at the
     default edge width) + sub, mul, add per value up to the winning window's end (on average 0.55 of that): ~1.9
 (the rare literal-log fallbacks and the per-frame scalars are not counted).
@@ -21,7 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "sdrainer_amd", "csrc", "k_fft_psd.hip")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-DSDR_BUILD", "-mllvm", "-disable-machine-licm"]
-DB_OPS, NOISE_OPS = 8.0, 1.9
+DB_OPS, NOISE_OPS = 0.6, 1.9
 
 with tempfile.TemporaryDirectory() as tmp:
     subprocess.check_call(["hipcc"] + FLAGS + ["-c", SRC, "-o", os.path.join(tmp, "k.o"), "--save-temps"], cwd=tmp,

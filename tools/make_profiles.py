@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from sdrainer_amd.csrc import build  # noqa: E402
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 key = "c3_f8192"  # bench.py's default batch for config 3
 G = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 P = os.path.join(ROOT, "profiles")
@@ -41,6 +41,11 @@ if measured_hash != build.source_hash():
 rows = list(csv.reader(open(find("trace/**/t_kernel_stats.csv"))))
 out = [rows[0]] + [r for r in rows[1:] if "sdr::" in r[0]]
 csv.writer(open(os.path.join(P, f"{tag}_kernel_stats_{key}.csv"), "w")).writerows(out)
+try:
+    rows5 = list(csv.reader(open(find("trace_c5/**/t_kernel_stats.csv"))))
+    csv.writer(open(os.path.join(P, f"{tag}_kernel_stats_c5_f2048.csv"), "w")).writerows([rows5[0]] + [r for r in rows5[1:] if "sdr::" in r[0]])
+except AssertionError:
+    print("missing: config-5 kernel trace")
 
 
 def pmc(directory, name):
@@ -85,7 +90,8 @@ copies = [("bench_full.json", f"{tag}_bench_{key}.json"), ("bench_serial.err", f
           ("fft_standalone.txt", f"{tag}_fft_standalone.txt"), ("fft_standalone_f8192.txt", f"{tag}_fft_standalone_f8192.txt"), ("fft_ablation_summary.txt", f"{tag}_fft_ablation_matrix.txt"),
           ("fft_phases.txt", f"{tag}_fft_phase_order.txt"), ("tool_manifest.txt", f"{tag}_tool_manifest.txt"),
           ("host_input_rate.txt", f"{tag}_host_input_rate.txt"), ("strain_e2e.json", f"{tag}_strain_e2e.json"),
-          ("mfma_f64.txt", f"{tag}_mfma_f64_probe.txt")]
+          ("mfma_f64.txt", f"{tag}_mfma_f64_probe.txt"), ("cu_time.txt", f"{tag}_cu_time_per_kernel.txt"),
+          ("noise_trace.txt", f"{tag}_noise_consumer_trace.txt")]
 for src, dst in copies:
     s = os.path.join(G, src)
     if os.path.exists(s) and os.path.getsize(s) > 0:

@@ -8,9 +8,10 @@
 # rocprofv3: the program itself after `--`, PMC passes separate from the kernel trace, a timeout on every call.
 cd /tmp && export TMPDIR=/tmp
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-R=${1:-r03}
+R=${1:-r04}
+PART=${2:-all}   # fft | pipeline | all (two gpurun calls fit the box limit more comfortably than one)
 O=gpurun_out/prof_$R
-rm -rf $O && mkdir -p $O
+[ "$PART" = pipeline ] || rm -rf $O; mkdir -p $O
 HASH=$(python3 -c "from sdrainer_amd.csrc import build; print(build.source_hash())")
 [ "$(cat sdrainer_amd/csrc/libsdrainer_hip.so.srchash 2>/dev/null)" = "$HASH" ] || { echo "libsdrainer_hip.so was not built from these sources"; exit 1; }
 need() {  # binary names: each must be in the manifest with the current hash
@@ -23,6 +24,7 @@ cp tools/bin/MANIFEST $O/tool_manifest.txt
 echo "sources sha256 $HASH" > $O/README.txt
 set -e
 
+if [ "$PART" != pipeline ]; then
 # 1. the dominant kernel alone: production binary, per-workgroup spans, ablation matrix, phase order
 # (2048 frames per launch: the size every earlier round's standalone numbers were taken at; then the bench's batch)
 FPWS="1" tools/fft_matrix.sh $O/fft_standalone.txt fb_prod fb_clock > /dev/null
@@ -34,9 +36,15 @@ echo "fft standalone done"
 # 2. SQ / TCP counters of the standalone production launch (one pass per group)
 BIN=fb_prod OUT=$O/fft_sq_counters.txt tools/pmc_fft.sh > /dev/null 2>&1 || true
 
+fi
+[ "$PART" = fft ] && { echo "fft part done"; exit 0; }
+
 # 3. the whole pipeline: kernel trace, HBM traffic (separate PMC passes), bench lines
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/rocprof_bench.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace_c5 -o t --output-format csv -- python3 bench.py --workload c5 --steps 150 --warmup 15 --no-cpu-baseline > $O/rocprof_bench_c5.log 2>&1
 echo "kernel trace done"
+# CU time per kernel (SQ_BUSY_CU_CYCLES, stages one after the other): what each stage holds against the FFT's whole CUs
+bash tools/pmc_cutime.sh > $O/cu_time.txt 2>&1 || true
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o fetch --output-format csv -- python3 bench.py --steps 3 --warmup 1 --settle-ms 0 --no-cpu-baseline --serial > $O/pmc_fetch.log 2>&1
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE -d $O/write -o write --output-format csv -- python3 bench.py --steps 3 --warmup 1 --settle-ms 0 --no-cpu-baseline --serial > $O/pmc_write.log 2>&1
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE -d $O/fetch_c5 -o fetch --output-format csv -- python3 bench.py --workload c5 --steps 3 --warmup 1 --settle-ms 0 --no-cpu-baseline --serial > $O/pmc_fetch_c5.log 2>&1
@@ -62,6 +70,7 @@ done
 python tools/host_input_rate.py > $O/host_input_rate.txt 2>&1 || true
 timeout -k 10 300 python tools/strain_e2e.py > $O/strain_e2e.json 2>/dev/null || true
 timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1 || true
+[ -f tools/abl/libntrace.so ] && { SDR_HIP_LIB=$PWD/tools/abl/libntrace.so timeout -k 10 120 python tools/noise_trace.py > $O/noise_trace.txt 2>&1; SDR_VAR_MFMA=0 SDR_HIP_LIB=$PWD/tools/abl/libntrace.so timeout -k 10 120 python tools/noise_trace.py >> $O/noise_trace.txt 2>&1; } || true
 [ -x tools/bin/ubench_mfma_f64 ] && timeout -k 5 120 tools/bin/ubench_mfma_f64 > $O/mfma_f64.txt 2>&1 || true
 echo "all done"
 tail -c 600 $O/bench_full.json
