@@ -137,7 +137,10 @@ int sdr_destroy(sdr_bank *bank);
  * rounding per step) adds its four terms one after the other, each step rounded, in order - 1024 wide-range quadruples
  * against the same chains on the vector ALU, bit for bit.  sdr_create runs it once per device and process and refuses to
  * create a bank (SDR_ERR_HIP, message in sdr_last_error) on a part where it fails: there is no second code path whose
- * results would merely be close.  0 = as assumed. */
+ * results would merely be close.  0 = as assumed.  A host has no need to call it; one that does should do so AFTER its
+ * first sdr_create: the probe launches a kernel, and HIP deals its four hardware queues to streams as they come - work
+ * issued before a bank's streams exist can leave two of them sharing a queue (measured: graph mode at two thirds of
+ * its rate). */
 int sdr_self_check(int device_id);
 /* Run on this hipStream_t (NULL = the null stream).  Must be called before the first process call
  * or while the bank is idle. */

@@ -176,11 +176,6 @@ int sdr_create(const sdr_config *cfg, sdr_bank **out)
     if (cfg->device_id < 0 || cfg->device_id >= ndev)
         return fail(SDR_ERR_BAD_ARG, "device_id out of range");
     HIP_TRY(hipSetDevice(cfg->device_id));
-    {
-        const int sc = self_check_once(cfg->device_id);  // the matrix pipe adds the way the variance chains need it to
-        if (sc != SDR_OK)
-            return sc;
-    }
 
     sdr_bank *b = new sdr_bank();
     b->cfg = *cfg;
@@ -211,6 +206,17 @@ int sdr_create(const sdr_config *cfg, sdr_bank **out)
             return fail(SDR_ERR_HIP, "hipStreamCreate failed");
         }
         b->own_stream[s] = true;
+    }
+    // The matrix pipe adds the way the variance chains need it to (sdr_self_check), checked BEHIND the creation of the
+    // bank's streams: HIP deals hardware queues to streams as they come, and a kernel launched before the bank's streams
+    // exist took the queue one of them was to get - two of the bank's streams then shared a queue and graph mode, whose
+    // replays overlap stream against stream, ran at 101 instead of 156 GS/s (config 3; round 4, found by bisection).
+    {
+        const int sc = self_check_once(cfg->device_id);
+        if (sc != SDR_OK) {
+            sdr_destroy(b);
+            return sc;
+        }
     }
     // twiddles: go-dsp's table, re-laid-out per register pass
     {
