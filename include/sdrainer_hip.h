@@ -195,7 +195,9 @@ int sdr_last_batch_chunks(sdr_bank *bank);
 /* Peaks of completed cumulation `chunk` (0-based within the last batch).  *frame_in_batch = index
  * of the frame that completed it. */
 int sdr_read_peaks(sdr_bank *bank, int band, int chunk, sdr_peak *out, int max, int *n_out, int *frame_in_batch);
-/* Cumulated spectrum (sum over 100 frames, float32[block_size]) of that chunk. */
+/* Cumulated spectrum (sum over 100 frames, float32[block_size]) of that chunk (rx/receiver.go:404-407), every bin the
+ * reference's ordered float32 sum.  The pipeline itself keeps a cumulation exact only where FindPeaks reads it; this call
+ * recomputes the whole row from the batch's retained spectra and the carry it started from. */
 int sdr_read_cumulation(sdr_bank *bank, int band, int chunk, float *out);
 /* Decoded text of a listener since the last read, UTF-8 (what the reference writes to io.Writer). */
 int sdr_read_text(sdr_bank *bank, int band, int listener_id, char *out, int max_bytes, int *n_bytes);
@@ -293,6 +295,9 @@ int sdr_graph_batches(sdr_bank *bank);
 int sdr_graph_capture(sdr_bank *bank, int n_frames);
 /* iq_dev: sdr_graph_batches() device pointers, one batch each, layout and alignment as sdr_process_device. */
 int sdr_graph_launch(sdr_bank *bank, const float *const *iq_dev);
+/* Back to sdr_process_*: drains the pipeline, moves what was not polled yet to the host-side queue (sdr_poll keeps
+ * delivering it, oldest first) and frees the replays' buffer sets; what the last replay's last batch left on the device
+ * goes with them - read it (sdr_read_*) before the release. */
 int sdr_graph_release(sdr_bank *bank);
 
 /* scope tap ---------------------------------------------------------------------------------- */

@@ -96,6 +96,13 @@ static int graph_release(sdr_bank *b, bool keep_sets)
             rs.ev_listen = rs.ev_peaks = nullptr;
         }
         b->set.resize(RING);
+        if (b->last_set >= RING) {
+            // the last batch lived in one of them: what it left on the device is gone with the set (its results were
+            // parked above); the per-batch reads (sdr_read_*) answer "nothing" until the next batch
+            b->last_set = 0;
+            b->last_frames = 0;
+            b->last_chunks = 0;
+        }
     }
     return SDR_OK;
 }

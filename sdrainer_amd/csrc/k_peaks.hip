@@ -277,7 +277,9 @@ __global__ __launch_bounds__(256) void k_spectrum_row(const float *__restrict__ 
 // lanes: entry k of the list goes to thread k (neighbouring bins of a run sit in neighbouring lanes).  Four workgroups
 // per row rather than the row's peak scan doing it itself: a cumulation's refinement is a latency chain (a hundred
 // scattered 64-byte sectors per candidate cluster) and at 2048 frames per batch the peaks stream had become the longest
-// of the four with it (134 instead of 150 GS/s).
+// of the four with it (134 instead of 150 GS/s).  (Whole rows x 1024 threads for batches with many rows hold less CU
+// time - 6.4 against 10.8 CU-ms per 8192-frame step, stages one after the other - and measured no better in the pipeline:
+// config 3 160.5 against 162.4 GS/s, config 5's share 182.9 against 180.8.  One shape.)
 // A neighbour span may be rewriting the halo bin this workgroup classifies while it reads it: it then sees either the
 // bound or the exact value, and both classify every bin that is above as above - the list can only differ in bins that
 // need not have been refined.
