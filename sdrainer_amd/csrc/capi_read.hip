@@ -100,6 +100,14 @@ int sdr_read_cumulation(sdr_bank *b, int band, int chunk, float *out)
     rc = sync_bank(b);
     if (rc)
         return rc;
+    // (tests only, SDR_READ_CUM_RAW=1: the row as the pipeline keeps it - an upper bound outside the bins FindPeaks reads -
+    // so that a test can check bound >= exact in every bin of every cumulation: tests/test_gpu_parity_bench_sizes.py)
+    if (const char *raw = getenv("SDR_READ_CUM_RAW"))
+        if (raw[0] == '1') {
+            HIP_TRY(hipMemcpy(out, b->set[b->last_set].cum_out.p + ((size_t)band * b->max_chunks + chunk) * b->cfg.block_size,
+                              sizeof(float) * (size_t)b->cfg.block_size, hipMemcpyDeviceToHost));
+            return SDR_OK;
+        }
     return exact_cumulation_row(b, band, chunk, out);
 }
 

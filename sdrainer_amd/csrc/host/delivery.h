@@ -217,8 +217,9 @@ public:
         // oldest first: parked batches are older than anything still in a set
         if (!parked_.empty() && parked_.front().meta.batch == deliver_next_)
             return poll_parked(out);
-        ResultSet &S = sets_[(size_t)set_index(deliver_next_)];
-        if (S.meta.batch != deliver_next_)
+        const int64_t want = deliver_next_;  // the batch this call is about, whatever happens while it waits unlocked
+        ResultSet &S = sets_[(size_t)set_index(want)];
+        if (S.meta.batch != want)
             return be_->report(SDR_ERR_STATE, "results of the next batch are not where they should be");
         for (void *e : {S.ev_listen, S.ev_peaks}) {
             if (wait) {
@@ -229,7 +230,9 @@ public:
                 guard.lock();
                 if (rc != SDR_OK)
                     return rc;
-                if (S.meta.batch != deliver_next_)  // the producer parked it (or another consumer took it) in the meantime
+                // the producer parked it, or another consumer took it, in the meantime - and the set may even hold a LATER
+                // batch by now (whose first event this call has not waited for): only batch `want`, still next, goes on
+                if (S.meta.batch != want || deliver_next_ != want)
                     return (!parked_.empty() && parked_.front().meta.batch == deliver_next_) ? poll_parked(out)
                            : deliver_next_ >= batches_enqueued_ ? be_->report(SDR_ERR_WOULD_BLOCK, "no batch waiting")
                                                                 : be_->report(SDR_ERR_WOULD_BLOCK, "the batch went to another consumer; poll again");

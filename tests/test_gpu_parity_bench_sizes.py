@@ -13,6 +13,8 @@ own (ctypes releases the GIL).
 """
 from concurrent.futures import ThreadPoolExecutor
 
+import os
+
 import numpy as np
 import pytest
 
@@ -139,7 +141,20 @@ def _eager_case(capi, rate, n, tones, n_bands, frames, n_batches, free_last, see
             for c in range(bank.last_batch_chunks):
                 _, _, fr = bank.read_peaks(b, c)
                 gc = list(outs[b]["peak_frames"]).index(a + fr)
-                assert _bits_equal(bank.read_cumulation(b, c), outs[b]["cumulation"][gc]), f"band {b} cumulation {gc}"
+                exact = outs[b]["cumulation"][gc]
+                assert _bits_equal(bank.read_cumulation(b, c), exact), f"band {b} cumulation {gc}"
+                # the row as the pipeline keeps it (k_peaks.hip: exact where FindPeaks reads it, an upper bound elsewhere):
+                # never below the exact cumulation in any bin, equal to it in every bin of every peak and beside its maximum
+                os.environ["SDR_READ_CUM_RAW"] = "1"
+                try:
+                    raw = bank.read_cumulation(b, c)
+                finally:
+                    del os.environ["SDR_READ_CUM_RAW"]
+                assert np.all(raw >= exact), f"band {b} cumulation {gc}: the kept row is below the exact one somewhere"
+                pk, _, _ = bank.read_peaks(b, c)
+                for p in pk:
+                    lo, hi = max(p[0], p[6] - 1), min(p[1], p[6] + 1)
+                    assert _bits_equal(raw[p[0]:p[1] + 1], exact[p[0]:p[1] + 1]) and _bits_equal(raw[lo:hi + 1], exact[lo:hi + 1])
     for b in range(n_bands):
         for lid in range(tones):
             assert text[b][lid] == refs[b].text(lid), f"band {b} listener {lid} text"
