@@ -170,6 +170,7 @@ struct sdr_bank {
     DevBuf<uint16_t> morse;
     DevBuf<uint32_t> text;         // [band][L][text_cap] decoded runes not yet read / delivered
     DevBuf<uint32_t> text_frames;  // [band][L][text_cap] bank frame index of the Tick that wrote each rune
+    DevBuf<uint32_t> edge_pos;     // [band][L][max_batch_frames] k_listen_decode's scratch: every edge's position in the batch (one decoder launch runs at a time: each needs the state the one before left)
     DevBuf<float> carry[2];  // [band][N] cumulation carried between batches (double buffered)
 
     std::vector<sdr::BandState> h_band_state;

@@ -266,6 +266,7 @@ int sdr_create(const sdr_config *cfg, sdr_bank **out)
     ALLOC(b->morse, cw::kMorseTableSize);
     ALLOC(b->text, B * L * (size_t)b->text_cap);
     ALLOC(b->text_frames, B * L * (size_t)b->text_cap);
+    ALLOC(b->edge_pos, B * L * (size_t)cfg->max_batch_frames);
     ALLOC(b->carry[0], B * N);
     ALLOC(b->carry[1], B * N);
 #undef ALLOC
@@ -327,6 +328,7 @@ int sdr_destroy(sdr_bank *b)
     b->morse.release();
     b->text.release();
     b->text_frames.release();
+    b->edge_pos.release();
     b->carry[0].release();
     b->carry[1].release();
     for (int s = 0; s < N_STAGES; s++)

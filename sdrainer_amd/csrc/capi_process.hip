@@ -210,11 +210,9 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     // set is free, the FFT queue holds kernels only): 0.161 ms with nothing else running, but 0.237 against 0.234
     // with the whole pipeline, where the FFT launches are spaced by the CUs the tail holds, not by their queue.
     static const bool host_waits = getenv("SDR_HOST_THROTTLE") && atoi(getenv("SDR_HOST_THROTTLE")) != 0;
-    int max_slots = 0, slots_in_use = 0;
-    for (int i = 0; i < B; i++) {
+    int max_slots = 0;
+    for (int i = 0; i < B; i++)
         max_slots = std::max(max_slots, b->n_slots[i]);
-        slots_in_use += b->n_slots[i];
-    }
     if (do_spectra) {
     // With bulk delivery on, the set's previous batch must have been delivered (or be parked) before its block is
     // written again - and a delivered batch is a finished one: every reader of the set is done, the queries below
@@ -325,7 +323,7 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         ProfScope ps(b, sdr::K_LISTEN_DECODE, stream_of(sdr::K_LISTEN_DECODE));
         SDR_LAUNCH(sdr::K_LISTEN_DECODE, sdr::launch_listen_decode(b->slots.p, b->morse.p, S.raw_bits.p, S.bits.p, b->text.p,
                                                                    b->text_frames.p, S.edges.p, S.edge_counts.p, S.tr_deb.p, b->drops.p, cur,
-                                                                   lg, n_frames, B, slots_in_use, stream_of(sdr::K_LISTEN_DECODE)));
+                                                                   lg, n_frames, B, b->edge_pos.p, c.max_batch_frames, stream_of(sdr::K_LISTEN_DECODE)));
     }
     if (b->results_on && SDR_ON(sdr::K_LISTEN_DECODE)) {
         // delivery of this batch's edges and runes, behind the decoder on its stream; the decoder's event is

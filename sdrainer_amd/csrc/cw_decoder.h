@@ -55,43 +55,6 @@ SDR_HD inline bool debounce(Debouncer &d, bool raw)
     return d.effectiveState != 0;
 }
 
-// `cnt` (1..64) consecutive Debounce calls at once, raw states in the low bits of `raw` (bit j = call j), results in
-// the same positions.  Debounce only counts the length of the current run of equal raw states, so a whole run is
-// handled in closed form: the run's value v becomes the effective state at the call where the count reaches the
-// threshold - call k = max(0, threshold - c0 - 1) of the run, c0 = the count carried into it - and stays it.
-SDR_HD inline uint64_t debounce_word(Debouncer &d, uint64_t raw, int cnt)
-{
-    const uint64_t valid = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
-    if (d.threshold < 2)
-        return raw & valid;  // dsp/dsp.go:165-167: a pass-through that keeps no state
-    uint64_t out = 0;
-    int pos = 0;
-    while (pos < cnt) {
-        const int32_t v = (int32_t)((raw >> pos) & 1ull);
-        const uint64_t diff = ((v ? ~raw : raw) & valid) >> pos;  // 1 where a later call's state differs from v
-#if defined(__HIP_DEVICE_COMPILE__)
-        const int run = diff ? (__ffsll((long long)diff) - 1) : (cnt - pos);
-#else
-        const int run = diff ? __builtin_ctzll(diff) : (cnt - pos);
-#endif
-        const int32_t c0 = v == d.lastRawState ? d.stateCount : 0;
-        int k = d.threshold - c0 - 1;
-        k = k < 0 ? 0 : (k > run ? run : k);  // calls of this run that still return the old effective state
-        // (k, run - k <= 64 - pos, and a 64-bit span only occurs at pos 0)
-        if (d.effectiveState && k > 0)
-            out |= (k >= 64 ? ~0ull : ((1ull << k) - 1ull)) << pos;
-        if (k < run) {
-            if (v)
-                out |= ((run - k) >= 64 ? ~0ull : ((1ull << (run - k)) - 1ull)) << (pos + k);
-            d.effectiveState = v;
-        }
-        d.lastRawState = v;
-        d.stateCount = c0 + run;
-        pos += run;
-    }
-    return out;
-}
-
 // cw/decode.go:360-369
 struct AdaptiveThreshold {
     double preset, upperBound, low, high, last, threshold;
@@ -162,11 +125,12 @@ SDR_HD inline double wpm_to_dit(const DecoderState &d, double wpm)  // :191-195
     const double ditSeconds = 60.0 / (50.0 * wpm);
     return ::ceil(ditSeconds / d.tickSeconds);
 }
-SDR_HD inline double dit_to_wpm(const DecoderState &d, double ditTicks)  // :197-200
+SDR_HD inline double dit_to_wpm(double tickSeconds, double ditTicks)  // :197-200
 {
-    const double ditSeconds = ditTicks * d.tickSeconds;
+    const double ditSeconds = ditTicks * tickSeconds;
     return 60.0 / (50.0 * ditSeconds);
 }
+SDR_HD inline double dit_to_wpm(const DecoderState &d, double ditTicks) { return dit_to_wpm(d.tickSeconds, ditTicks); }
 
 SDR_HD inline void decoder_init(DecoderState &d, int sampleRate, int blockSize)  // NewDecoder :131-147
 {
@@ -295,84 +259,11 @@ SDR_HD inline void decoder_tick(DecoderState &d, bool state, const uint16_t *tab
     }
 }
 
-// Tick(state) for a tick that IS an edge (state != lastState) — the same arithmetic as decoder_tick,
-// arranged for a SIMD lane: rising and falling edges share one AdaptiveThreshold.Put (selected copy in,
-// selected copy out) instead of two divergent code paths.  The end-of-tick check (:244-249) is skipped
-// because currentDuration is 0 on an edge tick and upperBound is never negative.
-template <class Sink>
-SDR_HD inline void decoder_edge(DecoderState &d, bool state, const uint16_t *table, Sink &out)
-{
-    d.ticks += 1;
-    const double now = d.ticks;
-    const double duration = state ? now - d.offStart : now - d.onStart;  // offDuration / onDuration
-    if (state)
-        d.onStart = now;
-    else
-        d.offStart = now;
-    if (duration >= kMinDitTime) {  // :254, :279
-        AdaptiveThreshold t = state ? d.offThreshold : d.onThreshold;
-        at_put(t, duration);
-        if (state)
-            d.offThreshold = t;
-        else
-            d.onThreshold = t;
-        const double threshold = t.threshold;
-        if (state) {  // onRisingEdge :260-274
-            if (duration >= 4.5 * t.low) {
-                decode_current_char(d, table, out);
-                out.put(' ');
-            } else if (duration >= threshold) {
-                decode_current_char(d, table, out);
-            }
-        } else {  // onFallingEdge :285-297
-            if (duration >= 2 * t.high) {
-                d.currentCharInvalid = 1;
-            } else {
-                const bool da = duration >= threshold;
-                append_symbol(d, da, table, out);
-                if (da)
-                    d.wpm = (d.wpm + dit_to_wpm(d, t.low)) / 2.0;
-            }
-        }
-    }
-    d.decoding = 1;
-    d.lastState = state;
-}
-
-// `k` consecutive Tick(state) calls with state == lastState, in closed form.  (The sink is told which tick of
-// the run writes - `at_run_tick` - so that a rune can be stamped with its frame.)  Between edges Tick only
-// counts (`ticks++`) and checks `decoding && currentDuration > upperBound` (:244-249); neither
-// threshold changes, currentDuration = now - start is an exact integer, so the check first fires at
-// the tick where now == floor(upperBound) + 1 + start (if that tick is within the run) and never again
-// (it clears `decoding`).  Results are identical to k literal Tick calls.
-template <class Sink>
-SDR_HD inline void decoder_advance(DecoderState &d, int k, const uint16_t *table, Sink &out)
-{
-    if (k <= 0)
-        return;
-    const double end = d.ticks + (double)k;
-    if (d.decoding) {
-        const double start = d.lastState ? d.onStart : d.offStart;
-        const double upperBound = d.offThreshold.threshold * (double)d.abortDecodeAfterDits;
-        // the check fires within the run iff the run's last tick has end - start > upperBound (both sides of the
-        // subtraction are exact integers; it cannot have fired before the run while decoding is still set)
-        if (end - start > upperBound) {
-            const double first_now = ::floor(upperBound) + 1.0 + start;  // smallest integer now with now-start > upperBound
-            d.decoding = 0;
-            out.at_run_tick((int)(first_now - d.ticks) - 1);  // which of the run's k ticks writes (0-based)
-            decode_current_char(d, table, out);
-        }
-    }
-    d.ticks = end;
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// The decoder as k_listen_decode runs it.  Same arithmetic as decoder_advance / decoder_edge above, arranged so that
-// a loop iteration (a run of equal states, then the edge that ends it) has ONE place where a rune is looked up and
-// written.  decodeCurrentChar (cw/decode.go:315-350) is reached from four places in a tick (the abort check, a
-// character gap, a word gap, a ninth symbol).  At most one of them can produce a rune in one iteration - each of them
-// empties the current character - so here they only TAKE the character (a table key, 0 = nothing) and the caller
-// emits it, then the word gap's space.  (tests/emu/emu_decoder.cpp: identical to Decoder.Tick tick by tick.)
+// Pieces of the decoder as k_listen_decode runs it (cw_stages.h has the rest).  decodeCurrentChar (cw/decode.go:315-350)
+// is reached from four places in a tick (the abort check, a character gap, a word gap, a ninth symbol); each of them
+// empties the current character, so the stages only TAKE the character (a table key, 0 = nothing) and the caller looks
+// it up and writes the rune.  (tests/emu/emu_stages.cpp: identical to Decoder.Tick tick by tick.)
 constexpr uint32_t kInvalidChar = 0xFFFFFFFFu;  // a character with an over-long Da in it: decodes to kUnknownCharacter
 
 // the state changes of decodeCurrentChar, without the output: returns the table key of the character taken
@@ -393,7 +284,10 @@ struct Emission {
     bool space;      // a word gap: ' ' after the character, stamped with the edge's frame
 };
 
-// decoder_advance: k ticks without an edge, the first of them frame `run_base`
+// `k` consecutive Tick(state) calls with state == lastState, the first of them frame `run_base`, in closed form.  Between
+// edges Tick only counts (`ticks++`) and checks `decoding && currentDuration > upperBound` (:244-249); neither threshold
+// changes, currentDuration = now - start is an exact integer, so the check first fires at the tick where
+// now == floor(upperBound) + 1 + start (if that tick is within the run) and never again (it clears `decoding`).
 SDR_HD inline void decoder_run(DecoderState &d, int k, uint32_t run_base, Emission &em)
 {
     const double end = d.ticks + (double)k;
@@ -409,86 +303,6 @@ SDR_HD inline void decoder_run(DecoderState &d, int k, uint32_t run_base, Emissi
         }
     }
     d.ticks = end;
-}
-
-// AdaptiveThreshold.Put (cw/decode.go:392-411) as straight-line code: both candidate updates are formed, the one the
-// reference's branches would take is selected (a select returns one of its operands unchanged, so every value is the
-// one the branching code computes), and `gate` false leaves the threshold untouched (the edge was shorter than
-// minDitTime: Put is not called).  One lane per signal walks its edges; with several signals per wave every branch any
-// lane takes is paid by all of them, and with one signal per wave a taken branch still costs its exec-mask bookkeeping on
-// the serial path: the round-3 ablations put two thirds of an edge's ~1100 clocks in this structure, not in the
-// square root or the division.
-SDR_HD inline void at_put_select(AdaptiveThreshold &t, double duration, bool gate)
-{
-    const double highFactor = 2;
-    const double avgWeight = 0.75;
-    const double currentWeight = 1.0 - avgWeight;
-    const bool use = gate && !(duration >= t.low * t.upperBound);
-    const bool down = t.last >= duration * highFactor;                // this one shorter: it is the new low sample
-    const bool up = !down && duration >= t.last * highFactor;         // this one longer: the new high sample
-    const bool moved = use && (down || up);
-    const double lo_sample = down ? duration : t.last, hi_sample = down ? t.last : duration;
-    const double low = avgWeight * t.low + currentWeight * lo_sample;
-    const double high = avgWeight * t.high + currentWeight * hi_sample;
-    t.low = moved ? low : t.low;
-    t.high = moved ? high : t.high;
-    t.last = use ? duration : t.last;
-    // updateThreshold() recomputes sqrt(low*high) on every Put; when neither moved, the stored value IS that square root
-    const double thr = ::sqrt(t.low * t.high);
-    t.threshold = moved ? thr : t.threshold;
-}
-
-// decoder_edge: the tick (frame `frame`) at which the debounced state changes to `state`
-SDR_HD inline void decoder_edge_deferred(DecoderState &d, bool state, uint32_t frame, Emission &em)
-{
-    d.ticks += 1;
-    const double now = d.ticks;
-    const double duration = now - (state ? d.offStart : d.onStart);
-    d.onStart = state ? now : d.onStart;
-    d.offStart = state ? d.offStart : now;
-    const bool gate = duration >= kMinDitTime;  // :254, :279: shorter runs are ignored
-    // a rising edge feeds the gap threshold, a falling edge the mark threshold: the four fields that change are picked
-    // from the one, updated once, and put back into the one they came from (preset and upperBound never change here)
-    AdaptiveThreshold t;
-    t.preset = 0;
-    t.upperBound = state ? d.offThreshold.upperBound : d.onThreshold.upperBound;
-    t.low = state ? d.offThreshold.low : d.onThreshold.low;
-    t.high = state ? d.offThreshold.high : d.onThreshold.high;
-    t.last = state ? d.offThreshold.last : d.onThreshold.last;
-    t.threshold = state ? d.offThreshold.threshold : d.onThreshold.threshold;
-    at_put_select(t, duration, gate);
-    d.offThreshold.low = state ? t.low : d.offThreshold.low;
-    d.offThreshold.high = state ? t.high : d.offThreshold.high;
-    d.offThreshold.last = state ? t.last : d.offThreshold.last;
-    d.offThreshold.threshold = state ? t.threshold : d.offThreshold.threshold;
-    d.onThreshold.low = state ? d.onThreshold.low : t.low;
-    d.onThreshold.high = state ? d.onThreshold.high : t.high;
-    d.onThreshold.last = state ? d.onThreshold.last : t.last;
-    d.onThreshold.threshold = state ? d.onThreshold.threshold : t.threshold;
-    uint32_t key = 0;
-    if (state) {  // onRisingEdge :260-274
-        const bool word_gap = duration >= 4.5 * d.offThreshold.low;
-        if (gate && (word_gap || duration >= d.offThreshold.threshold))
-            key = take_char(d);
-        em.space = gate && word_gap;
-    } else {  // onFallingEdge :285-297
-        const bool invalid = gate && duration >= 2 * d.onThreshold.high;
-        const bool symbol = gate && !invalid;
-        const bool da = duration >= d.onThreshold.threshold;
-        d.currentCharInvalid = invalid ? 1 : d.currentCharInvalid;
-        if (symbol && d.charLen == kMaxSymbolCount)  // (rare)
-            key = take_char(d);
-        d.charBits = symbol ? ((d.charBits << 1) | (da ? 1u : 0u)) : d.charBits;
-        d.charLen += symbol ? 1 : 0;
-        const double wpm = (d.wpm + dit_to_wpm(d, d.onThreshold.low)) / 2.0;
-        d.wpm = (symbol && da) ? wpm : d.wpm;
-    }
-    if (key) {  // (if the abort check of this iteration's run took the character, there is none left here)
-        em.key = key;
-        em.frame = frame;
-    }
-    d.decoding = 1;
-    d.lastState = state;
 }
 
 template <class Sink>

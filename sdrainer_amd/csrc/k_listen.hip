@@ -6,15 +6,14 @@
 //   k_listen_gather  data-parallel over (signal, frame): one lane takes 64 consecutive frames of one
 //                    signal, reads the psd values the FFT kernel tapped for it, projects them to dB,
 //                    compares against each frame's threshold and packs the 64 results into one word.
-//   k_listen_decode  one LANE per signal (4 signals per wave): the debouncer and the decoder are
-//                    inherently serial per signal, but between keying edges Decoder.Tick only counts, so
-//                    the lane walks RUNS of equal bits (ffs on the XOR-ed word) and handles each run in
-//                    closed form (cw::decoder_advance) — a few hundred edges per batch instead of
-//                    thousands of ticks.
+//   k_listen_decode  the debouncer and the decoder, taken apart by what is serial in them (cw_stages.h): bit
+//                    operations per 64-tick word, a short float64 chain per keying edge, everything else per
+//                    edge in parallel, the character bookkeeping per edge - 64 listeners to a workgroup.
 #include <hip/hip_runtime.h>
 
 #include "../../include/sdrainer_hip.h"
 #include "cw_decoder.h"
+#include "cw_stages.h"
 #include "gomath.h"
 #include "sdr_device.h"
 
@@ -26,19 +25,10 @@ namespace sdr {
 // certificate fails - and collects its own 64 comparison results into one word.  Sixteen waves to a workgroup: round
 // 2's one-wave workgroups with the literal logarithm (0.031 ms) went to 128 different CUs and kept an FFT workgroup,
 // which needs a whole CU, off each of them for that long; these are 8 workgroups for a few microseconds.
-// Waves per workgroup.  Four decoder waves (one per SIMD) share a workgroup: with every lane of a wave working
-// (k_listen_decode) they run as fast together as alone - 0.134 against 0.130 ms - and 16 workgroups keep 16 CUs from
-// the FFT instead of 64: 0.221 against 0.234 ms per pipelined step (eight waves: 0.159 ms / 0.247, sixteen: 0.240 /
-// 0.32; before the lanes were filled, four waves of four active lanes took 0.234 ms against 0.137 alone).  The gather
-// waves stay one to a workgroup (two, four, eight: no difference beyond the noise).
 #ifndef SDR_GATHER_WAVES
 #define SDR_GATHER_WAVES 16
 #endif
-#ifndef SDR_DECODE_WAVES
-#define SDR_DECODE_WAVES 4
-#endif
 constexpr int GATHER_WAVES = SDR_GATHER_WAVES;  // 64-frame words per workgroup, one per wave
-constexpr int DECODE_WAVES = SDR_DECODE_WAVES;  // signal groups per workgroup, one per wave
 
 // the literal Go algorithm, out of line: it is rare (about three values in 10^5 fail the shortcut's certificate)
 __device__ __attribute__((noinline)) float gather_db_slow(float psd, double inv_n2) { return gomath::psd_value_in_db(psd, inv_n2); }
@@ -108,17 +98,43 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) void k_listen_gather(const float
     raw_bits[lidx * g.bit_words + word] = mask;
 }
 
-// Signals per decoder wave.  The lanes of a wave walk their signals' edges in lockstep and take every branch any of
-// them takes, so fewer signals per wave means a shorter wave - and the decoder is the long pole of the listen stream.
-// Standalone / per pipelined step, four waves per workgroup: 1 signal 0.089 ms / 0.2327, 2: 0.115 / 0.2267,
-// 4: 0.134 / 0.2207, 8: 0.151 / 0.2349 (fewer signals per wave = more workgroups holding CUs the FFT wants).
-// The kernel is compiled for 1, 2 and 4 signals per wave and the launch picks the fewest that keep the decoders
-// within 64 waves (16 workgroups): a small pool - config 2's 16 signals - gets a wave per signal (0.39 instead of
-// 0.59 ms per 4096-frame batch), config 3's 256 signals get four per wave.
-#ifndef SDR_DECODE_LANES
-#define SDR_DECODE_LANES 4
+// ---------------------------------------------------------------------------------------------------------------
+// k_listen_decode - debouncer and decoder of every listener, by the stages of cw_stages.h.  A workgroup takes
+// DEC_GROUP consecutive listener slots:
+//   stage 0   a WAVE per listener, a lane per 64-tick word: debounced bits (bit operations per word, three scans over
+//             the words by ballot / shuffle), the edge list - to the batch's edge buffer for the host, and every
+//             edge's position to a scratch row (the host's buffer may be shorter than the list) - and the debouncer's
+//             state behind the batch;
+//   then, DEC_ROUND edges of every listener at a time, as a pipeline of three stages on different waves with one
+//   workgroup barrier per step (step t: A works on round t, B on round t - 1, C on round t - 2, through LDS):
+//   stage A   a LANE per listener (wave 0), edge after edge: the threshold chain;
+//   stage B   a thread per (listener, edge), waves of the SIMDs the serial waves are not on: thresholds (the square
+//             roots), classification, the speed term (the division), the abort ticks of the runs;
+//   stage C   a lane per listener (wave 1), edge after edge: characters, the speed average, the text buffer (table
+//             keys; translated to runes by everybody at the end).
+// The serial stages walk rising and falling edges in alternating steps (a listener whose first edge is a falling one
+// sits out the first step), so no step selects a polarity; they hold no square root, no division, no table lookup
+// and no branch but the predicated store of a rune: about 35 (A) and 45 (C) instructions per edge, issued by one wave -
+// a wave's instruction takes four cycles however many of its lanes work, so that, not the float64 chain's latency, is
+// what an edge costs.  Sixteen workgroups decode config 3's 256 listeners.
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef SDR_DECODE_GROUP
+#define SDR_DECODE_GROUP 16
 #endif
-constexpr int DECODE_LANES_MAX = SDR_DECODE_LANES;
+#ifndef SDR_DECODE_WAVES
+#define SDR_DECODE_WAVES 16
+#endif
+#ifndef SDR_DECODE_ROUND
+#define SDR_DECODE_ROUND 32
+#endif
+#ifndef SDR_DECODE_B_SIMD23
+#define SDR_DECODE_B_SIMD23 1
+#endif
+constexpr int DEC_GROUP = SDR_DECODE_GROUP;  // listeners per workgroup: lanes of the waves that run the serial stages
+constexpr int DEC_WAVES = SDR_DECODE_WAVES;
+constexpr int DEC_ROUND = SDR_DECODE_ROUND;  // edges per listener and round
+constexpr int DEC_POS_ROWS = DEC_ROUND + 3;  // a round's positions: one edge before it, two behind
+static_assert(DEC_GROUP <= 64 && DEC_ROUND % 2 == 0 && DEC_WAVES >= 4, "lanes of a wave; rising / falling steps alternate");
 
 // The io.Writer of a listener's decoder (cw/decode.go:352): runes and, beside each, the bank frame index of the
 // Tick that wrote it (the host stamps TextProcessor.Write with that frame's time: rx/text_processor.go:208-209,
@@ -127,154 +143,389 @@ struct TextSink {
     uint32_t *buf;
     uint32_t *frames;
     uint32_t count, cap, dropped;
-    uint32_t frame;     // frame of the tick being processed
-    uint32_t run_base;  // frame of the first tick of the run decoder_advance is walking
-    bool writer;        // false: a lane that only follows another lane's signal (k_listen_decode) and stores nothing
-    __device__ void at_run_tick(int k) { frame = run_base + (uint32_t)k; }
-    __device__ void put(uint32_t r)
+    __device__ __forceinline__ void put_if(bool valid, uint32_t r, uint32_t frame)
     {
-        if (count < cap) {
-            if (writer) {
-                buf[count] = r;
-                frames[count] = frame;
-            }
-            count++;
-        } else {
-            dropped++;
+        const bool ok = valid && count < cap;
+        if (ok) {
+            buf[count] = r;
+            frames[count] = frame;
         }
+        count += ok ? 1u : 0u;
+        dropped += valid && !ok ? 1u : 0u;
     }
 };
 
-// (the decoder as the kernel runs it - one place per loop iteration that writes runes - is cw_decoder.h's
-// decoder_run / decoder_edge_deferred, checked tick by tick against Decoder.Tick on the CPU: tests/emu/emu_decoder.cpp)
-using cw::Emission;
-using cw::kInvalidChar;
+// what stage 0 leaves for the later stages, per listener of the group
+struct DecodeLocal {
+    double t0;            // Decoder.ticks before the batch
+    double start0;        // the start the first edge's duration is measured from (offStart / onStart as carried)
+    double tick_seconds;  // Decoder.tickSeconds
+    int first, end;       // the listener's ticks in the batch
+    int n_edges;          // -1: no listener in this slot
+    int state0;           // the first edge's new state
+    int abort_dits;       // Decoder.abortDecodeAfterDits
+    uint32_t text_from, text_to;  // stage C -> the translation at the end: the batch's entries in the text buffer
+};
+// an edge's 16 bytes of LDS: stage A's output, replaced by stage B's
+union EdgeSlot {
+    struct {
+        double low, high;
+    } chain;
+    cw::EdgeRec rec;
+};
 
-template <int DECODE_LANES>
-__global__ __launch_bounds__(64 * DECODE_WAVES) void k_listen_decode(ListenerSlot *__restrict__ slots, const uint16_t *morse,
-                                                      const uint64_t *__restrict__ raw_bits,
-                                                      uint64_t *__restrict__ deb_bits, uint32_t *__restrict__ text,
-                                                      uint32_t *__restrict__ text_frames, sdr_edge *__restrict__ edges,
-                                                      uint32_t *__restrict__ edge_counts, uint8_t *__restrict__ tr_deb,
-                                                      DropCounters *__restrict__ drops,
-                                                      const BatchCursor *__restrict__ cur, ListenGeom g, int n_frames,
-                                                      int n_total)
+__device__ __forceinline__ int shfl_i(int v, int src) { return __shfl(v, src, 64); }
+
+__global__ __launch_bounds__(64 * DEC_WAVES) void k_listen_decode(ListenerSlot *__restrict__ slots, const uint16_t *__restrict__ morse,
+                                                                  const uint64_t *__restrict__ raw_bits, uint64_t *__restrict__ deb_bits,
+                                                                  uint32_t *__restrict__ text, uint32_t *__restrict__ text_frames,
+                                                                  sdr_edge *__restrict__ edges, uint32_t *__restrict__ edge_counts,
+                                                                  uint8_t *__restrict__ tr_deb, DropCounters *__restrict__ drops,
+                                                                  const BatchCursor *__restrict__ cur, ListenGeom g, int n_frames, int n_total,
+                                                                  uint32_t *__restrict__ edge_pos, int pos_stride)
 {
     if (cur)
         g.frame_base = cur->frame_base;
-    // the 512-entry code table is hit on every decoded character, on the serial path: keep it in LDS
-    __shared__ uint16_t s_morse[cw::kMorseTableSize];
-    for (int i = threadIdx.x; i < cw::kMorseTableSize; i += blockDim.x)
-        s_morse[i] = morse[i];
+    __shared__ DecodeLocal s_loc[DEC_GROUP];
+    __shared__ uint32_t s_pos[4][DEC_POS_ROWS][DEC_GROUP + 1];  // [round & 3][i][l]: position of listener l's edge k0 - 1 + i (behind the last one: the span's end)
+    __shared__ __attribute__((aligned(16))) EdgeSlot s_edge[3][DEC_ROUND][DEC_GROUP];
+    __shared__ int s_max_edges;
+    if (threadIdx.x == 0)
+        s_max_edges = 0;
     __syncthreads();
-    morse = s_morse;
-    // Every lane of the wave works: lanes DECODE_LANES.. follow the signal of lane (lane mod DECODE_LANES) - same
-    // loads, same arithmetic, same branches, no stores.  A wave with a few active lanes is the slow case of this
-    // hardware, and several such waves on one CU slow each other further (tools/ubench_share.hip, dependent
-    // v_add_f64: 1.68 ms with 4 active lanes against 1.31 ms with 64, one wave per CU; 3.06 against 1.31 ms with four
-    // waves per CU, 4.60 against 1.31 with eight).  Full waves cost the same however many share the CU, so the
-    // decoders can sit DECODE_WAVES to a workgroup and leave the other CUs to the FFT.
-    const int lane = threadIdx.x & 63;
-    const int first = (blockIdx.x * DECODE_WAVES + (int)(threadIdx.x >> 6)) * DECODE_LANES;  // (band, slot) flattened
-    int sub = lane % DECODE_LANES;
-    const bool mine = lane < DECODE_LANES && first + sub < n_total && slots[min(first + sub, n_total - 1)].active;
-    const unsigned long long live = __ballot(mine);  // bit i: signal first+i is decoded by this wave
-    if (!live)
-        return;
-    if (!((live >> sub) & 1ull))
-        sub = __ffsll((long long)live) - 1;  // nothing of its own to follow: follow the wave's first signal
-    const bool writer = mine;
-    const int idx = first + sub;
-    ListenerSlot *slot = &slots[idx];
-    cw::Debouncer deb = slot->deb;
-    cw::DecoderState dec = slot->dec;
-    TextSink sink{text + (size_t)idx * g.text_cap, text_frames + (size_t)idx * g.text_cap, slot->text_count,
-                  (uint32_t)g.text_cap, slot->text_dropped, g.frame_base, g.frame_base, writer};
-    sdr_edge *my_edges = edges + (size_t)idx * g.edge_cap;
-    const uint64_t *rw = raw_bits + (size_t)idx * g.bit_words;
-    uint64_t *dw = deb_bits + (size_t)idx * g.bit_words;
-    uint32_t n_edges = 0;
-    const int band = idx / g.max_listeners, l = idx - band * g.max_listeners;
-    // frames of this batch before the listener's first one (sdr_attach_at; 0 or less for everybody else)
-    const int skip = (int)(slot->start_frame - g.frame_base);
-
-    // The words of raw states are fetched four ahead: a load per word in the loop would put a trip to memory on the
-    // serial path of every 64 frames (32 of them per 2048-frame batch).
+    const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6);
+    const int group0 = blockIdx.x * DEC_GROUP;
     const int n_words = (n_frames + 63) >> 6;
-    uint64_t ahead[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-        ahead[k] = rw[min(k, n_words - 1)];
-    for (int f0 = 0; f0 < n_frames; f0 += 64) {
-        const int cnt = min(64, n_frames - f0);
-        const uint64_t raw = ahead[0];
-        ahead[0] = ahead[1];
-        ahead[1] = ahead[2];
-        ahead[2] = ahead[3];
-        ahead[3] = rw[min((f0 >> 6) + 4, n_words - 1)];
-        int pos = skip > f0 ? min(skip - f0, cnt) : 0;  // ticks of this word that are not the listener's
-        // dsp/dsp.go:164-182, a run of equal raw states at a time
-        const uint64_t d = pos >= cnt ? 0ull : pos ? cw::debounce_word(deb, raw >> pos, cnt - pos) << pos : cw::debounce_word(deb, raw, cnt);
-        if (writer)
-            dw[f0 >> 6] = d;
-        // walk the runs of equal debounced bits
-        while (pos < cnt) {
-            const bool cur = dec.lastState != 0;
-            uint64_t diff = (cur ? ~d : d) >> pos;  // 1 where the bit differs from the decoder's state
-            if (cnt - pos < 64)
-                diff &= (1ull << (cnt - pos)) - 1ull;
-            const int run = diff ? (__ffsll((long long)diff) - 1) : (cnt - pos);
-            Emission em{0u, 0u, false};
-            cw::decoder_run(dec, run, g.frame_base + (uint32_t)(f0 + pos), em);
-            pos += run;
-            uint32_t edge_frame = 0;
-            if (pos < cnt) {  // the edge tick
-                const bool st = !cur;
-                edge_frame = g.frame_base + (uint32_t)(f0 + pos);
-                if (writer && n_edges < (uint32_t)g.edge_cap)
-                    my_edges[n_edges] = sdr_edge{edge_frame, st ? 1u : 0u};
-                n_edges++;
-                cw::decoder_edge_deferred(dec, st, edge_frame, em);
-                pos++;
+#if defined(SDR_DEC_CLOCK)
+    unsigned long long ck[4] = {}, ck_last = __builtin_amdgcn_s_memtime();
+#define SDR_DEC_TICK(i)                                               \
+    do {                                                              \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        ck[i] += now_ - ck_last;                                      \
+        ck_last = now_;                                               \
+    } while (0)
+#else
+#define SDR_DEC_TICK(i)
+#endif
+
+    // ---- stage 0: wave per listener, lane per word
+    for (int li = wave; li < DEC_GROUP; li += DEC_WAVES) {
+        const int idx = group0 + li;
+        if (idx >= n_total || !slots[idx].active) {  // (the same for every lane of the wave)
+            if (lane == 0)
+                s_loc[li].n_edges = -1;
+            continue;
+        }
+        ListenerSlot *slot = &slots[idx];
+        const cw::Debouncer deb = slot->deb;
+        const int last_state = slot->dec.lastState;
+        // frames of this batch before the listener's first one (sdr_attach_at; 0 or less for everybody else)
+        const int skip = (int)(slot->start_frame - g.frame_base);
+        const cw::TickSpan span{min(max(skip, 0), n_frames), n_frames};
+        const uint64_t *rw = raw_bits + (size_t)idx * g.bit_words;
+        uint64_t *dw = deb_bits + (size_t)idx * g.bit_words;
+        sdr_edge *my_edges = edges + (size_t)idx * g.edge_cap;
+        uint32_t *my_pos = edge_pos + (size_t)idx * pos_stride;
+        const int band = idx / g.max_listeners, l = idx - band * g.max_listeners;
+        const bool pass = deb.threshold < 2;  // dsp/dsp.go:165-167: a pass-through that keeps no state
+        int last_restart = cw::deb_run_origin(deb, span);
+        bool carried = deb.effectiveState != 0;
+        uint32_t top_below = 0;  // the word below the chunk's first: upper half of its effective states
+        int n_edges = 0;
+        const int last = span.end - 1, last_word = last >> 6;  // (span.end > span.first whenever these are used)
+        int last_raw = 0, last_eff = 0;
+        for (int w0 = 0; w0 < n_words; w0 += 64) {
+            const int w = w0 + lane;
+            const bool in = w < n_words;
+            const uint64_t r = in ? rw[w] : 0ull, below = in && w > 0 ? rw[w - 1] : 0ull;
+            uint64_t eff;
+            if (pass) {
+                eff = r & cw::span_mask(span, w);
+            } else {
+                const uint64_t ch = cw::deb_changes(deb, r, below, span, w);
+                // the latest restart before this word: the nearest lane below that has one, else what the chunks below left
+                const uint64_t has_ch = __ballot(ch != 0);
+                const uint64_t ch_below = has_ch & cw::low_mask(lane);
+                const int my_restart = ch ? 64 * w + cw::top_bit(ch) : 0;
+                const int got = shfl_i(my_restart, ch_below ? cw::top_bit(ch_below) : 0);
+                const uint64_t q = cw::deb_qualified(ch, span, w, ch_below ? got : last_restart, deb.threshold);
+                const cw::DebFill f = cw::deb_fill(r, q);
+                // the state carried into this word: the nearest word below with a qualified tick decides it
+                const uint64_t has_q = __ballot(q != 0);
+                const uint64_t vals = __ballot(q != 0 && ((r >> cw::top_bit(q | 1ull)) & 1ull));
+                const uint64_t q_below = has_q & cw::low_mask(lane);
+                const bool cin = q_below ? (vals >> cw::top_bit(q_below)) & 1ull : carried;
+                eff = cw::deb_effective(f, cin, span, w);
+                if (has_ch)
+                    last_restart = shfl_i(my_restart, cw::top_bit(has_ch));
+                if (has_q)
+                    carried = (vals >> cw::top_bit(has_q)) & 1ull;
             }
-            if (em.key | (uint32_t)em.space) {  // the one place a tick's runes are written
-                if (em.key) {
-                    uint32_t r = cw::kUnknownCharacter;
-                    if (em.key != kInvalidChar) {
-                        const uint32_t looked_up = morse[em.key];
-                        r = looked_up ? looked_up : cw::kUnknownCharacter;
-                    }
-                    sink.frame = em.frame;
-                    sink.put(r);
-                }
-                if (em.space) {
-                    sink.frame = edge_frame;
-                    sink.put(' ');
-                }
+            if (in)
+                dw[w] = eff;
+            if (last_word >= w0 && last_word < w0 + 64) {
+                last_raw = shfl_i((int)((r >> (last & 63)) & 1ull), last_word - w0);
+                last_eff = shfl_i((int)((eff >> (last & 63)) & 1ull), last_word - w0);
+            }
+            // edges: the word below's top bit, the number of edges in the words below
+            const uint32_t eff_hi = (uint32_t)(eff >> 32);
+            uint32_t hi_below = (uint32_t)__shfl_up((int)eff_hi, 1, 64);
+            if (lane == 0)
+                hi_below = top_below;
+            top_below = (uint32_t)shfl_i((int)eff_hi, 63);
+            uint64_t e = cw::dec_edges(eff, (uint64_t)hi_below << 32, last_state, span, w);
+            const int cnt = cw::count_bits(e);
+            int incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int v = __shfl_up(incl, d, 64);
+                if (lane >= d)
+                    incl += v;
+            }
+            int k = n_edges + incl - cnt;
+            n_edges += shfl_i(incl, 63);
+            while (e) {
+                const int j = cw::bottom_bit(e);
+                e &= e - 1ull;
+                const uint32_t pos = (uint32_t)(64 * w + j);
+                my_pos[k] = pos;
+                if (k < g.edge_cap)
+                    my_edges[k] = sdr_edge{g.frame_base + pos, (uint32_t)((eff >> j) & 1ull)};
+                k++;
+            }
+            if (g.trace && in) {
+                const int cnt_w = min(64, n_frames - 64 * w);
+                for (int j = 0; j < cnt_w; j++)
+                    tr_deb[((size_t)band * g.stride + 64 * w + j) * g.max_listeners + l] = (eff >> j) & 1ull;
             }
         }
-        if (g.trace && writer)
-            for (int j = 0; j < cnt; j++)
-                tr_deb[((size_t)band * g.stride + f0 + j) * g.max_listeners + l] = (d >> j) & 1ull;
+        if (lane == 0) {
+            if (!pass && span.first < span.end) {
+                slot->deb.lastRawState = last_raw;
+                slot->deb.stateCount = last - last_restart + 1;
+                slot->deb.effectiveState = last_eff;
+            }
+            edge_counts[idx] = (uint32_t)n_edges;
+            // nothing is lost silently: what did not fit is counted bank-wide (rare; the host reads or polls the totals)
+            if (n_edges > g.edge_cap)
+                atomicAdd(&drops->edges, (unsigned long long)(n_edges - g.edge_cap));
+            DecodeLocal &L = s_loc[li];
+            const int state0 = last_state ? 0 : 1;
+            L.t0 = slot->dec.ticks;
+            L.start0 = state0 ? slot->dec.offStart : slot->dec.onStart;
+            L.tick_seconds = slot->dec.tickSeconds;
+            L.first = span.first;
+            L.end = span.end;
+            L.n_edges = n_edges;
+            L.state0 = state0;
+            L.abort_dits = slot->dec.abortDecodeAfterDits;
+            L.text_from = L.text_to = 0;
+            atomicMax(&s_max_edges, n_edges);
+        }
     }
-    if (!writer)
-        return;
-    slot->deb = deb;
-    slot->dec = dec;
-    // Frame numbers are 32 bits and compared as differences: a listener that has started must not keep a start_frame that
-    // falls 2^31 frames behind (config 5 gets there in 100 days and a decode-mode listener has no time-out) - the
-    // difference would turn positive and the listener go deaf.  Once a batch has reached the listener's first frame, both
-    // marks move along with the batches (nothing per listener depends on the absolute number after that).
-    if (skip < n_frames)
+    __syncthreads();  // (stage 0's global writes of edge positions are read below by other waves of this workgroup)
+    SDR_DEC_TICK(0);
+
+    // ---- who does what from here on
+    const bool wave_a = wave == 0, wave_c = wave == 1;
+    // stage B's threads: the waves of SIMD 2 and 3 (waves go to the SIMDs round-robin; the serial waves 0 and 1 keep theirs
+    // to themselves), or simply waves 2 ...
+    const int helper = SDR_DECODE_B_SIMD23 ? ((wave & 2) ? (((wave >> 2) * 2 + (wave & 1)) * 64 + lane) : -1) : (wave >= 2 ? (int)threadIdx.x - 128 : -1);
+    constexpr int N_HELPERS = SDR_DECODE_B_SIMD23 ? (DEC_WAVES / 4) * 2 * 64 : (DEC_WAVES - 2) * 64;
+    const bool serial_lane = (wave_a || wave_c) && lane < DEC_GROUP;
+    DecodeLocal loc{};
+    bool on = false;
+    ListenerSlot *slot = nullptr;
+    if (serial_lane) {
+        loc = s_loc[lane];
+        on = loc.n_edges >= 0 && loc.first < loc.end;
+        slot = &slots[min(group0 + lane, n_total - 1)];
+    }
+    const int shift = loc.state0 ? 0 : 1;  // a listener whose first edge is a falling one sits out the first (rising) step
+    cw::Chain chain{};                      // wave A
+    cw::DecoderState dec{};                 // wave A: what the chain goes back into; wave C: the current character, the speed
+    TextSink sink{nullptr, nullptr, 0u, 0u, 0u};
+    bool pend = false;      // wave C: the run behind the next falling edge aborts ...
+    uint32_t pend_at = 0;   // ... this many ticks into it
+    double gap_threshold_in = 0;
+    if (on) {
+        dec = slot->dec;
+        if (wave_a) {
+            chain = cw::chain_load(dec);
+        } else {
+            const int idx = group0 + lane;
+            sink = TextSink{text + (size_t)idx * g.text_cap, text_frames + (size_t)idx * g.text_cap, slot->text_count, (uint32_t)g.text_cap,
+                            slot->text_dropped};
+            loc.text_from = sink.count;
+            gap_threshold_in = dec.offThreshold.threshold;
+            // the run in front of the first edge: the decoder as carried
+            const int p0 = loc.n_edges ? (int)edge_pos[(size_t)idx * pos_stride] : loc.end;
+            cw::Emission em{0u, 0u, false};
+            cw::decoder_run(dec, p0 - loc.first, g.frame_base + (uint32_t)loc.first, em);
+            sink.put_if(em.key != 0, em.key, em.frame);
+        }
+    }
+    const int rounds = (s_max_edges + DEC_ROUND - 1) / DEC_ROUND;
+    // a round's edge positions, one before and two behind: a helper thread fetches one of them
+    auto fetch_position = [&](int round, int it) -> uint32_t {
+        const int li = it / DEC_POS_ROWS, i = it - li * DEC_POS_ROWS, k = round * DEC_ROUND - 1 + i;
+        const int ne = s_loc[li].n_edges;
+        if (ne < 0 || k < 0)
+            return 0u;
+        return k < ne ? edge_pos[(size_t)(group0 + li) * pos_stride + k] : (uint32_t)s_loc[li].end;
+    };
+    auto store_position = [&](int round, int it, uint32_t p) {
+        const int li = it / DEC_POS_ROWS, i = it - li * DEC_POS_ROWS;
+        s_pos[round & 3][i][li] = p;
+    };
+    constexpr int N_POS = DEC_POS_ROWS * DEC_GROUP;
+    constexpr int POS_PER_HELPER = (N_POS + N_HELPERS - 1) / N_HELPERS;
+    if (helper >= 0 && rounds > 0)
+        for (int n = 0; n < POS_PER_HELPER; n++)
+            if (helper + n * N_HELPERS < N_POS)
+                store_position(0, helper + n * N_HELPERS, fetch_position(0, helper + n * N_HELPERS));
+    __syncthreads();
+    SDR_DEC_TICK(1);
+
+    for (int t = 0; t < rounds + 2; t++) {
+        uint32_t ahead[POS_PER_HELPER];
+        const bool fetch = helper >= 0 && t + 1 < rounds;
+        if (fetch)
+#pragma unroll
+            for (int n = 0; n < POS_PER_HELPER; n++)
+                if (helper + n * N_HELPERS < N_POS)
+                    ahead[n] = fetch_position(t + 1, helper + n * N_HELPERS);
+        if (wave_a) {
+            // ---- stage A, round t
+            const int mine = on && t < rounds ? max(0, min(DEC_ROUND, loc.n_edges - t * DEC_ROUND)) : 0;
+            const auto &P = s_pos[t & 3];
+            auto &E = s_edge[t % 3];
+            if (__ballot(mine > 0))
+#pragma unroll 2
+                for (int j = 0; j <= DEC_ROUND / 2; j++) {
+                    const int kr = 2 * j - shift, kf = kr + 1;
+                    if (kr >= 0 && kr < mine) {
+                        double low, high;
+                        cw::chain_edge(chain, true, loc.t0 + (double)((int)P[kr + 1][lane] - loc.first + 1), &low, &high);
+                        E[kr][lane].chain.low = low;
+                        E[kr][lane].chain.high = high;
+                    }
+                    if (kf < mine) {
+                        double low, high;
+                        cw::chain_edge(chain, false, loc.t0 + (double)((int)P[kf + 1][lane] - loc.first + 1), &low, &high);
+                        E[kf][lane].chain.low = low;
+                        E[kf][lane].chain.high = high;
+                    }
+                }
+        } else if (wave_c) {
+            // ---- stage C, round t - 2
+            const int rc = t - 2;
+            const int mine = on && rc >= 0 ? max(0, min(DEC_ROUND, loc.n_edges - rc * DEC_ROUND)) : 0;
+            const auto &P = s_pos[rc & 3];
+            const auto &E = s_edge[(rc + 3) % 3];
+            if (mine > 0 && rc == 0 && shift) {
+                // the batch's first edge is a falling one: the run behind it is judged by the gap threshold as carried
+                const int p = (int)P[1][lane], p1 = (int)P[2][lane];
+                pend = cw::run_aborts(loc.t0 + (double)(p - loc.first + 1), p1 - p - 1, gap_threshold_in, loc.abort_dits, &pend_at);
+            }
+            if (__ballot(mine > 0))
+#pragma unroll 2
+                for (int j = 0; j <= DEC_ROUND / 2; j++) {
+                    const int kr = 2 * j - shift, kf = kr + 1;
+                    uint32_t key_edge, key_abort;
+                    bool space;
+                    if (kr >= 0 && kr < mine) {
+                        const cw::EdgeRec rec = E[kr][lane].rec;
+                        const uint32_t frame = g.frame_base + P[kr + 1][lane];
+                        cw::assemble_edge(dec, true, rec, (rec.flags & cw::ER_ABORT) != 0, &key_edge, &space, &key_abort);
+                        sink.put_if(key_edge != 0, key_edge, frame);
+                        sink.put_if(space, cw::kSpaceKey, frame);
+                        sink.put_if(key_abort != 0, key_abort, frame + 1u + rec.abort_at);
+                        pend = rec.flags & cw::ER_ABORT_NEXT;
+                        pend_at = rec.rise.abort_next_at;
+                    }
+                    if (kf < mine) {
+                        const cw::EdgeRec rec = E[kf][lane].rec;
+                        const uint32_t frame = g.frame_base + P[kf + 1][lane];
+                        cw::assemble_edge(dec, false, rec, pend, &key_edge, &space, &key_abort);
+                        sink.put_if(key_edge != 0, key_edge, frame);
+                        sink.put_if(key_abort != 0, key_abort, frame + 1u + pend_at);
+                    }
+                }
+        } else if (helper >= 0 && t >= 1 && t - 1 < rounds) {
+            // ---- stage B, round t - 1
+            const int rb = t - 1, k0 = rb * DEC_ROUND;
+            const auto &P = s_pos[rb & 3];
+            auto &E = s_edge[rb % 3];
+            for (int it = helper; it < DEC_ROUND * DEC_GROUP; it += N_HELPERS) {
+                const int kk = it / DEC_GROUP, li = it - kk * DEC_GROUP, k = k0 + kk;
+                const DecodeLocal &L = s_loc[li];
+                if (k >= L.n_edges)
+                    continue;
+                const int p_prev = (int)P[kk][li], p = (int)P[kk + 1][li], p1 = (int)P[kk + 2][li], p2 = (int)P[kk + 3][li];
+                const double now = L.t0 + (double)(p - L.first + 1);
+                const double duration = now - (k ? L.t0 + (double)(p_prev - L.first + 1) : L.start0);
+                const double low = E[kk][li].chain.low, high = E[kk][li].chain.high;
+                cw::EdgeRec rec;
+                if ((L.state0 ^ (k & 1)) != 0)
+                    rec = cw::classify_rising(duration, low, high, now, p1 - p - 1, L.t0 + (double)(p1 - L.first + 1), k + 1 < L.n_edges ? p2 - p1 - 1 : -1,
+                                              L.abort_dits);
+                else
+                    rec = cw::classify_falling(L.tick_seconds, duration, low, high);
+                E[kk][li].rec = rec;
+            }
+        }
+        if (fetch)
+#pragma unroll
+            for (int n = 0; n < POS_PER_HELPER; n++)
+                if (helper + n * N_HELPERS < N_POS)
+                    store_position(t + 1, helper + n * N_HELPERS, ahead[n]);
+        SDR_DEC_TICK(2);
+        __syncthreads();
+        SDR_DEC_TICK(3);
+    }
+
+    // ---- the decoder's state behind the batch; the batch's text: table keys -> runes
+    if (on && wave_a) {
+        cw::chain_store(chain, dec);
+        slot->dec.onThreshold = dec.onThreshold;
+        slot->dec.offThreshold = dec.offThreshold;
+        slot->dec.onStart = dec.onStart;
+        slot->dec.offStart = dec.offStart;
+        slot->dec.ticks = loc.t0 + (double)(loc.end - loc.first);
+        if (loc.n_edges)
+            slot->dec.lastState = loc.state0 ^ ((loc.n_edges - 1) & 1);
+        // Frame numbers are 32 bits and compared as differences: a listener that has started must not keep a start_frame
+        // that falls 2^31 frames behind (config 5 gets there in 100 days and a decode-mode listener has no time-out) - the
+        // difference would turn positive and the listener go deaf.  Once a batch has reached the listener's first frame,
+        // both marks move along with the batches (nothing per listener depends on the absolute number after that).
         slot->start_frame = slot->tapped_from = g.frame_base + (uint32_t)n_frames;
-    slot->text_count = sink.count;
-    // nothing is lost silently: what did not fit is counted bank-wide (rare; the host reads or polls the totals)
-    if (sink.dropped != slot->text_dropped)
-        atomicAdd(&drops->runes, (unsigned long long)(sink.dropped - slot->text_dropped));
-    if (n_edges > (uint32_t)g.edge_cap)
-        atomicAdd(&drops->edges, (unsigned long long)(n_edges - (uint32_t)g.edge_cap));
-    slot->text_dropped = sink.dropped;
-    edge_counts[idx] = n_edges;
+    }
+    if (on && wave_c) {
+        slot->dec.decoding = dec.decoding;
+        slot->dec.currentCharInvalid = dec.currentCharInvalid;
+        slot->dec.charLen = dec.charLen;
+        slot->dec.charBits = dec.charBits;
+        slot->dec.wpm = dec.wpm;
+        slot->text_count = sink.count;
+        if (sink.dropped != slot->text_dropped)
+            atomicAdd(&drops->runes, (unsigned long long)(sink.dropped - slot->text_dropped));
+        slot->text_dropped = sink.dropped;
+        s_loc[lane].text_from = loc.text_from;
+        s_loc[lane].text_to = sink.count;
+    }
+    __syncthreads();
+    for (int li = 0; li < DEC_GROUP; li++) {
+        if (s_loc[li].n_edges < 0)
+            continue;
+        uint32_t *buf = text + (size_t)(group0 + li) * g.text_cap;
+        for (uint32_t e = s_loc[li].text_from + threadIdx.x; e < s_loc[li].text_to; e += blockDim.x)
+            buf[e] = cw::key_to_rune(buf[e], morse);
+    }
+#if defined(SDR_DEC_CLOCK)
+    if (blockIdx.x == 0 && lane == 0 && wave < 4)  // (tools only: shader cycles of the chain wave, the character wave and two helpers)
+        printf("decode clocks wave %d: stage0 %llu setup %llu work %llu wait %llu rounds %d\n", wave, ck[0], ck[1], ck[2], ck[3], rounds);
+#endif
 }
 
 // cw.Decoder.stop for one listener (cw/decode.go:352-354)
@@ -284,13 +535,17 @@ __global__ void k_listener_stop(ListenerSlot *slot, const uint16_t *morse, uint3
     if (threadIdx.x != 0 || !slot->active)
         return;
     cw::DecoderState dec = slot->dec;
-    TextSink sink{text, text_frames, slot->text_count, (uint32_t)text_cap, slot->text_dropped, frame, frame, true};
+    struct StopSink {
+        TextSink to;
+        uint32_t frame;
+        __device__ void put(uint32_t r) { to.put_if(true, r, frame); }
+    } sink{TextSink{text, text_frames, slot->text_count, (uint32_t)text_cap, slot->text_dropped}, frame};
     cw::decoder_stop(dec, morse, sink);
     slot->dec = dec;
-    slot->text_count = sink.count;
-    if (sink.dropped != slot->text_dropped)
-        atomicAdd(&drops->runes, (unsigned long long)(sink.dropped - slot->text_dropped));
-    slot->text_dropped = sink.dropped;
+    slot->text_count = sink.to.count;
+    if (sink.to.dropped != slot->text_dropped)
+        atomicAdd(&drops->runes, (unsigned long long)(sink.to.dropped - slot->text_dropped));
+    slot->text_dropped = sink.to.dropped;
 }
 
 // Receiver.SetSignalDebounce on the band's current listeners (rx/receiver.go:238-244)
@@ -315,20 +570,12 @@ hipError_t launch_listen_gather(const float *tap, const float *psd, const sdr_fr
 hipError_t launch_listen_decode(ListenerSlot *slots, const uint16_t *morse, const uint64_t *raw_bits,
                                 uint64_t *deb_bits, uint32_t *text, uint32_t *text_frames, sdr_edge *edges,
                                 uint32_t *edge_counts, uint8_t *tr_deb, DropCounters *drops, const BatchCursor *cur, ListenGeom g,
-                                int n_frames, int n_bands, int live_hint, hipStream_t stream)
+                                int n_frames, int n_bands, uint32_t *edge_pos, int pos_stride, hipStream_t stream)
 {
-    // live_hint: an upper bound of the signals being decoded (the slots in use)
+    // edge_pos: [band][listener][pos_stride] scratch, pos_stride >= n_frames (an edge per tick at most)
     const int n_total = n_bands * g.max_listeners;
-    const int lanes = (live_hint <= 64 || DECODE_LANES_MAX < 2) ? 1 : (live_hint <= 128 || DECODE_LANES_MAX < 4) ? 2 : DECODE_LANES_MAX;
-    const dim3 grid((n_total + lanes * DECODE_WAVES - 1) / (lanes * DECODE_WAVES)), block(64 * DECODE_WAVES);
-#define SDR_DECODE_ARGS slots, morse, raw_bits, deb_bits, text, text_frames, edges, edge_counts, tr_deb, drops, cur, g, n_frames, n_total
-    if (lanes == 1)
-        launch_kernel(k_listen_decode<1>, grid, block, 0, stream, SDR_DECODE_ARGS);
-    else if (lanes == 2)
-        launch_kernel(k_listen_decode<2>, grid, block, 0, stream, SDR_DECODE_ARGS);
-    else
-        launch_kernel(k_listen_decode<DECODE_LANES_MAX>, grid, block, 0, stream, SDR_DECODE_ARGS);
-#undef SDR_DECODE_ARGS
+    launch_kernel(k_listen_decode, dim3((n_total + DEC_GROUP - 1) / DEC_GROUP), dim3(64 * DEC_WAVES), 0, stream, slots, morse, raw_bits, deb_bits, text,
+                  text_frames, edges, edge_counts, tr_deb, drops, cur, g, n_frames, n_total, edge_pos, pos_stride);
     return hipGetLastError();
 }
 

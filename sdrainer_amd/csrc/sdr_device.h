@@ -141,7 +141,7 @@ hipError_t launch_listen_gather(const float *tap, const float *psd, const sdr_fr
 hipError_t launch_listen_decode(ListenerSlot *slots, const uint16_t *morse, const uint64_t *raw_bits,
                                 uint64_t *deb_bits, uint32_t *text, uint32_t *text_frames, sdr_edge *edges,
                                 uint32_t *edge_counts, uint8_t *tr_deb, DropCounters *drops, const BatchCursor *cur, ListenGeom g,
-                                int n_frames, int n_bands, int live_hint, hipStream_t stream);
+                                int n_frames, int n_bands, uint32_t *edge_pos, int pos_stride, hipStream_t stream);
 hipError_t launch_listener_stop(ListenerSlot *slot, const uint16_t *morse, uint32_t *text, uint32_t *text_frames, int text_cap,
                                 uint32_t frame, DropCounters *drops, hipStream_t stream);
 hipError_t launch_set_debounce(ListenerSlot *slots, int n, int threshold, hipStream_t stream);

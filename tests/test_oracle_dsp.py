@@ -325,33 +325,22 @@ def test_fast_db_path_is_certified(tmp_path):
     assert "mismatches 0" in out.stdout
 
 
-def test_debounce_word_matches_the_literal_debouncer(tmp_path):
-    """The decoder kernel debounces a 64-frame word a run at a time (cw_decoder.h debounce_word); that is the same
-    function as 64 literal BoolDebouncer.Debounce calls, state included: 2M words, thresholds 0-9, on the CPU."""
+def test_staged_listener_chain_matches_literal_ticks(tmp_path):
+    """k_listen_decode's stages (cw_stages.h: debouncer per 64-tick word, edge list, threshold chain per edge,
+    classification per edge, character assembly per edge) against literal BoolDebouncer.Debounce + Decoder.Tick calls
+    on the CPU, tick by tick: same debounced bits, edges, runes, rune frames, and the same debouncer and decoder state at
+    the end of every batch - 600 streams (keyed with jitter, glitches, over-long marks, long silences, over-long
+    characters, plain noise) cut into batches of random length, debounce thresholds 1 ... 200, listeners that start
+    inside a batch."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "emu_debounce")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(root, "tests", "emu", "emu_debounce.cpp")])
-    out = subprocess.run([exe], capture_output=True, text=True)
-    assert out.returncode == 0, out.stdout + out.stderr
-    assert "mismatches 0" in out.stdout
-
-
-def test_kernel_decoder_loop_matches_literal_ticks(tmp_path):
-    """The decoder loop of k_listen_decode - closed form over a run of equal states, the edge tick, one place per
-    iteration that writes runes (cw_decoder.h decoder_run / decoder_edge_deferred) - against literal Decoder.Tick calls
-    on the CPU: same runes, same frames, same state after every 64-tick word, over 400 keyed streams with glitches,
-    over-long marks, long silences and over-long characters."""
-    import os
-    import subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "emu_decoder")
+    exe = str(tmp_path / "emu_stages")
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-o", exe,
-                           os.path.join(root, "tests", "emu", "emu_decoder.cpp")])
+                           os.path.join(root, "tests", "emu", "emu_stages.cpp")])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "mismatches 0" in out.stdout and " 0 runes" not in out.stdout
+    assert "mismatches 0" in out.stdout and " 0 runes" not in out.stdout and " 0 edges" not in out.stdout
 
 
 def test_cumulation_bound_is_an_upper_bound(tmp_path):
