@@ -264,7 +264,7 @@ SDR_HD inline void decoder_tick(DecoderState &d, bool state, const uint16_t *tab
 // is reached from four places in a tick (the abort check, a character gap, a word gap, a ninth symbol); each of them
 // empties the current character, so the stages only TAKE the character (a table key, 0 = nothing) and the caller looks
 // it up and writes the rune.  (tests/emu/emu_stages.cpp: identical to Decoder.Tick tick by tick.)
-constexpr uint32_t kInvalidChar = 0xFFFFFFFFu;  // a character with an over-long Da in it: decodes to kUnknownCharacter
+constexpr uint32_t kInvalidChar = 0xFFFFu;  // a character with an over-long Da in it: decodes to kUnknownCharacter (table keys are below 512: a key fits 16 bits)
 
 // the state changes of decodeCurrentChar, without the output: returns the table key of the character taken
 // (kInvalidChar for an invalid one), 0 if there was none

@@ -139,24 +139,17 @@ SDR_HD inline Chain chain_load(const DecoderState &d)
                  d.offThreshold.low, d.offThreshold.high, d.offThreshold.last, d.offThreshold.upperBound,
                  d.onStart,          d.offStart,          false,               false};
 }
-// The tick `now` (Decoder.ticks after its increment) at which the debounced state changes to `state`: :222-240, with
-// AdaptiveThreshold.Put (:392-411) as straight-line selects - both candidate updates are formed and the one the
-// reference's branches take is chosen; a select returns one of its operands unchanged, so every value is the one the
-// branching code computes.  A rising edge feeds the gap (off) threshold, a falling edge the mark (on) threshold.
-// *low, *high: the fed threshold's values behind the edge.
-SDR_HD inline void chain_edge(Chain &c, bool state, double now, double *low, double *high)
+// AdaptiveThreshold.Put (cw/decode.go:392-411) on one threshold's (low, high, last), as straight-line selects - both
+// candidate updates are formed and the one the reference's branches take is chosen; a select returns one of its operands
+// unchanged, so every value is the one the branching code computes.  `duration`: the run the edge ends (Put is only
+// called for runs of minDitTime and more, :254, :279).  Returns whether low / high changed.
+SDR_HD inline bool chain_step(double &lo, double &hi, double &last, double bound, double duration)
 {
-    const double duration = now - (state ? c.off_start : c.on_start);  // offDuration / onDuration
-    c.on_start = state ? now : c.on_start;
-    c.off_start = state ? c.off_start : now;
-    const bool gate = duration >= kMinDitTime;  // :254, :279: shorter runs are ignored
-    double lo = state ? c.off_low : c.on_low, hi = state ? c.off_high : c.on_high;
-    double last = state ? c.off_last : c.on_last;
-    const double bound = state ? c.off_bound : c.on_bound;
+    const bool gate = duration >= kMinDitTime;
     const double highFactor = 2, avgWeight = 0.75, currentWeight = 1.0 - avgWeight;
     const bool use = gate && !(duration >= lo * bound);
-    const bool down = last >= duration * highFactor;            // this one shorter: it is the new low sample
-    const bool up = !down && duration >= last * highFactor;     // this one longer: the new high sample
+    const bool down = last >= duration * highFactor;         // this one shorter: it is the new low sample
+    const bool up = !down && duration >= last * highFactor;  // this one longer: the new high sample
     const bool moved = use && (down || up);
     const double lo_sample = down ? duration : last, hi_sample = down ? last : duration;
     const double new_lo = avgWeight * lo + currentWeight * lo_sample;
@@ -164,34 +157,45 @@ SDR_HD inline void chain_edge(Chain &c, bool state, double now, double *low, dou
     lo = moved ? new_lo : lo;
     hi = moved ? new_hi : hi;
     last = use ? duration : last;
-    c.off_low = state ? lo : c.off_low;
-    c.off_high = state ? hi : c.off_high;
-    c.off_last = state ? last : c.off_last;
-    c.on_low = state ? c.on_low : lo;
-    c.on_high = state ? c.on_high : hi;
-    c.on_last = state ? c.on_last : last;
-    c.off_moved = c.off_moved || (state && moved);
-    c.on_moved = c.on_moved || (!state && moved);
-    *low = lo;
-    *high = hi;
+    return moved;
+}
+// The tick `now` (Decoder.ticks after its increment) at which the debounced state changes to `state`: :222-240.  A rising
+// edge feeds the gap (off) threshold with the gap it ends, a falling edge the mark (on) threshold with the mark: the two
+// thresholds are two independent chains (the kernel runs them on two waves), coupled only through the edges' ticks -
+// a run's duration is its edge's tick minus the edge's before.  *low, *high: the fed threshold's values behind the edge.
+SDR_HD inline void chain_edge(Chain &c, bool state, double now, double *low, double *high)
+{
+    const double duration = now - (state ? c.off_start : c.on_start);  // offDuration / onDuration
+    if (state) {
+        c.on_start = now;
+        c.off_moved = chain_step(c.off_low, c.off_high, c.off_last, c.off_bound, duration) || c.off_moved;
+        *low = c.off_low;
+        *high = c.off_high;
+    } else {
+        c.off_start = now;
+        c.on_moved = chain_step(c.on_low, c.on_high, c.on_last, c.on_bound, duration) || c.on_moved;
+        *low = c.on_low;
+        *high = c.on_high;
+    }
 }
 // the chain back into the decoder at the end of the batch (updateThreshold :413-416 for a threshold that moved; one that
 // did not keeps the square root it has)
-SDR_HD inline void chain_store(const Chain &c, DecoderState &d)
+SDR_HD inline void chain_store(const Chain &c, AdaptiveThreshold &on, AdaptiveThreshold &off, double *on_start, double *off_start)
 {
-    d.onThreshold.low = c.on_low;
-    d.onThreshold.high = c.on_high;
-    d.onThreshold.last = c.on_last;
-    d.offThreshold.low = c.off_low;
-    d.offThreshold.high = c.off_high;
-    d.offThreshold.last = c.off_last;
+    on.low = c.on_low;
+    on.high = c.on_high;
+    on.last = c.on_last;
+    off.low = c.off_low;
+    off.high = c.off_high;
+    off.last = c.off_last;
     if (c.on_moved)
-        at_update(d.onThreshold);
+        at_update(on);
     if (c.off_moved)
-        at_update(d.offThreshold);
-    d.onStart = c.on_start;
-    d.offStart = c.off_start;
+        at_update(off);
+    *on_start = c.on_start;
+    *off_start = c.off_start;
 }
+SDR_HD inline void chain_store(const Chain &c, DecoderState &d) { chain_store(c, d.onThreshold, d.offThreshold, &d.onStart, &d.offStart); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Stage B, per edge: everything that reads the chain.
@@ -264,12 +268,16 @@ SDR_HD inline EdgeRec classify_falling(double tick_seconds, double duration, dou
 // ---------------------------------------------------------------------------------------------------------------
 // Stage C, per listener, edge after edge: the current character.
 // ---------------------------------------------------------------------------------------------------------------
-// What an edge and the run behind it do to the current character, as selects (the 64 listeners of a group walk their
-// edges in lockstep: a branch any of them takes is paid by all).  `rising`: the edge's polarity (the caller's steps
-// alternate, so it is a constant where this is inlined).  `abort`: the abort check fires in the run behind the edge - for
-// a rising edge its own ER_ABORT, for a falling one the ER_ABORT_NEXT of the rising edge before it (for the batch's first
-// edge: run_aborts with the gap threshold as carried).  Out: the table keys of the characters taken at the edge's tick
-// and at the abort's (0: none; kInvalidChar), and whether a word gap's ' ' follows the edge's character.
+// What an edge and the run behind it do to the current character, as selects (the listeners of a group walk their edges
+// in lockstep: a branch any of them takes is paid by all - so the two rare things, a ninth symbol and an abort, are
+// skipped by a vote of the lanes, everything else is straight-line).  `rising`: the edge's polarity (the caller's steps
+// alternate, so it is a constant where this is inlined).  Out: the table key of the character taken at the edge's tick
+// (0: none; kInvalidChar), and whether a word gap's ' ' follows it.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SDR_ANY_LANE(x) (__builtin_amdgcn_ballot_w64(x) != 0ull)  // true in every active lane if true in any
+#else
+#define SDR_ANY_LANE(x) (x)
+#endif
 SDR_HD inline uint32_t take_char_if(DecoderState &d, bool cond)  // take_char(d) if cond, nothing otherwise
 {
     const bool has = cond && d.charLen != 0;
@@ -279,7 +287,7 @@ SDR_HD inline uint32_t take_char_if(DecoderState &d, bool cond)  // take_char(d)
     d.charBits = cond ? 0u : d.charBits;
     return has ? key : 0u;
 }
-SDR_HD inline void assemble_edge(DecoderState &d, bool rising, const EdgeRec &r, bool abort, uint32_t *key_edge, bool *space, uint32_t *key_abort)
+SDR_HD inline void assemble_edge(DecoderState &d, bool rising, const EdgeRec &r, uint32_t *key_edge, bool *space)
 {
     if (rising) {  // onRisingEdge :260-274
         *key_edge = take_char_if(d, (r.flags & ER_TAKE) != 0);
@@ -287,17 +295,41 @@ SDR_HD inline void assemble_edge(DecoderState &d, bool rising, const EdgeRec &r,
     } else {  // onFallingEdge :285-297
         d.currentCharInvalid = (r.flags & ER_INVALID) ? 1 : d.currentCharInvalid;
         const bool symbol = r.flags & ER_SYMBOL, da = r.flags & ER_DA;
-        *key_edge = take_char_if(d, symbol && d.charLen == kMaxSymbolCount);  // appendSymbol :308-310 (rare)
+        const bool ninth = symbol && d.charLen == kMaxSymbolCount;  // appendSymbol :308-310
+        *key_edge = 0;
+        if (SDR_ANY_LANE(ninth))
+            *key_edge = take_char_if(d, ninth);
         *space = false;
         d.charBits = symbol ? ((d.charBits << 1) | (da ? 1u : 0u)) : d.charBits;
         d.charLen += symbol ? 1 : 0;
         const double wpm = (d.wpm + r.wpm_term) / 2.0;
         d.wpm = (symbol && da) ? wpm : d.wpm;
     }
-    *key_abort = take_char_if(d, abort);  // :244-249 in the run behind the edge
-    d.decoding = abort ? 0 : 1;
+    d.decoding = 1;  // :241
 }
-constexpr uint32_t kSpaceKey = 0xFFFFFFFEu;  // ' ' in a list of table keys
+// the abort check in the run behind the edge (:244-249): `abort` - for a rising edge its own ER_ABORT, for a falling one the
+// ER_ABORT_NEXT of the rising edge before it (the batch's first edge: run_aborts with the gap threshold as carried)
+SDR_HD inline uint32_t assemble_abort(DecoderState &d, bool abort)
+{
+    uint32_t key = 0;
+    if (SDR_ANY_LANE(abort)) {
+        key = take_char_if(d, abort);
+        d.decoding = abort ? 0 : d.decoding;
+    }
+    return key;
+}
+// What an edge's step may write, in the reference's order: the edge's character, the word gap's ' ' (both at the edge's
+// frame), the abort's character (at its own).
+constexpr uint32_t kSpaceKey = 0xFFFEu;  // ' ' in a list of table keys
+struct EdgeEvents {
+    uint32_t keys;   // the edge's character | the abort's << 16 (table keys, kInvalidChar; 0: none)
+    uint32_t space;  // a word gap's ' ' between them
+    uint32_t frame, abort_frame;
+};
+SDR_HD inline EdgeEvents edge_events(uint32_t key_edge, bool space, uint32_t key_abort, uint32_t frame, uint32_t abort_at)
+{
+    return EdgeEvents{key_edge | (key_abort << 16), space ? 1u : 0u, frame, frame + 1u + abort_at};
+}
 // a key as the rune the reference writes (decodeCurrentChar :315-350)
 SDR_HD inline uint32_t key_to_rune(uint32_t key, const uint16_t *table)
 {

@@ -105,18 +105,24 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) void k_listen_gather(const float
 //             the words by ballot / shuffle), the edge list - to the batch's edge buffer for the host, and every
 //             edge's position to a scratch row (the host's buffer may be shorter than the list) - and the debouncer's
 //             state behind the batch;
-//   then, DEC_ROUND edges of every listener at a time, as a pipeline of three stages on different waves with one
-//   workgroup barrier per step (step t: A works on round t, B on round t - 1, C on round t - 2, through LDS):
-//   stage A   a LANE per listener (wave 0), edge after edge: the threshold chain;
-//   stage B   a thread per (listener, edge), waves of the SIMDs the serial waves are not on: thresholds (the square
-//             roots), classification, the speed term (the division), the abort ticks of the runs;
-//   stage C   a lane per listener (wave 1), edge after edge: characters, the speed average, the text buffer (table
-//             keys; translated to runes by everybody at the end).
-// The serial stages walk rising and falling edges in alternating steps (a listener whose first edge is a falling one
-// sits out the first step), so no step selects a polarity; they hold no square root, no division, no table lookup
-// and no branch but the predicated store of a rune: about 35 (A) and 45 (C) instructions per edge, issued by one wave -
-// a wave's instruction takes four cycles however many of its lanes work, so that, not the float64 chain's latency, is
-// what an edge costs.  Sixteen workgroups decode config 3's 256 listeners.
+//   then, DEC_ROUND edges of every listener at a time, as a pipeline of four stages on different waves with one
+//   workgroup barrier per step (step t: A works on round t, B on round t - 1, C on t - 2, D on t - 3, through LDS):
+//   stage A   a LANE per listener, edge after edge, on TWO waves: the gap threshold's chain over the rising edges (wave
+//             0) and the mark threshold's over the falling ones (wave 2) - they are independent of each other;
+//   stage B   a thread per (listener, edge), helper waves: thresholds (the square roots), classification, the speed
+//             term (the division), the abort ticks of the runs;
+//   stage C   a lane per listener (wave 1), edge after edge: the current character, the speed average; what the edge
+//             writes - up to two characters (as table keys) and a ' ' - goes to LDS;
+//   stage D   helper waves, half a wave per listener, a lane per edge: the written runes' places by a prefix sum, table
+//             lookup, runes and frames into the text buffer.
+// Each serial wave has a SIMD's issue slots to itself (waves go to the four SIMDs round-robin).  The serial stages hold
+// no square root, no division, no table lookup and no store to memory; C walks rising and falling edges in alternating
+// steps (a listener whose first edge is a falling one sits out the first step), so no step selects a polarity, and
+// skips the two rare things - a ninth symbol, an abort - by a vote of the lanes.  Measured (tools/build_abl.sh with
+// -DSDR_DEC_CLOCK, config 3, 8192 frames, 530 edges per listener): a chain wave spends 185 clocks per edge of its
+// polarity, the character wave 430 per edge (70 instructions; a wave's instruction takes four cycles however many of
+// its lanes work, and the compare -> mask -> select patterns add their latency): C paces the pipeline, 0.12 ms per batch
+// where one lane per listener walking everything took 0.44.  Sixteen workgroups decode config 3's 256 listeners.
 // ---------------------------------------------------------------------------------------------------------------
 #ifndef SDR_DECODE_GROUP
 #define SDR_DECODE_GROUP 16
@@ -127,8 +133,8 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) void k_listen_gather(const float
 #ifndef SDR_DECODE_ROUND
 #define SDR_DECODE_ROUND 32
 #endif
-#ifndef SDR_DECODE_B_SIMD23
-#define SDR_DECODE_B_SIMD23 1
+#ifndef SDR_DECODE_HELPERS
+#define SDR_DECODE_HELPERS 1
 #endif
 constexpr int DEC_GROUP = SDR_DECODE_GROUP;  // listeners per workgroup: lanes of the waves that run the serial stages
 constexpr int DEC_WAVES = SDR_DECODE_WAVES;
@@ -164,14 +170,15 @@ struct DecodeLocal {
     int n_edges;          // -1: no listener in this slot
     int state0;           // the first edge's new state
     int abort_dits;       // Decoder.abortDecodeAfterDits
-    uint32_t text_from, text_to;  // stage C -> the translation at the end: the batch's entries in the text buffer
+    uint32_t first_key, first_frame;  // the character the run in front of the first edge took (0: none), for stage D
 };
-// an edge's 16 bytes of LDS: stage A's output, replaced by stage B's
+// an edge's 16 bytes of LDS: stage A's output, replaced by stage B's, replaced by stage C's
 union EdgeSlot {
     struct {
         double low, high;
     } chain;
     cw::EdgeRec rec;
+    cw::EdgeEvents events;
 };
 
 __device__ __forceinline__ int shfl_i(int v, int src) { return __shfl(v, src, 64); }
@@ -188,7 +195,8 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void k_listen_decode(ListenerSlot *
         g.frame_base = cur->frame_base;
     __shared__ DecodeLocal s_loc[DEC_GROUP];
     __shared__ uint32_t s_pos[4][DEC_POS_ROWS][DEC_GROUP + 1];  // [round & 3][i][l]: position of listener l's edge k0 - 1 + i (behind the last one: the span's end)
-    __shared__ __attribute__((aligned(16))) EdgeSlot s_edge[3][DEC_ROUND][DEC_GROUP];
+    __shared__ double s_now[3][DEC_POS_ROWS][DEC_GROUP + 1];    // [round % 3]: ... and the edge's tick (Decoder.ticks behind its increment)
+    __shared__ __attribute__((aligned(16))) EdgeSlot s_edge[4][DEC_ROUND][DEC_GROUP];
     __shared__ int s_max_edges;
     if (threadIdx.x == 0)
         s_max_edges = 0;
@@ -319,7 +327,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void k_listen_decode(ListenerSlot *
             L.n_edges = n_edges;
             L.state0 = state0;
             L.abort_dits = slot->dec.abortDecodeAfterDits;
-            L.text_from = L.text_to = 0;
+            L.first_key = L.first_frame = 0;
             atomicMax(&s_max_edges, n_edges);
         }
     }
@@ -327,11 +335,17 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void k_listen_decode(ListenerSlot *
     SDR_DEC_TICK(0);
 
     // ---- who does what from here on
-    const bool wave_a = wave == 0, wave_c = wave == 1;
-    // stage B's threads: the waves of SIMD 2 and 3 (waves go to the SIMDs round-robin; the serial waves 0 and 1 keep theirs
-    // to themselves), or simply waves 2 ...
-    const int helper = SDR_DECODE_B_SIMD23 ? ((wave & 2) ? (((wave >> 2) * 2 + (wave & 1)) * 64 + lane) : -1) : (wave >= 2 ? (int)threadIdx.x - 128 : -1);
-    constexpr int N_HELPERS = SDR_DECODE_B_SIMD23 ? (DEC_WAVES / 4) * 2 * 64 : (DEC_WAVES - 2) * 64;
+    // Waves go to the CU's four SIMDs round-robin.  Each serial stage has a SIMD's issue slots to itself: the gap
+    // threshold's chain (wave 0), the character assembly (wave 1), the mark threshold's chain (wave 2); the helpers
+    // (stage B, the position fetches, stage D) are the waves of SIMD 3 - and, SDR_DECODE_HELPERS = 1, the other waves of SIMD 2.
+    const bool wave_ar = wave == 0, wave_c = wave == 1, wave_af = wave == 2, wave_a = wave_ar || wave_af;
+    constexpr int N_HELPER_WAVES = DEC_WAVES / 4 + (SDR_DECODE_HELPERS ? DEC_WAVES / 4 - 1 : 0);
+    const int helper_wave = (wave & 3) == 3 ? wave >> 2 : (SDR_DECODE_HELPERS && (wave & 3) == 2 && wave > 2) ? DEC_WAVES / 4 + (wave >> 2) - 1 : -1;
+    const int helper = helper_wave >= 0 ? helper_wave * 64 + lane : -1;
+    constexpr int N_HELPERS = N_HELPER_WAVES * 64;
+    constexpr int N_PAIRS = (DEC_GROUP + 1) / 2;  // stage D: two listeners to a wave, a lane per edge of the round
+    constexpr int D_PER_WAVE = (N_PAIRS + N_HELPER_WAVES - 1) / N_HELPER_WAVES;
+    static_assert(DEC_ROUND == 32, "stage D: half a wave per listener");
     const bool serial_lane = (wave_a || wave_c) && lane < DEC_GROUP;
     DecodeLocal loc{};
     bool on = false;
@@ -341,28 +355,31 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void k_listen_decode(ListenerSlot *
         on = loc.n_edges >= 0 && loc.first < loc.end;
         slot = &slots[min(group0 + lane, n_total - 1)];
     }
-    const int shift = loc.state0 ? 0 : 1;  // a listener whose first edge is a falling one sits out the first (rising) step
-    cw::Chain chain{};                      // wave A
-    cw::DecoderState dec{};                 // wave A: what the chain goes back into; wave C: the current character, the speed
-    TextSink sink{nullptr, nullptr, 0u, 0u, 0u};
-    bool pend = false;      // wave C: the run behind the next falling edge aborts ...
-    uint32_t pend_at = 0;   // ... this many ticks into it
+    const int shift = loc.state0 ? 0 : 1;  // the round's rising edges are the ones at shift, shift + 2, ... (a round is an even number of edges)
+    // waves A: one threshold's chain
+    double t_low = 0, t_high = 0, t_last = 0, t_bound = 0, last_now = 0;
+    bool t_moved = false, any_mine = false;
+    // wave C: the current character, the speed
+    cw::DecoderState dec{};
+    bool pend = false;     // the run behind the next falling edge aborts ...
+    uint32_t pend_at = 0;  // ... this many ticks into it
     double gap_threshold_in = 0;
     if (on) {
-        dec = slot->dec;
         if (wave_a) {
-            chain = cw::chain_load(dec);
+            const cw::AdaptiveThreshold &th = wave_ar ? slot->dec.offThreshold : slot->dec.onThreshold;
+            t_low = th.low;
+            t_high = th.high;
+            t_last = th.last;
+            t_bound = th.upperBound;
         } else {
-            const int idx = group0 + lane;
-            sink = TextSink{text + (size_t)idx * g.text_cap, text_frames + (size_t)idx * g.text_cap, slot->text_count, (uint32_t)g.text_cap,
-                            slot->text_dropped};
-            loc.text_from = sink.count;
+            dec = slot->dec;
             gap_threshold_in = dec.offThreshold.threshold;
             // the run in front of the first edge: the decoder as carried
-            const int p0 = loc.n_edges ? (int)edge_pos[(size_t)idx * pos_stride] : loc.end;
+            const int p0 = loc.n_edges ? (int)edge_pos[(size_t)(group0 + lane) * pos_stride] : loc.end;
             cw::Emission em{0u, 0u, false};
             cw::decoder_run(dec, p0 - loc.first, g.frame_base + (uint32_t)loc.first, em);
-            sink.put_if(em.key != 0, em.key, em.frame);
+            s_loc[lane].first_key = em.key;
+            s_loc[lane].first_frame = em.frame;
         }
     }
     const int rounds = (s_max_edges + DEC_ROUND - 1) / DEC_ROUND;
@@ -374,9 +391,11 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void k_listen_decode(ListenerSlot *
             return 0u;
         return k < ne ? edge_pos[(size_t)(group0 + li) * pos_stride + k] : (uint32_t)s_loc[li].end;
     };
+    // ... and lays it down as a position (stages B, C) and as the edge's tick, Decoder.ticks behind its increment (A, B)
     auto store_position = [&](int round, int it, uint32_t p) {
         const int li = it / DEC_POS_ROWS, i = it - li * DEC_POS_ROWS;
         s_pos[round & 3][i][li] = p;
+        s_now[round % 3][i][li] = s_loc[li].t0 + (double)((int)p - s_loc[li].first + 1);
     };
     constexpr int N_POS = DEC_POS_ROWS * DEC_GROUP;
     constexpr int POS_PER_HELPER = (N_POS + N_HELPERS - 1) / N_HELPERS;
@@ -386,8 +405,33 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void k_listen_decode(ListenerSlot *
                 store_position(0, helper + n * N_HELPERS, fetch_position(0, helper + n * N_HELPERS));
     __syncthreads();
     SDR_DEC_TICK(1);
+    // stage D's state: where the next rune of this lane's listener goes (the same in the 32 lanes of a listener)
+    uint32_t text_at[D_PER_WAVE] = {}, text_cap_hit[D_PER_WAVE] = {};
+    auto d_listener = [&](int n) {  // the listener this lane works for in its wave's n-th pair, -1: none
+        const int li = (helper_wave + n * N_HELPER_WAVES) * 2 + (lane >> 5);
+        return helper_wave >= 0 && li < DEC_GROUP && s_loc[li].n_edges >= 0 && s_loc[li].first < s_loc[li].end ? li : -1;
+    };
+#pragma unroll
+    for (int n = 0; n < D_PER_WAVE; n++) {
+        const int li = d_listener(n);
+        if (li < 0)
+            continue;
+        const int idx = group0 + li;
+        text_at[n] = slots[idx].text_count;
+        if (s_loc[li].first_key) {  // the character the run in front of the first edge took
+            if (text_at[n] < (uint32_t)g.text_cap) {
+                if ((lane & 31) == 0) {
+                    text[(size_t)idx * g.text_cap + text_at[n]] = cw::key_to_rune(s_loc[li].first_key, morse);
+                    text_frames[(size_t)idx * g.text_cap + text_at[n]] = s_loc[li].first_frame;
+                }
+                text_at[n]++;
+            } else {
+                text_cap_hit[n]++;
+            }
+        }
+    }
 
-    for (int t = 0; t < rounds + 2; t++) {
+    for (int t = 0; t < rounds + 3; t++) {
         uint32_t ahead[POS_PER_HELPER];
         const bool fetch = helper >= 0 && t + 1 < rounds;
         if (fetch)
@@ -396,83 +440,139 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void k_listen_decode(ListenerSlot *
                 if (helper + n * N_HELPERS < N_POS)
                     ahead[n] = fetch_position(t + 1, helper + n * N_HELPERS);
         if (wave_a) {
-            // ---- stage A, round t
+            // ---- stage A, round t: this wave's threshold, the edges of its polarity
             const int mine = on && t < rounds ? max(0, min(DEC_ROUND, loc.n_edges - t * DEC_ROUND)) : 0;
-            const auto &P = s_pos[t & 3];
-            auto &E = s_edge[t % 3];
-            if (__ballot(mine > 0))
-#pragma unroll 2
-                for (int j = 0; j <= DEC_ROUND / 2; j++) {
-                    const int kr = 2 * j - shift, kf = kr + 1;
-                    if (kr >= 0 && kr < mine) {
-                        double low, high;
-                        cw::chain_edge(chain, true, loc.t0 + (double)((int)P[kr + 1][lane] - loc.first + 1), &low, &high);
-                        E[kr][lane].chain.low = low;
-                        E[kr][lane].chain.high = high;
-                    }
-                    if (kf < mine) {
-                        double low, high;
-                        cw::chain_edge(chain, false, loc.t0 + (double)((int)P[kf + 1][lane] - loc.first + 1), &low, &high);
-                        E[kf][lane].chain.low = low;
-                        E[kf][lane].chain.high = high;
+            const auto &T = s_now[t % 3];
+            auto &E = s_edge[t & 3];
+            if (__ballot(mine > 0)) {
+                const int k_first = wave_ar ? shift : 1 - shift;
+                double before = T[k_first][lane], now = T[k_first + 1][lane];
+#pragma unroll 4
+                for (int kk = k_first; kk < DEC_ROUND; kk += 2) {
+                    const double t0 = before, t1 = now;
+                    before = T[min(kk + 2, DEC_POS_ROWS - 1)][lane];  // (the next step's, on their way while this one computes)
+                    now = T[min(kk + 3, DEC_POS_ROWS - 1)][lane];
+                    if (kk < mine) {
+                        const double duration = t1 - (t * DEC_ROUND + kk ? t0 : loc.start0);
+                        t_moved = cw::chain_step(t_low, t_high, t_last, t_bound, duration) || t_moved;
+                        last_now = t1;
+                        any_mine = true;
+                        E[kk][lane].chain.low = t_low;
+                        E[kk][lane].chain.high = t_high;
                     }
                 }
+            }
         } else if (wave_c) {
             // ---- stage C, round t - 2
             const int rc = t - 2;
-            const int mine = on && rc >= 0 ? max(0, min(DEC_ROUND, loc.n_edges - rc * DEC_ROUND)) : 0;
+            const int mine = on && rc >= 0 && rc < rounds ? max(0, min(DEC_ROUND, loc.n_edges - rc * DEC_ROUND)) : 0;
             const auto &P = s_pos[rc & 3];
-            const auto &E = s_edge[(rc + 3) % 3];
+            auto &E = s_edge[rc & 3];
             if (mine > 0 && rc == 0 && shift) {
                 // the batch's first edge is a falling one: the run behind it is judged by the gap threshold as carried
                 const int p = (int)P[1][lane], p1 = (int)P[2][lane];
                 pend = cw::run_aborts(loc.t0 + (double)(p - loc.first + 1), p1 - p - 1, gap_threshold_in, loc.abort_dits, &pend_at);
             }
-            if (__ballot(mine > 0))
-#pragma unroll 2
-                for (int j = 0; j <= DEC_ROUND / 2; j++) {
+            if (__ballot(mine > 0)) {
+                // rising and falling edges in alternating steps (a listener whose first edge is a falling one sits out the
+                // first rising step): no step selects a polarity
+                cw::EdgeRec next_r = E[max(-shift, 0)][lane].rec, next_f = E[1 - shift][lane].rec;
+                uint32_t next_pr = P[max(1 - shift, 0)][lane], next_pf = P[2 - shift][lane];
+#pragma unroll 1
+                for (int j = 0; j <= DEC_ROUND / 2; j++) {  // (unrolled twice the character wave spills)
                     const int kr = 2 * j - shift, kf = kr + 1;
-                    uint32_t key_edge, key_abort;
+                    const cw::EdgeRec rec_r = next_r, rec_f = next_f;
+                    const uint32_t pos_r = next_pr, pos_f = next_pf;
+                    // (the next step's, on their way while this one computes; past the round's end: never used)
+                    next_r = E[min(kr + 2, DEC_ROUND - 1)][lane].rec;
+                    next_f = E[min(kf + 2, DEC_ROUND - 1)][lane].rec;
+                    next_pr = P[min(kr + 3, DEC_POS_ROWS - 1)][lane];
+                    next_pf = P[min(kf + 3, DEC_POS_ROWS - 1)][lane];
+                    uint32_t key_edge;
                     bool space;
                     if (kr >= 0 && kr < mine) {
-                        const cw::EdgeRec rec = E[kr][lane].rec;
-                        const uint32_t frame = g.frame_base + P[kr + 1][lane];
-                        cw::assemble_edge(dec, true, rec, (rec.flags & cw::ER_ABORT) != 0, &key_edge, &space, &key_abort);
-                        sink.put_if(key_edge != 0, key_edge, frame);
-                        sink.put_if(space, cw::kSpaceKey, frame);
-                        sink.put_if(key_abort != 0, key_abort, frame + 1u + rec.abort_at);
-                        pend = rec.flags & cw::ER_ABORT_NEXT;
-                        pend_at = rec.rise.abort_next_at;
+                        cw::assemble_edge(dec, true, rec_r, &key_edge, &space);
+                        const uint32_t key_abort = cw::assemble_abort(dec, (rec_r.flags & cw::ER_ABORT) != 0);
+                        E[kr][lane].events = cw::edge_events(key_edge, space, key_abort, g.frame_base + pos_r, rec_r.abort_at);
+                        pend = rec_r.flags & cw::ER_ABORT_NEXT;
+                        pend_at = rec_r.rise.abort_next_at;
                     }
                     if (kf < mine) {
-                        const cw::EdgeRec rec = E[kf][lane].rec;
-                        const uint32_t frame = g.frame_base + P[kf + 1][lane];
-                        cw::assemble_edge(dec, false, rec, pend, &key_edge, &space, &key_abort);
-                        sink.put_if(key_edge != 0, key_edge, frame);
-                        sink.put_if(key_abort != 0, key_abort, frame + 1u + pend_at);
+                        cw::assemble_edge(dec, false, rec_f, &key_edge, &space);
+                        const uint32_t key_abort = cw::assemble_abort(dec, pend);
+                        E[kf][lane].events = cw::edge_events(key_edge, false, key_abort, g.frame_base + pos_f, pend_at);
                     }
                 }
-        } else if (helper >= 0 && t >= 1 && t - 1 < rounds) {
+            }
+        } else if (helper >= 0) {
             // ---- stage B, round t - 1
-            const int rb = t - 1, k0 = rb * DEC_ROUND;
-            const auto &P = s_pos[rb & 3];
-            auto &E = s_edge[rb % 3];
-            for (int it = helper; it < DEC_ROUND * DEC_GROUP; it += N_HELPERS) {
-                const int kk = it / DEC_GROUP, li = it - kk * DEC_GROUP, k = k0 + kk;
-                const DecodeLocal &L = s_loc[li];
-                if (k >= L.n_edges)
-                    continue;
-                const int p_prev = (int)P[kk][li], p = (int)P[kk + 1][li], p1 = (int)P[kk + 2][li], p2 = (int)P[kk + 3][li];
-                const double now = L.t0 + (double)(p - L.first + 1);
-                const double duration = now - (k ? L.t0 + (double)(p_prev - L.first + 1) : L.start0);
-                const double low = E[kk][li].chain.low, high = E[kk][li].chain.high;
-                cw::EdgeRec rec;
-                if ((L.state0 ^ (k & 1)) != 0)
-                    rec = cw::classify_rising(duration, low, high, now, p1 - p - 1, L.t0 + (double)(p1 - L.first + 1), k + 1 < L.n_edges ? p2 - p1 - 1 : -1,
-                                              L.abort_dits);
-                else
-                    rec = cw::classify_falling(L.tick_seconds, duration, low, high);
-                E[kk][li].rec = rec;
+            const int rb = t - 1;
+            if (rb >= 0 && rb < rounds) {
+                const int k0 = rb * DEC_ROUND;
+                const auto &P = s_pos[rb & 3];
+                const auto &T = s_now[rb % 3];
+                auto &E = s_edge[rb & 3];
+                for (int it = helper; it < DEC_ROUND * DEC_GROUP; it += N_HELPERS) {
+                    const int kk = it / DEC_GROUP, li = it - kk * DEC_GROUP, k = k0 + kk;
+                    const DecodeLocal &L = s_loc[li];
+                    if (k >= L.n_edges)
+                        continue;
+                    const int p = (int)P[kk + 1][li], p1 = (int)P[kk + 2][li], p2 = (int)P[kk + 3][li];
+                    const double now = T[kk + 1][li];
+                    const double duration = now - (k ? T[kk][li] : L.start0);
+                    const double low = E[kk][li].chain.low, high = E[kk][li].chain.high;
+                    cw::EdgeRec rec;
+                    if ((L.state0 ^ (k & 1)) != 0)
+                        rec = cw::classify_rising(duration, low, high, now, p1 - p - 1, T[kk + 2][li], k + 1 < L.n_edges ? p2 - p1 - 1 : -1, L.abort_dits);
+                    else
+                        rec = cw::classify_falling(L.tick_seconds, duration, low, high);
+                    E[kk][li].rec = rec;
+                }
+            }
+            // ---- stage D, round t - 3: a lane per edge, the edges' runes and frames to the text buffer in their order
+            const int rd = t - 3;
+            if (rd >= 0 && rd < rounds) {
+                const auto &E = s_edge[rd & 3];
+#pragma unroll
+                for (int n = 0; n < D_PER_WAVE; n++) {
+                    const int li = d_listener(n), kk = lane & 31;
+                    cw::EdgeEvents ev{0u, 0u, 0u, 0u};
+                    if (li >= 0 && rd * DEC_ROUND + kk < s_loc[li].n_edges)
+                        ev = E[kk][li].events;
+                    const uint32_t key_edge = ev.keys & 0xFFFFu, key_abort = ev.keys >> 16;
+                    const int cnt = (key_edge ? 1 : 0) + (ev.space ? 1 : 0) + (key_abort ? 1 : 0);
+                    if (!__ballot(cnt != 0))
+                        continue;
+                    int incl = cnt;
+#pragma unroll
+                    for (int d = 1; d < 32; d <<= 1) {
+                        const int v = __shfl_up(incl, d, 32);
+                        if (kk >= d)
+                            incl += v;
+                    }
+                    const uint32_t total = (uint32_t)__shfl(incl, 31, 32), cap = (uint32_t)g.text_cap;
+                    uint32_t at = text_at[n] + (uint32_t)(incl - cnt);
+                    if (li >= 0) {
+                        uint32_t *buf = text + (size_t)(group0 + li) * g.text_cap, *frm = text_frames + (size_t)(group0 + li) * g.text_cap;
+                        if (key_edge && at < cap) {
+                            buf[at] = cw::key_to_rune(key_edge, morse);
+                            frm[at] = ev.frame;
+                        }
+                        at += key_edge ? 1u : 0u;
+                        if (ev.space && at < cap) {
+                            buf[at] = ' ';
+                            frm[at] = ev.frame;
+                        }
+                        at += ev.space ? 1u : 0u;
+                        if (key_abort && at < cap) {
+                            buf[at] = cw::key_to_rune(key_abort, morse);
+                            frm[at] = ev.abort_frame;
+                        }
+                    }
+                    const uint32_t room = cap - min(text_at[n], cap);
+                    text_cap_hit[n] += total > room ? total - room : 0u;
+                    text_at[n] += min(total, room);
+                }
             }
         }
         if (fetch)
@@ -485,21 +585,34 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void k_listen_decode(ListenerSlot *
         SDR_DEC_TICK(3);
     }
 
-    // ---- the decoder's state behind the batch; the batch's text: table keys -> runes
+    // ---- the decoder's state and the text buffer's fill behind the batch
     if (on && wave_a) {
-        cw::chain_store(chain, dec);
-        slot->dec.onThreshold = dec.onThreshold;
-        slot->dec.offThreshold = dec.offThreshold;
-        slot->dec.onStart = dec.onStart;
-        slot->dec.offStart = dec.offStart;
-        slot->dec.ticks = loc.t0 + (double)(loc.end - loc.first);
-        if (loc.n_edges)
-            slot->dec.lastState = loc.state0 ^ ((loc.n_edges - 1) & 1);
-        // Frame numbers are 32 bits and compared as differences: a listener that has started must not keep a start_frame
-        // that falls 2^31 frames behind (config 5 gets there in 100 days and a decode-mode listener has no time-out) - the
-        // difference would turn positive and the listener go deaf.  Once a batch has reached the listener's first frame,
-        // both marks move along with the batches (nothing per listener depends on the absolute number after that).
-        slot->start_frame = slot->tapped_from = g.frame_base + (uint32_t)n_frames;
+        // (nobody else touches this threshold: what the chain does not hold of it - preset, upperBound, a square root that
+        // did not move - is read back rather than kept in registers across the rounds)
+        cw::AdaptiveThreshold th = wave_ar ? slot->dec.offThreshold : slot->dec.onThreshold;
+        th.low = t_low;
+        th.high = t_high;
+        th.last = t_last;
+        if (t_moved)
+            cw::at_update(th);  // updateThreshold :413-416
+        if (wave_ar) {
+            slot->dec.offThreshold = th;
+            if (any_mine)
+                slot->dec.onStart = last_now;  // :223
+            slot->dec.ticks = loc.t0 + (double)(loc.end - loc.first);
+            if (loc.n_edges)
+                slot->dec.lastState = loc.state0 ^ ((loc.n_edges - 1) & 1);
+            // Frame numbers are 32 bits and compared as differences: a listener that has started must not keep a
+            // start_frame that falls 2^31 frames behind (config 5 gets there in 100 days and a decode-mode listener has no
+            // time-out) - the difference would turn positive and the listener go deaf.  Once a batch has reached the
+            // listener's first frame, both marks move along with the batches (nothing per listener depends on the
+            // absolute number after that).
+            slot->start_frame = slot->tapped_from = g.frame_base + (uint32_t)n_frames;
+        } else {
+            slot->dec.onThreshold = th;
+            if (any_mine)
+                slot->dec.offStart = last_now;  // :231
+        }
     }
     if (on && wave_c) {
         slot->dec.decoding = dec.decoding;
@@ -507,23 +620,21 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void k_listen_decode(ListenerSlot *
         slot->dec.charLen = dec.charLen;
         slot->dec.charBits = dec.charBits;
         slot->dec.wpm = dec.wpm;
-        slot->text_count = sink.count;
-        if (sink.dropped != slot->text_dropped)
-            atomicAdd(&drops->runes, (unsigned long long)(sink.dropped - slot->text_dropped));
-        slot->text_dropped = sink.dropped;
-        s_loc[lane].text_from = loc.text_from;
-        s_loc[lane].text_to = sink.count;
     }
-    __syncthreads();
-    for (int li = 0; li < DEC_GROUP; li++) {
-        if (s_loc[li].n_edges < 0)
-            continue;
-        uint32_t *buf = text + (size_t)(group0 + li) * g.text_cap;
-        for (uint32_t e = s_loc[li].text_from + threadIdx.x; e < s_loc[li].text_to; e += blockDim.x)
-            buf[e] = cw::key_to_rune(buf[e], morse);
+#pragma unroll
+    for (int n = 0; n < D_PER_WAVE; n++) {
+        const int li = d_listener(n);
+        if (li >= 0 && (lane & 31) == 0) {
+            ListenerSlot *sl = &slots[group0 + li];
+            sl->text_count = text_at[n];
+            if (text_cap_hit[n]) {  // nothing is lost silently: counted per listener and bank-wide
+                sl->text_dropped += text_cap_hit[n];
+                atomicAdd(&drops->runes, (unsigned long long)text_cap_hit[n]);
+            }
+        }
     }
 #if defined(SDR_DEC_CLOCK)
-    if (blockIdx.x == 0 && lane == 0 && wave < 4)  // (tools only: shader cycles of the chain wave, the character wave and two helpers)
+    if (blockIdx.x == 0 && lane == 0 && wave < 4)  // (tools only: shader cycles of the chain waves, the character wave and a helper)
         printf("decode clocks wave %d: stage0 %llu setup %llu work %llu wait %llu rounds %d\n", wave, ck[0], ck[1], ck[2], ck[3], rounds);
 #endif
 }

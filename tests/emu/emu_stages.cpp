@@ -84,7 +84,7 @@ static std::vector<uint8_t> make_stream(int ticks, int kind)
 
 // One batch through the stages.  raw: the batch's raw states, one per frame; first: the listener's first frame in it.
 static void staged_batch(cw::Debouncer &deb, cw::DecoderState &dec, const std::vector<uint8_t> &raw, int first, uint32_t frame_base,
-                         const uint16_t *table, std::vector<uint64_t> &eff_words, std::vector<Edge> &edges, std::vector<Rec> &runes)
+                         const uint16_t *table, std::vector<uint64_t> &eff_words, std::vector<Edge> &edges, std::vector<Rec> &runes, bool split_chains)
 {
     const int n = (int)raw.size(), n_words = (n + 63) / 64;
     const cw::TickSpan span{first < n ? first : n, n};
@@ -152,12 +152,33 @@ static void staged_batch(cw::Debouncer &deb, cw::DecoderState &dec, const std::v
     auto now_of = [&](int k) { return t0 + (double)((int)pos[(size_t)k] - span.first + 1); };
     auto run_behind = [&](int k) { return (k + 1 < n_edges ? (int)pos[(size_t)k + 1] : span.end) - (int)pos[(size_t)k] - 1; };
 
-    // ---- stage A
+    // ---- stage A: the gap threshold's chain over the rising edges, the mark threshold's over the falling ones (the
+    // kernel runs the two on two waves; even streams go through chain_edge instead: one walk over all edges, the same bits)
     cw::Chain chain = cw::chain_load(dec);
     const double start0 = state0 ? chain.off_start : chain.on_start;
     std::vector<double> lows((size_t)n_edges), highs((size_t)n_edges);
-    for (int k = 0; k < n_edges; k++)
-        cw::chain_edge(chain, (state0 ^ (k & 1)) != 0, now_of(k), &lows[(size_t)k], &highs[(size_t)k]);
+    if (split_chains) {
+        for (int pol = 1; pol >= 0; pol--)  // rising first, then falling: neither reads what the other writes
+            for (int k = 0; k < n_edges; k++) {
+                if (((state0 ^ (k & 1)) != 0) != (pol != 0))
+                    continue;
+                const double duration = now_of(k) - (k ? now_of(k - 1) : start0);
+                if (pol) {
+                    chain.off_moved = cw::chain_step(chain.off_low, chain.off_high, chain.off_last, chain.off_bound, duration) || chain.off_moved;
+                    chain.on_start = now_of(k);
+                    lows[(size_t)k] = chain.off_low;
+                    highs[(size_t)k] = chain.off_high;
+                } else {
+                    chain.on_moved = cw::chain_step(chain.on_low, chain.on_high, chain.on_last, chain.on_bound, duration) || chain.on_moved;
+                    chain.off_start = now_of(k);
+                    lows[(size_t)k] = chain.on_low;
+                    highs[(size_t)k] = chain.on_high;
+                }
+            }
+    } else {
+        for (int k = 0; k < n_edges; k++)
+            cw::chain_edge(chain, (state0 ^ (k & 1)) != 0, now_of(k), &lows[(size_t)k], &highs[(size_t)k]);
+    }
     // ---- stage B
     std::vector<cw::EdgeRec> recs((size_t)n_edges);
     for (int k = 0; k < n_edges; k++) {
@@ -179,15 +200,17 @@ static void staged_batch(cw::Debouncer &deb, cw::DecoderState &dec, const std::v
         const cw::EdgeRec &r = recs[(size_t)k];
         const bool rising = r.flags & cw::ER_STATE;
         const uint32_t frame = frame_base + pos[(size_t)k], at = rising ? r.abort_at : pend_at;
-        uint32_t key_edge, key_abort;
+        uint32_t key_edge;
         bool space;
-        cw::assemble_edge(dec, rising, r, rising ? (r.flags & cw::ER_ABORT) != 0 : pend, &key_edge, &space, &key_abort);
-        if (key_edge)
-            emit(key_edge, frame);
-        if (space)
-            emit(cw::kSpaceKey, frame);
-        if (key_abort)
-            emit(key_abort, frame + 1u + at);
+        cw::assemble_edge(dec, rising, r, &key_edge, &space);
+        const uint32_t key_abort = cw::assemble_abort(dec, rising ? (r.flags & cw::ER_ABORT) != 0 : pend);
+        const cw::EdgeEvents ev = cw::edge_events(key_edge, space, key_abort, frame, at);
+        if (ev.keys & 0xFFFFu)
+            emit(ev.keys & 0xFFFFu, ev.frame);
+        if (ev.space)
+            emit(cw::kSpaceKey, ev.frame);
+        if (ev.keys >> 16)
+            emit(ev.keys >> 16, ev.abort_frame);
         if (rising) {
             pend = r.flags & cw::ER_ABORT_NEXT;
             pend_at = r.rise.abort_next_at;
@@ -243,7 +266,7 @@ int main()
             std::vector<uint64_t> eff;
             std::vector<Edge> edges;
             std::vector<Rec> runes;
-            staged_batch(sdeb, sdec, raw, first, (uint32_t)at, table, eff, edges, runes);
+            staged_batch(sdeb, sdec, raw, first, (uint32_t)at, table, eff, edges, runes, ((it >> 2) & 1) != 0);
             bool bad = false;
             if (eff != ref_eff) {
                 if (mismatches < 8)
