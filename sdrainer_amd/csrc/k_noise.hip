@@ -802,24 +802,26 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_noise_stats(const float *__re
 // ---------------------------------------------------------------------------------------------
 // k_thresholds — RollingMean.Put x2 per frame (dsp/dsp.go:257-268, rx/receiver.go:383-385) in frame
 // order.  The value leaving the 60-frame window at frame f is the input of frame f-60 (or the ring
-// carried over from the previous batch), so only the two float32 running sums form a serial chain:
-// lanes 0 and 1 of wave 0 run them side by side, everything else is data-parallel.
+// carried over from the previous batch), so only the two float32 running sums form a serial chain - two
+// dependent additions per frame: lanes 0 and 1 of wave 0 run them side by side, chunk after chunk without a
+// pause, while the other waves fetch the next chunk's inputs and turn the previous chunk's sums into
+// thresholds (one barrier per chunk; round 4: 0.127 -> see DESIGN.md, the chain used to wait for both).
 // ---------------------------------------------------------------------------------------------
 #ifndef SDR_THR_CHUNK
 #define SDR_THR_CHUNK 1024
 #endif
 constexpr int THR_CHUNK = SDR_THR_CHUNK;
+static_assert(THR_CHUNK % 8 == 0, "the chain walks eight frames at a time");
 
 __global__ __launch_bounds__(256) void k_thresholds(sdr_frame_rec *__restrict__ recs, BandState *__restrict__ st,
                                                     int n_frames, int stride)
 {
-    __shared__ float s_in[2][THR_CHUNK];
-    __shared__ float s_old[2][THR_CHUNK];
-    __shared__ float s_sum[2][THR_CHUNK];
+    __shared__ __attribute__((aligned(16))) float s_in[2][2][THR_CHUNK];   // [buffer][nf / dev][frame of the chunk]
+    __shared__ __attribute__((aligned(16))) float s_old[2][2][THR_CHUNK];
+    __shared__ __attribute__((aligned(16))) float s_sum[2][2][THR_CHUNK];
     __shared__ float s_ring[2][SDR_NOISE_WINDOW];
-    __shared__ float s_carry[2];
     const int band = blockIdx.x;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6;
     BandState *s = &st[band];
     sdr_frame_rec *r = recs + (size_t)band * stride;
     const int next0 = s->next;
@@ -828,48 +830,94 @@ __global__ __launch_bounds__(256) void k_thresholds(sdr_frame_rec *__restrict__ 
         s_ring[0][tid] = s->nf_ring[tid];
         s_ring[1][tid] = s->dev_ring[tid];
     }
-    if (tid == 0) {
-        s_carry[0] = s->nf_sum;
-        s_carry[1] = s->dev_sum;
-    }
+    float sum = 0.f;  // (lanes 0 and 1 of wave 0: the chains)
+    if (tid < 2)
+        sum = tid ? s->dev_sum : s->nf_sum;
     __syncthreads();
-
-    for (int base = 0; base < n_frames; base += THR_CHUNK) {
-        const int cnt = min(THR_CHUNK, n_frames - base);
-        for (int j = tid; j < cnt; j += blockDim.x) {
+    const int n_chunks = (n_frames + THR_CHUNK - 1) / THR_CHUNK;
+    const int helpers = (int)blockDim.x - 64, hid = tid - 64;
+    // chunk c's inputs and the values that leave the window at its frames (terms past the batch's end: zeros, never used)
+    auto load_chunk = [&](int c, int first, int step) {
+        const int base = c * THR_CHUNK;
+        for (int j = first; j < THR_CHUNK; j += step) {
             const int f = base + j;
-            s_in[0][j] = r[f].nf_in;
-            s_in[1][j] = r[f].dev_in;
-            if (f >= SDR_NOISE_WINDOW) {
-                s_old[0][j] = r[f - SDR_NOISE_WINDOW].nf_in;
-                s_old[1][j] = r[f - SDR_NOISE_WINDOW].dev_in;
-            } else {
-                const int slot = (next0 + f) % SDR_NOISE_WINDOW;
-                s_old[0][j] = s_ring[0][slot];
-                s_old[1][j] = s_ring[1][slot];
+            float in0 = 0.f, in1 = 0.f, old0 = 0.f, old1 = 0.f;
+            if (f < n_frames) {
+                in0 = r[f].nf_in;
+                in1 = r[f].dev_in;
+                if (f >= SDR_NOISE_WINDOW) {
+                    old0 = r[f - SDR_NOISE_WINDOW].nf_in;
+                    old1 = r[f - SDR_NOISE_WINDOW].dev_in;
+                } else {
+                    const int slot = (next0 + f) % SDR_NOISE_WINDOW;
+                    old0 = s_ring[0][slot];
+                    old1 = s_ring[1][slot];
+                }
             }
+            s_in[c & 1][0][j] = in0;
+            s_in[c & 1][1][j] = in1;
+            s_old[c & 1][0][j] = old0;
+            s_old[c & 1][1][j] = old1;
         }
-        __syncthreads();
-        if (tid < 2) {
-            float sum = s_carry[tid];
-            const float *in = s_in[tid], *old = s_old[tid];
-            float *out = s_sum[tid];
-            for (int j = 0; j < cnt; j++) {
-                sum = sum - old[j];  // v.sumForMean -= v.values[v.next]
-                sum = sum + in[j];   // v.sumForMean += v.values[v.next]
-                out[j] = sum;
-            }
-            s_carry[tid] = sum;
-        }
-        __syncthreads();
-        for (int j = tid; j < cnt; j += blockDim.x) {
+    };
+    auto finish_chunk = [&](int c, int first, int step) {
+        const int base = c * THR_CHUNK, cnt = min(THR_CHUNK, n_frames - base);
+        for (int j = first; j < cnt; j += step) {
             const int f = base + j;
-            const float noiseFloor = __fdiv_rn(s_sum[0][j], (float)SDR_NOISE_WINDOW);
-            const float noiseDeviation = __fdiv_rn(s_sum[1][j], (float)SDR_NOISE_WINDOW);
+            const float noiseFloor = __fdiv_rn(s_sum[c & 1][0][j], (float)SDR_NOISE_WINDOW);
+            const float noiseDeviation = __fdiv_rn(s_sum[c & 1][1][j], (float)SDR_NOISE_WINDOW);
             r[f].noise_floor = noiseFloor;
             r[f].noise_dev = noiseDeviation;
-            r[f].peak_thr = peak_threshold + noiseFloor;  // rx/receiver.go:385
+            r[f].peak_thr = peak_threshold + noiseFloor;    // rx/receiver.go:385
             r[f].listen_thr = noiseFloor + noiseDeviation;  // rx/receiver.go:394
+        }
+    };
+    if (n_chunks > 0)
+        load_chunk(0, tid, (int)blockDim.x);
+    __syncthreads();
+    for (int c = 0; c <= n_chunks; c++) {
+        if (wave == 0) {
+            if (tid < 2 && c < n_chunks) {
+                // eight frames at a time, the next eight's operands on their way while these are added
+                const int cnt = min(THR_CHUNK, n_frames - c * THR_CHUNK);
+                const float4 *in = reinterpret_cast<const float4 *>(s_in[c & 1][tid]);
+                const float4 *old = reinterpret_cast<const float4 *>(s_old[c & 1][tid]);
+                float4 *out = reinterpret_cast<float4 *>(s_sum[c & 1][tid]);
+                float4 i0 = in[0], i1 = in[1], o0 = old[0], o1 = old[1];
+                const int groups = cnt / 8;
+                for (int q = 0; q < groups; q++) {
+                    const float4 a0 = i0, a1 = i1, b0 = o0, b1 = o1;
+                    const int qn = min(q + 1, THR_CHUNK / 8 - 1);
+                    i0 = in[2 * qn];
+                    i1 = in[2 * qn + 1];
+                    o0 = old[2 * qn];
+                    o1 = old[2 * qn + 1];
+                    float4 r0, r1;
+#define SDR_THR_PUT(dst, o, i)                              \
+    sum = sum - (o); /* v.sumForMean -= v.values[v.next] */ \
+    sum = sum + (i); /* v.sumForMean += v.values[v.next] */ \
+    dst = sum
+                    SDR_THR_PUT(r0.x, b0.x, a0.x);
+                    SDR_THR_PUT(r0.y, b0.y, a0.y);
+                    SDR_THR_PUT(r0.z, b0.z, a0.z);
+                    SDR_THR_PUT(r0.w, b0.w, a0.w);
+                    SDR_THR_PUT(r1.x, b1.x, a1.x);
+                    SDR_THR_PUT(r1.y, b1.y, a1.y);
+                    SDR_THR_PUT(r1.z, b1.z, a1.z);
+                    SDR_THR_PUT(r1.w, b1.w, a1.w);
+                    out[2 * q] = r0;
+                    out[2 * q + 1] = r1;
+                }
+                for (int j = groups * 8; j < cnt; j++) {  // (the batch's last frames, fewer than eight)
+                    SDR_THR_PUT(s_sum[c & 1][tid][j], s_old[c & 1][tid][j], s_in[c & 1][tid][j]);
+                }
+#undef SDR_THR_PUT
+            }
+        } else {
+            if (c >= 1)
+                finish_chunk(c - 1, hid, helpers);
+            if (c + 1 < n_chunks)
+                load_chunk(c + 1, hid, helpers);
         }
         __syncthreads();
     }
@@ -883,11 +931,12 @@ __global__ __launch_bounds__(256) void k_thresholds(sdr_frame_rec *__restrict__ 
             s->dev_ring[tid] = r[f].dev_in;
         }
     }
-    if (tid == 0) {
-        s->nf_sum = s_carry[0];
-        s->dev_sum = s_carry[1];
+    if (tid == 0)
+        s->nf_sum = sum;
+    if (tid == 1)
+        s->dev_sum = sum;
+    if (tid == 0)
         s->next = (next0 + n_frames) % SDR_NOISE_WINDOW;
-    }
 }
 
 
