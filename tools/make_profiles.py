@@ -91,7 +91,7 @@ copies = [("bench_full.json", f"{tag}_bench_{key}.json"), ("bench_serial.err", f
           ("fft_phases.txt", f"{tag}_fft_phase_order.txt"), ("tool_manifest.txt", f"{tag}_tool_manifest.txt"),
           ("host_input_rate.txt", f"{tag}_host_input_rate.txt"), ("strain_e2e.json", f"{tag}_strain_e2e.json"),
           ("mfma_f64.txt", f"{tag}_mfma_f64_probe.txt"), ("cu_time.txt", f"{tag}_cu_time_per_kernel.txt"),
-          ("noise_trace.txt", f"{tag}_noise_consumer_trace.txt")]
+          ("noise_trace.txt", f"{tag}_noise_consumer_trace.txt"), ("decode_clocks.txt", f"{tag}_decode_stage_clocks.txt")]
 for src, dst in copies:
     s = os.path.join(G, src)
     if os.path.exists(s) and os.path.getsize(s) > 0:

@@ -72,5 +72,7 @@ timeout -k 10 300 python tools/strain_e2e.py > $O/strain_e2e.json 2>/dev/null ||
 timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1 || true
 [ -f tools/abl/libntrace.so ] && { SDR_HIP_LIB=$PWD/tools/abl/libntrace.so timeout -k 10 120 python tools/noise_trace.py > $O/noise_trace.txt 2>&1; SDR_VAR_MFMA=0 SDR_HIP_LIB=$PWD/tools/abl/libntrace.so timeout -k 10 120 python tools/noise_trace.py >> $O/noise_trace.txt 2>&1; } || true
 [ -x tools/bin/ubench_mfma_f64 ] && timeout -k 5 120 tools/bin/ubench_mfma_f64 > $O/mfma_f64.txt 2>&1 || true
+# k_listen_decode's stage clocks (tools/build_abl.sh decclk "-DSDR_DEC_CLOCK"): workgroup 0's chain waves (0, 2), character wave (1) and a helper (3)
+[ -f tools/abl/libdecclk.so ] && { for w in c3 c2; do echo "== $w"; SDR_HIP_LIB=$PWD/tools/abl/libdecclk.so timeout -k 10 120 python bench.py --workload $w --no-cpu-baseline --steps 6 --warmup 2 --serial 2>/dev/null | grep "decode clocks" | tail -4; done > $O/decode_clocks.txt; } || true
 echo "all done"
 tail -c 600 $O/bench_full.json
