@@ -68,7 +68,8 @@ for i in 1 2 3; do
   python bench.py --steps 498 --warmup 48 --no-cpu-baseline --graph > $O/bench_graph_c3_$i.json 2>/dev/null || true
 done
 python tools/host_input_rate.py > $O/host_input_rate.txt 2>&1 || true
-timeout -k 10 300 python tools/strain_e2e.py > $O/strain_e2e.json 2>/dev/null || true
+# (three fresh processes: the hunting phase is 11 ms long and one run in three has been seen to take twice that)
+for i in 1 2 3; do timeout -k 10 300 python tools/strain_e2e.py 2>/dev/null | tail -1; done > $O/strain_e2e.json || true
 timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1 || true
 [ -f tools/abl/libntrace.so ] && { SDR_HIP_LIB=$PWD/tools/abl/libntrace.so timeout -k 10 120 python tools/noise_trace.py > $O/noise_trace.txt 2>&1; SDR_VAR_MFMA=0 SDR_HIP_LIB=$PWD/tools/abl/libntrace.so timeout -k 10 120 python tools/noise_trace.py >> $O/noise_trace.txt 2>&1; } || true
 [ -x tools/bin/ubench_mfma_f64 ] && timeout -k 5 120 tools/bin/ubench_mfma_f64 > $O/mfma_f64.txt 2>&1 || true
