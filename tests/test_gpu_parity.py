@@ -252,6 +252,33 @@ def test_debounce_threshold_3(capi):
     bank.close()
 
 
+@pytest.mark.parametrize("debounce", [1, 2, 5, 9, 70])
+def test_debounce_thresholds_weak_signals_and_carry(capi, debounce):
+    """The debouncer per 64-tick word and the staged decoder (cw_stages.h) against the oracle's literal Debounce + Tick:
+    signals weak enough for the raw states to glitch, thresholds from the pass-through (1) to longer than a word (70),
+    four uneven batches, one of a single frame (the debouncer's count, the decoder's clocks and the current character are
+    carried)."""
+    n, rate, frames = 512, 48000, 700
+    iq, bins, _ = synth.make_band(frames, rate, n, 4, seed=77 + debounce, amplitude=synth.TONE_AMPLITUDE * 0.0027)
+    ref = orc.Receiver(rate, n, 70, 15.0, debounce)
+    bank = capi.Bank(rate, n, signal_debounce=debounce, max_batch_frames=512, max_listeners=4, trace=True)
+    for b in bins:
+        ref.attach(int(b))
+        bank.attach(0, int(b))
+    glitches = 0
+    for lo, hi in ((0, 130), (130, 131), (131, 517), (517, 700)):
+        out = ref.process(iq[lo:hi])
+        bank.process_host(iq[lo:hi])
+        for lid in range(4):
+            _, r, d = bank.read_trace(0, lid)
+            assert np.array_equal(r, out["raw"][:, lid]) and np.array_equal(d, out["deb"][:, lid]), (debounce, lo, lid)
+            glitches += int(np.count_nonzero(np.diff(out["raw"][:, lid].astype(np.int8))))
+    for lid in range(4):
+        assert bank.read_text(0, lid) == ref.text(lid)
+    assert glitches > 450  # (the raw states chatter - clean keying of these frames has about 240 transitions: that is what the test is for)
+    bank.close()
+
+
 def test_device_resident_input_and_profile(capi):
     """sdr_process_device: IQ already in HBM (torch tensor), run on torch's current stream."""
     import torch
