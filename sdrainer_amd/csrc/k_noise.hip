@@ -33,6 +33,12 @@ constexpr int MAX_WAVES = 16;  // a workgroup is 1024 threads: one to four chain
 #define SDR_WM_GROUPS 4
 #endif
 constexpr int WM_GROUPS = SDR_WM_GROUPS;
+// ... and HALF-SIZE workgroups (two groups, eight waves, 70 KB of LDS) where the FFT kernel's workgroups are not whole
+// CUs (block sizes up to 8192: 512 threads, two to a CU): a 1024-thread workgroup then waits for a CU that BOTH of its
+// FFT workgroups have left, a half-size one slots in beside one of them.  Config 5's share (8 bands x 8192), one box,
+// interleaved twice: 191.8 / 192.7 GS/s against 186.2 / 187.0 (graph-captured 190.3 / 188.8 against 184.0 / 184.1);
+// config 3, whose FFT workgroups ARE whole CUs, 167.2 / 167.9 against 167.2 / 168.2 - there the note above still holds.
+constexpr int WM_GROUPS_HALF = 2;
 // Variance chains (SDR_VAR_MFMA=0, the default from round 4 on): TWO chain groups of eight waves per workgroup, vector-ALU
 // consumers that square for themselves (chain_consumer<VAR>).  Round 3 ran them on the float64 matrix pipe, one group of
 // 64 chains per workgroup over four consumer waves: 5.4 clocks per term for ONE wave alone on a CU (tools/ubench_mfma_f64)
@@ -48,10 +54,11 @@ constexpr int NS_GROUPS_VALU = 2;
 constexpr int CHAIN_THREADS = 64 * MAX_WAVES;
 // SLOTS = LDS tiles between producers and consumer: 4 float64 tiles (133 KB) for the long variance chains, 2 float32
 // tiles per group (4 x 35 KB) for the short window sums.
-template <int SLOTS, class T, int PAD_ = (sizeof(T) == 8 ? 2 : 4)>
+template <int SLOTS, class T, int PAD_ = (sizeof(T) == 8 ? 2 : 4), int TAG_ = 0>
 struct ChainShared {
     using term_t = T;
     static constexpr int RING_SLOTS = SLOTS;
+    static constexpr int TAG = TAG_;  // (tells rings of the same shape apart: each kernel's LDS holds only its own)
     // [slot][chain][column]; rows are 528 bytes apart (float64) / 272 bytes (float32): 16-byte aligned for the
     // consumer's ds_read_b128, and the sixteen lanes one LDS cycle serves start on sixteen different 16-byte bank
     // groups, so neither side has bank conflicts.  (The variance ring's rows are 264 bytes apart: its consumers read
@@ -67,6 +74,7 @@ struct ChainShared {
     double chain_sum[TILE];                   // ... and where they leave their chains' sums
 };
 using WindowRing = ChainShared<2, float>;
+using WindowRingHalf = ChainShared<2, float, 4, 1>;  // the half-size window-sum workgroups' (two of them instead of four)
 using VarianceRing = ChainShared<6, float, 2>;  // (matrix-pipe variant)
 using NoiseRing = ChainShared<4, float>;        // variance chains on the vector ALU: two groups x four float32 tiles
 
@@ -81,12 +89,15 @@ extern "C" __attribute__((visibility("default"))) int sdr_debug_noise_trace(unsi
 
 // The rings live at file scope so that the consumer can be a function of its own (see chain_consumer).
 __shared__ WindowRing g_ring_wm[WM_GROUPS];
+__shared__ WindowRingHalf g_ring_wm_half[WM_GROUPS_HALF];
 __shared__ VarianceRing g_ring_ns[1];
 __shared__ NoiseRing g_ring_var[NS_GROUPS_VALU];
 template <class Shared>
 __device__ __forceinline__ Shared &ring(int group)
 {
-    if constexpr (Shared::RING_SLOTS == WindowRing::RING_SLOTS)
+    if constexpr (Shared::RING_SLOTS == WindowRing::RING_SLOTS && Shared::TAG == 1)
+        return g_ring_wm_half[group];
+    else if constexpr (Shared::RING_SLOTS == WindowRing::RING_SLOTS)
         return g_ring_wm[group];
     else if constexpr (Shared::RING_SLOTS == VarianceRing::RING_SLOTS)
         return g_ring_ns[group];
@@ -405,13 +416,13 @@ __device__ __attribute__((noinline)) double chain_consumer(int n_tiles_any_lane,
 // Runs 64 chains (lane i of wave 0 owns chain i).  `my_terms` / `my_mean` are the consumer lane's chain
 // length and mean; returns the chain's sum in the consumer lanes.  All waits are on waves of the same
 // workgroup (co-resident by construction), so every spin terminates.
-template <bool VARIANCE, int GROUPS, class Shared>
+template <bool VARIANCE, int GROUPS, class Shared, int WAVES = MAX_WAVES>
 __device__ __forceinline__ double chain_run(Shared &sh, int group, int wig, const float *__restrict__ base,
                                             size_t row_stride, int rows, int n_cols, int my_terms, double my_mean)
 {
     // `group` = which of the workgroup's chain groups this wave belongs to (sh is that group's ring), `wig` = the
     // wave's index in the group, wave-uniform both; wave 0 of a group is its consumer.
-    constexpr int N_PRODUCERS = MAX_WAVES / GROUPS - 1;
+    constexpr int N_PRODUCERS = WAVES / GROUPS - 1;
     const int lane = threadIdx.x & 63;
     // HW_REG_HW_ID bits 5:4 = SIMD this wave runs on.  The consumer's additions are a pure latency chain;
     // a producer on the same SIMD puts its float64 instructions between them (measured: 13.5 instead of
@@ -706,19 +717,20 @@ __device__ __forceinline__ double variance_run(int wave, const float *__restrict
 // pass 1: mean of window w of frame f = sequential float64 sum of psd[edge + w*W .. +W) / W (:239-241,:230).
 // A workgroup walks `windows_per_block` windows of its 64 frames back to back: with many bands there are
 // thousands of (frame group, window) chains, and one long-lived workgroup per CU beats ten short ones.
-__global__ __launch_bounds__(CHAIN_THREADS) void k_window_means(const float *__restrict__ psd,
+template <int GROUPS, class Ring>
+__global__ __launch_bounds__(64 * (MAX_WAVES / WM_GROUPS) * GROUPS) void k_window_means(const float *__restrict__ psd,
                                                                 double *__restrict__ win_mean, NoiseGeom g,
                                                                 int n_frames, int stride, int windows_per_block)
 {
-    constexpr int WPG = MAX_WAVES / WM_GROUPS;
+    constexpr int WPG = MAX_WAVES / WM_GROUPS, WAVES = WPG * GROUPS;  // four waves per group either way
     // (readfirstlane: the role split in chain_run becomes scalar branches instead of exec-masked regions)
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int group = wave / WPG;
     // group k's consumer is its wave k, so that the consumers of a workgroup sit on different SIMDs (waves are dealt
     // to SIMDs round-robin; chain_run asks the hardware where each one landed anyway)
     const int wig = (wave - group * WPG - group + WPG) % WPG;
-    WindowRing &sh = ring<WindowRing>(group);
-    const int f0 = (blockIdx.x * WM_GROUPS + group) * TILE, band = blockIdx.z;
+    Ring &sh = ring<Ring>(group);
+    const int f0 = (blockIdx.x * GROUPS + group) * TILE, band = blockIdx.z;
     const int rows = max(0, min(TILE, n_frames - f0));  // (0: the odd group out at the end of a band sums nothing)
     const size_t frame0 = (size_t)band * stride + f0;
     const int w_end = min(g.n_windows, (int)(blockIdx.y + 1) * windows_per_block);
@@ -727,7 +739,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_window_means(const float *__r
 #endif
     for (int w = blockIdx.y * windows_per_block; w < w_end; w++) {
         const float *base = psd + frame0 * g.n + g.edge + (size_t)w * g.window;
-        const double sum = chain_run<false, WM_GROUPS>(sh, group, wig, base, g.n, rows, g.window, lane < rows ? g.window : 0, 0.0);
+        const double sum = chain_run<false, GROUPS, Ring, WAVES>(sh, group, wig, base, g.n, rows, g.window, lane < rows ? g.window : 0, 0.0);
         if (wig == 0 && lane < rows)
             win_mean[(frame0 + lane) * 10 + w] = sum / (double)g.window;
     }
@@ -1011,15 +1023,21 @@ hipError_t launch_window_means(const float *psd, double *win_mean, NoiseGeom g, 
     // per batch, 1 / 2 / 5 / 10 windows per workgroup 158.4 / 159.0 / 161.4 / 160.5 GS/s - fewer, longer-lived workgroups
     // hold less CU time, within the noise of a run; config 5's share, whose noise stream is the longest of its four,
     // 184.1 with one window against 174.2 with two.  One window stays.)
-    const int per_band = ((n_frames + TILE - 1) / TILE + WM_GROUPS - 1) / WM_GROUPS;
-    int wpb = (per_band * n_bands * g.n_windows) / 512;
+    const bool half = g.n <= 8192;  // the FFT kernel's workgroups are 512 threads or fewer: see WM_GROUPS_HALF
+    const int groups = half ? WM_GROUPS_HALF : WM_GROUPS;
+    const int per_band = ((n_frames + TILE - 1) / TILE + groups - 1) / groups;
+    int wpb = (per_band * n_bands * g.n_windows) / (512 * WM_GROUPS / groups);
     wpb = wpb < 1 ? 1 : (wpb > g.n_windows ? g.n_windows : wpb);
     static const int wpb_env = getenv("SDR_WM_WPB") ? atoi(getenv("SDR_WM_WPB")) : 0;  // (development)
     if (wpb_env > 0)
         wpb = wpb_env > g.n_windows ? g.n_windows : wpb_env;
 
-    launch_kernel(k_window_means, dim3(per_band, (g.n_windows + wpb - 1) / wpb, n_bands), dim3(CHAIN_THREADS), 0, stream, psd,
-                       win_mean, g, n_frames, stride, wpb);
+    const dim3 grid(per_band, (g.n_windows + wpb - 1) / wpb, n_bands);
+    if (half)
+        launch_kernel((k_window_means<WM_GROUPS_HALF, WindowRingHalf>), grid, dim3(64 * (MAX_WAVES / WM_GROUPS) * WM_GROUPS_HALF), 0, stream, psd, win_mean, g,
+                      n_frames, stride, wpb);
+    else
+        launch_kernel((k_window_means<WM_GROUPS, WindowRing>), grid, dim3(CHAIN_THREADS), 0, stream, psd, win_mean, g, n_frames, stride, wpb);
     return hipGetLastError();
 }
 
