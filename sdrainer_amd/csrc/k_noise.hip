@@ -38,6 +38,8 @@ constexpr int WM_GROUPS = SDR_WM_GROUPS;
 // FFT workgroups have left, a half-size one slots in beside one of them.  Config 5's share (8 bands x 8192), one box,
 // interleaved twice: 191.8 / 192.7 GS/s against 186.2 / 187.0 (graph-captured 190.3 / 188.8 against 184.0 / 184.1);
 // config 3, whose FFT workgroups ARE whole CUs, 167.2 / 167.9 against 167.2 / 168.2 - there the note above still holds.
+// (The variance chains the same way - one vector-ALU group of eight waves per 512-thread workgroup - were measured too and
+// are worse everywhere: config 5's share 181.5 against 186.3 with the matrix-pipe kernel, config 3 160.9 against 162.8.)
 constexpr int WM_GROUPS_HALF = 2;
 // Variance chains (SDR_VAR_MFMA=0, the default from round 4 on): TWO chain groups of eight waves per workgroup, vector-ALU
 // consumers that square for themselves (chain_consumer<VAR>).  Round 3 ran them on the float64 matrix pipe, one group of
