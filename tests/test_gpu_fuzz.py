@@ -3,6 +3,8 @@ signals, debounce threshold and cuts into batches (down to single frames) are dr
 bits, edges, decoder state, text and the peaks of every completed cumulation, bit for bit.  Complements the fixed cases of
 test_gpu_parity.py: the staged decoder, the cumulation's bound-and-refine path and the carried state all see shapes nobody
 picked by hand."""
+import os
+
 import numpy as np
 import pytest
 
@@ -24,7 +26,7 @@ def _bits_equal(a, b):
     return a.shape == b.shape and a.dtype == b.dtype and a.tobytes() == b.tobytes()
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SDR_FUZZ_SEEDS", "10"))))  # (a longer soak: SDR_FUZZ_SEEDS=300)
 def test_random_streams_and_cuts(capi, seed):
     rng = np.random.default_rng(4242 + seed)
     n = int(rng.choice([512, 1024, 2048]))
