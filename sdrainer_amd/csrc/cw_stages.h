@@ -17,7 +17,11 @@
 //     the dit / da / gap classification, the speed estimate's term (a division), the abort tick of the run behind the
 //     edge.  Stage B computes those for every edge independently (classify_rising / classify_falling).
 //   * What is left is the bookkeeping of the current character - append a symbol, take the character, write a rune -
-//     and the speed average: integer work and one add + one multiply per da, in edge order (stage C, assemble_edge).
+//     and the speed average.  The bookkeeping is not a chain either: every take empties the character whatever it
+//     held, so what an edge writes is a question about the events since the last take before it, and stage B has said
+//     which events happen - stage C answers it per edge with bit counting over a round's events (round_lane; the
+//     edge-after-edge form, assemble_edge, is kept: the CPU emulation runs both).  The speed average is one add and one
+//     multiply per da, in order: a loop over the round's das.
 // Before this split one lane walked all of it per edge: ~1 900 clocks per edge at config 3, ~530 edges per listener and
 // 8192-frame batch, 0.44 ms with 64 waves resident for that long.
 #pragma once
@@ -318,6 +322,131 @@ SDR_HD inline uint32_t assemble_abort(DecoderState &d, bool abort)
     }
     return key;
 }
+// ---------------------------------------------------------------------------------------------------------------
+// Stage C without a chain: the current character per ROUND of up to 32 edges, a lane per edge.
+// The character bookkeeping looks serial (append a symbol, take the character) but every take empties the character
+// whatever it held, so what an edge's character is made of is a question about the events between it and the last take
+// before it - and stage B has already said, per edge, which events happen: as bit masks over the round's edges (a wave's
+// ballots on the GPU) every lane answers it for its own edge with bit counting:
+//   * boundaries = takes (a rising edge's gap) and aborts (the run behind any edge); the symbols behind the last
+//     boundary form the segment; with `n` symbols in it so far the current character holds ((n - 1) mod 8) + 1 of them
+//     (appendSymbol's ninth-symbol rule, :308-310, restarts the count) - the carried character counts as symbols before
+//     the round's first edge while no boundary has been passed;
+//   * a boundary writes a character iff its segment is not empty; a symbol that finds eight writes those eight;
+//   * the character is invalid iff an over-long mark (:287-288) lies between the last WRITTEN character and this one
+//     (a take that finds nothing to write leaves the flag alone, :320-327);
+//   * its table key is made of the most recent symbols' da bits - the round's, then the carried ones.
+// Only the speed average (one add and one multiply per da, :291) stays a loop, over the round's das.
+// (tests/emu/emu_stages.cpp runs both forms - this one and assemble_edge's walk - against literal Tick calls.)
+// ---------------------------------------------------------------------------------------------------------------
+struct RoundMasks {  // bit k: edge k of the round
+    uint32_t take;     // rising edge with ER_TAKE
+    uint32_t abort;    // the abort check fires in the run behind the edge
+    uint32_t invalid;  // falling edge with ER_INVALID
+    uint32_t symbol;   // falling edge with ER_SYMBOL ...
+    uint32_t da;       // ... a da
+};
+struct CharCarry {  // Decoder.currentChar / currentCharInvalid between rounds
+    int32_t len;
+    uint32_t bits;
+    int32_t invalid;
+};
+SDR_HD inline uint32_t low_mask32(int n) { return n <= 0 ? 0u : n >= 32 ? ~0u : ((1u << n) - 1u); }
+SDR_HD inline uint32_t between32(int lo, int hi) { return low_mask32(hi) & ~low_mask32(lo); }  // bits lo .. hi - 1
+SDR_HD inline int top_bit32(uint32_t x)  // x != 0
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return 31 - __clz((int)x);
+#else
+    return 31 - __builtin_clz(x);
+#endif
+}
+SDR_HD inline int count_bits32(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popc(x);
+#else
+    return __builtin_popcount(x);
+#endif
+}
+SDR_HD inline int chunk_len(int n) { return n == 0 ? 0 : ((n - 1) & 7) + 1; }
+// the bits of the `len` most recent symbols: the round's (`symbols`: the segment's, up to the point in question), then
+// the carried ones; most recent symbol in bit 0, as charBits has it
+SDR_HD inline uint32_t chunk_bits(uint32_t symbols, uint32_t da, int len, const CharCarry &c)
+{
+    uint32_t bits = 0, r = symbols;
+    int got = 0;
+    while (got < len && r) {
+        const int b = top_bit32(r);
+        bits |= ((da >> b) & 1u) << got;
+        r &= ~(1u << b);
+        got++;
+    }
+    if (got < len)
+        bits |= (c.bits & ((1u << (len - got)) - 1u)) << got;
+    return bits;
+}
+struct RoundLane {  // what edge k contributes
+    uint32_t key_edge, key_abort;  // characters written at the edge's tick / at the abort's (0: none); WITHOUT the invalid flag
+    int n_after;                   // symbols in the segment behind the edge's own
+};
+// lane k, first pass: which characters the edge writes (the invalid flag needs everybody's answer first).  One table
+// key is formed in straight line - the common one: a rising edge's gap takes the character - the two rare ones (a ninth
+// symbol's, an abort's) behind a vote of the lanes.
+SDR_HD inline RoundLane round_lane(int k, bool rising, const RoundMasks &m, const CharCarry &c)
+{
+    const uint32_t boundaries = (m.take | m.abort) & low_mask32(k);
+    const int seg_lo = boundaries ? top_bit32(boundaries) + 1 : 0;
+    const uint32_t before = m.symbol & between32(seg_lo, k);
+    const int n_before = count_bits32(before) + (boundaries ? 0 : c.len);
+    const bool take = (m.take >> k) & 1u, abort = (m.abort >> k) & 1u;
+    const bool symbol = !rising && ((m.symbol >> k) & 1u);
+    RoundLane r{0u, 0u, n_before + (symbol ? 1 : 0)};
+    const bool gap_takes = rising && take && n_before > 0;
+    if (SDR_ANY_LANE(gap_takes)) {
+        const int len = chunk_len(n_before);
+        r.key_edge = gap_takes ? ((1u << len) | chunk_bits(before, m.da, len, c)) : 0u;
+    }
+    const bool ninth = symbol && chunk_len(n_before) == kMaxSymbolCount;  // appendSymbol :308-310
+    if (SDR_ANY_LANE(ninth))
+        r.key_edge = ninth ? ((1u << kMaxSymbolCount) | chunk_bits(before, m.da, kMaxSymbolCount, c)) : r.key_edge;
+    // the abort in the run behind the edge: behind a rising edge whose gap took the character there is nothing left
+    const bool aborts = abort && !(rising && take) && r.n_after > 0;
+    if (SDR_ANY_LANE(aborts)) {
+        const int len = chunk_len(r.n_after);
+        r.key_abort = aborts ? ((1u << len) | chunk_bits(before | (symbol ? 1u << k : 0u), m.da, len, c)) : 0u;
+    }
+    return r;
+}
+// second pass: `writes` = the edges that write a character (either kind).  The invalid flag of edge k's characters.
+SDR_HD inline void round_lane_invalid(int k, RoundLane &r, uint32_t writes, const RoundMasks &m, const CharCarry &c)
+{
+    const uint32_t earlier = writes & low_mask32(k);
+    const int lo = earlier ? top_bit32(earlier) + 1 : 0;
+    const bool inv = (m.invalid & between32(lo, k + 1)) != 0u || (!earlier && c.invalid);
+    if (r.key_edge) {
+        r.key_edge = inv ? kInvalidChar : r.key_edge;
+        r.key_abort = r.key_abort;  // (a second character at the same edge: nothing invalid can lie between the two)
+    } else if (r.key_abort) {
+        r.key_abort = inv ? kInvalidChar : r.key_abort;
+    }
+}
+// the character carried out of a round of `cnt` edges
+SDR_HD inline CharCarry round_carry(int cnt, uint32_t writes, const RoundMasks &m, const CharCarry &c)
+{
+    const uint32_t boundaries = (m.take | m.abort) & low_mask32(cnt);
+    const int seg_lo = boundaries ? top_bit32(boundaries) + 1 : 0;
+    const uint32_t seg = m.symbol & between32(seg_lo, cnt);
+    const int n = count_bits32(seg) + (boundaries ? 0 : c.len);
+    CharCarry o;
+    o.len = chunk_len(n);
+    o.bits = chunk_bits(seg, m.da, o.len, c);
+    const uint32_t w = writes & low_mask32(cnt);
+    const int lo = w ? top_bit32(w) + 1 : 0;
+    o.invalid = ((m.invalid & between32(lo, cnt)) != 0u || (!w && c.invalid)) ? 1 : 0;
+    return o;
+}
+
 // What an edge's step may write, in the reference's order: the edge's character, the word gap's ' ' (both at the edge's
 // frame), the abort's character (at its own).
 constexpr uint32_t kSpaceKey = 0xFFFEu;  // ' ' in a list of table keys

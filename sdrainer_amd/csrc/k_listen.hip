@@ -105,24 +105,23 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) void k_listen_gather(const float
 //             the words by ballot / shuffle), the edge list - to the batch's edge buffer for the host, and every
 //             edge's position to a scratch row (the host's buffer may be shorter than the list) - and the debouncer's
 //             state behind the batch;
-//   then, DEC_ROUND edges of every listener at a time, as a pipeline of four stages on different waves with one
-//   workgroup barrier per step (step t: A works on round t, B on round t - 1, C on t - 2, D on t - 3, through LDS):
+//   then, DEC_ROUND = 32 edges of every listener at a time, as a pipeline of three stages on different waves with one
+//   workgroup barrier per step (step t: A works on round t, B on round t - 1, C + D on round t - 2, through LDS):
 //   stage A   a LANE per listener, edge after edge, on TWO waves: the gap threshold's chain over the rising edges (wave
-//             0) and the mark threshold's over the falling ones (wave 2) - they are independent of each other;
+//             0) and the mark threshold's over the falling ones (wave 2) - they are independent of each other.  The only
+//             chain left in the kernel: 185 clocks per edge of a polarity;
 //   stage B   a thread per (listener, edge), helper waves: thresholds (the square roots), classification, the speed
 //             term (the division), the abort ticks of the runs;
-//   stage C   a lane per listener (wave 1), edge after edge: the current character, the speed average; what the edge
-//             writes - up to two characters (as table keys) and a ' ' - goes to LDS;
-//   stage D   helper waves, half a wave per listener, a lane per edge: the written runes' places by a prefix sum, table
-//             lookup, runes and frames into the text buffer.
-// Each serial wave has a SIMD's issue slots to itself (waves go to the four SIMDs round-robin).  The serial stages hold
-// no square root, no division, no table lookup and no store to memory; C walks rising and falling edges in alternating
-// steps (a listener whose first edge is a falling one sits out the first step), so no step selects a polarity, and
-// skips the two rare things - a ninth symbol, an abort - by a vote of the lanes.  Measured (tools/build_abl.sh with
-// -DSDR_DEC_CLOCK, config 3, 8192 frames, 530 edges per listener): a chain wave spends 185 clocks per edge of its
-// polarity, the character wave 430 per edge (70 instructions; a wave's instruction takes four cycles however many of
-// its lanes work, and the compare -> mask -> select patterns add their latency): C paces the pipeline, 0.12 ms per batch
-// where one lane per listener walking everything took 0.44.  Sixteen workgroups decode config 3's 256 listeners.
+//   stage C+D half a helper wave per listener, a lane per edge: the current character WITHOUT a chain - every take empties
+//             the character, so what an edge writes follows from the round's events as bit masks (the half-wave's ballots)
+//             and the character carried into the round (cw_stages.h round_lane) - then the written runes' places by
+//             popcounts of those masks, the table lookup, runes and frames into the text buffer; the speed average's one
+//             add and one multiply per da is the only loop, over the round's das.
+// The kernel is bound by instruction issue, so the waves are dealt over the CU's four SIMDs by weight (see "who does
+// what" below).  Measured (tools/build_abl.sh with -DSDR_DEC_CLOCK, config 3, 8192 frames, 530 edges per listener, 17
+// rounds): stage 0 18 k clocks, a chain wave 93 k, the busiest helper 120 k: 0.09 ms per batch where one lane per listener
+// walking everything took 0.44 (round 3: 0.51); config 2 - sixteen listeners, one workgroup - 40 -> 90 GS/s.  Sixteen
+// workgroups decode config 3's 256 listeners.
 // ---------------------------------------------------------------------------------------------------------------
 #ifndef SDR_DECODE_GROUP
 #define SDR_DECODE_GROUP 16
@@ -132,9 +131,6 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) void k_listen_gather(const float
 #endif
 #ifndef SDR_DECODE_ROUND
 #define SDR_DECODE_ROUND 32
-#endif
-#ifndef SDR_DECODE_HELPERS
-#define SDR_DECODE_HELPERS 1
 #endif
 constexpr int DEC_GROUP = SDR_DECODE_GROUP;  // listeners per workgroup: lanes of the waves that run the serial stages
 constexpr int DEC_WAVES = SDR_DECODE_WAVES;
@@ -172,13 +168,23 @@ struct DecodeLocal {
     int abort_dits;       // Decoder.abortDecodeAfterDits
     uint32_t first_key, first_frame;  // the character the run in front of the first edge took (0: none), for stage D
 };
-// an edge's 16 bytes of LDS: stage A's output, replaced by stage B's, replaced by stage C's
+// an edge's 16 bytes of LDS: stage A's output, replaced by stage B's
 union EdgeSlot {
     struct {
         double low, high;
     } chain;
     cw::EdgeRec rec;
-    cw::EdgeEvents events;
+};
+// the character stage between rounds, per listener of the group
+struct CharState {
+    double wpm;               // Decoder.wpm
+    double gap_threshold_in;  // offThreshold.threshold as carried into the batch (judges the run behind a first, falling edge)
+    int32_t len;              // Decoder.currentChar: symbols ...
+    uint32_t bits;            // ... their das, most recent in bit 0
+    int32_t invalid;          // Decoder.currentCharInvalid
+    int32_t pend;             // the run behind the next round's first edge, if that is a falling one, aborts ...
+    uint32_t pend_at;         // ... this many ticks into it
+    int32_t decoding;         // Decoder.decoding
 };
 
 __device__ __forceinline__ int shfl_i(int v, int src) { return __shfl(v, src, 64); }
@@ -197,6 +203,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void k_listen_decode(ListenerSlot *
     __shared__ uint32_t s_pos[4][DEC_POS_ROWS][DEC_GROUP + 1];  // [round & 3][i][l]: position of listener l's edge k0 - 1 + i (behind the last one: the span's end)
     __shared__ double s_now[3][DEC_POS_ROWS][DEC_GROUP + 1];    // [round % 3]: ... and the edge's tick (Decoder.ticks behind its increment)
     __shared__ __attribute__((aligned(16))) EdgeSlot s_edge[4][DEC_ROUND][DEC_GROUP];
+    __shared__ CharState s_char[DEC_GROUP];
     __shared__ int s_max_edges;
     if (threadIdx.x == 0)
         s_max_edges = 0;
@@ -335,18 +342,23 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void k_listen_decode(ListenerSlot *
     SDR_DEC_TICK(0);
 
     // ---- who does what from here on
-    // Waves go to the CU's four SIMDs round-robin.  Each serial stage has a SIMD's issue slots to itself: the gap
-    // threshold's chain (wave 0), the character assembly (wave 1), the mark threshold's chain (wave 2); the helpers
-    // (stage B, the position fetches, stage D) are the waves of SIMD 3 - and, SDR_DECODE_HELPERS = 1, the other waves of SIMD 2.
-    const bool wave_ar = wave == 0, wave_c = wave == 1, wave_af = wave == 2, wave_a = wave_ar || wave_af;
-    constexpr int N_HELPER_WAVES = DEC_WAVES / 4 + (SDR_DECODE_HELPERS ? DEC_WAVES / 4 - 1 : 0);
-    const int helper_wave = (wave & 3) == 3 ? wave >> 2 : (SDR_DECODE_HELPERS && (wave & 3) == 2 && wave > 2) ? DEC_WAVES / 4 + (wave >> 2) - 1 : -1;
+    // Waves go to the CU's four SIMDs round-robin.  The kernel is bound by instruction issue, so the stages are dealt over the
+    // SIMDs by weight: the gap threshold's chain (wave 0, SIMD 0) and the mark threshold's (wave 2, SIMD 2) - an edge each per
+    // 185 clocks; every other wave is a helper: the six that share a SIMD with a chain come first in the helpers' numbering
+    // and take stage B's items (the lightest stage), the eight of SIMD 1 and 3 take stage C + D, a pair of listeners each.
+    const bool wave_ar = wave == 0, wave_af = wave == 2, wave_a = wave_ar || wave_af;
+    constexpr int N_HELPER_WAVES = DEC_WAVES - 2, N_CD_WAVES = DEC_WAVES / 2, N_B_FIRST = N_HELPER_WAVES - N_CD_WAVES;
+    const int helper_wave = wave_a ? -1
+                            : (wave & 1) ? N_B_FIRST + (wave >> 2) + ((wave & 2) ? DEC_WAVES / 4 : 0)
+                                         : (wave >> 2) - 1 + ((wave & 2) ? DEC_WAVES / 4 - 1 : 0);
+    const int cd_wave = helper_wave - N_B_FIRST;  // (>= 0: a wave of SIMD 1 or 3)
     const int helper = helper_wave >= 0 ? helper_wave * 64 + lane : -1;
     constexpr int N_HELPERS = N_HELPER_WAVES * 64;
-    constexpr int N_PAIRS = (DEC_GROUP + 1) / 2;  // stage D: two listeners to a wave, a lane per edge of the round
-    constexpr int D_PER_WAVE = (N_PAIRS + N_HELPER_WAVES - 1) / N_HELPER_WAVES;
-    static_assert(DEC_ROUND == 32, "stage D: half a wave per listener");
-    const bool serial_lane = (wave_a || wave_c) && lane < DEC_GROUP;
+    constexpr int N_PAIRS = (DEC_GROUP + 1) / 2;  // stage C + D: two listeners to a wave, a lane per edge of the round
+    constexpr int D_PER_WAVE = (N_PAIRS + N_CD_WAVES - 1) / N_CD_WAVES;
+    static_assert(DEC_ROUND == 32, "stage C + D: half a wave per listener");
+    // one lane per listener: wave 1 sets the character stage up (the decoder as carried), waves 0 and 2 run the chains
+    const bool serial_lane = (wave_a || wave == 1) && lane < DEC_GROUP;
     DecodeLocal loc{};
     bool on = false;
     ListenerSlot *slot = nullptr;
@@ -359,11 +371,6 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void k_listen_decode(ListenerSlot *
     // waves A: one threshold's chain
     double t_low = 0, t_high = 0, t_last = 0, t_bound = 0, last_now = 0;
     bool t_moved = false, any_mine = false;
-    // wave C: the current character, the speed
-    cw::DecoderState dec{};
-    bool pend = false;     // the run behind the next falling edge aborts ...
-    uint32_t pend_at = 0;  // ... this many ticks into it
-    double gap_threshold_in = 0;
     if (on) {
         if (wave_a) {
             const cw::AdaptiveThreshold &th = wave_ar ? slot->dec.offThreshold : slot->dec.onThreshold;
@@ -372,14 +379,15 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void k_listen_decode(ListenerSlot *
             t_last = th.last;
             t_bound = th.upperBound;
         } else {
-            dec = slot->dec;
-            gap_threshold_in = dec.offThreshold.threshold;
-            // the run in front of the first edge: the decoder as carried
+            // the run in front of the first edge: the decoder as carried; what is left is the character stage's start
+            cw::DecoderState dec = slot->dec;
+            const double gap_threshold_in = dec.offThreshold.threshold;
             const int p0 = loc.n_edges ? (int)edge_pos[(size_t)(group0 + lane) * pos_stride] : loc.end;
             cw::Emission em{0u, 0u, false};
             cw::decoder_run(dec, p0 - loc.first, g.frame_base + (uint32_t)loc.first, em);
             s_loc[lane].first_key = em.key;
             s_loc[lane].first_frame = em.frame;
+            s_char[lane] = CharState{dec.wpm, gap_threshold_in, dec.charLen, dec.charBits, dec.currentCharInvalid, 0, 0u, dec.decoding};
         }
     }
     const int rounds = (s_max_edges + DEC_ROUND - 1) / DEC_ROUND;
@@ -408,8 +416,8 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void k_listen_decode(ListenerSlot *
     // stage D's state: where the next rune of this lane's listener goes (the same in the 32 lanes of a listener)
     uint32_t text_at[D_PER_WAVE] = {}, text_cap_hit[D_PER_WAVE] = {};
     auto d_listener = [&](int n) {  // the listener this lane works for in its wave's n-th pair, -1: none
-        const int li = (helper_wave + n * N_HELPER_WAVES) * 2 + (lane >> 5);
-        return helper_wave >= 0 && li < DEC_GROUP && s_loc[li].n_edges >= 0 && s_loc[li].first < s_loc[li].end ? li : -1;
+        const int li = (cd_wave + n * N_CD_WAVES) * 2 + (lane >> 5);
+        return cd_wave >= 0 && li < DEC_GROUP && s_loc[li].n_edges >= 0 && s_loc[li].first < s_loc[li].end ? li : -1;
     };
 #pragma unroll
     for (int n = 0; n < D_PER_WAVE; n++) {
@@ -431,7 +439,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void k_listen_decode(ListenerSlot *
         }
     }
 
-    for (int t = 0; t < rounds + 3; t++) {
+    for (int t = 0; t < rounds + 2; t++) {
         uint32_t ahead[POS_PER_HELPER];
         const bool fetch = helper >= 0 && t + 1 < rounds;
         if (fetch)
@@ -462,48 +470,6 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void k_listen_decode(ListenerSlot *
                     }
                 }
             }
-        } else if (wave_c) {
-            // ---- stage C, round t - 2
-            const int rc = t - 2;
-            const int mine = on && rc >= 0 && rc < rounds ? max(0, min(DEC_ROUND, loc.n_edges - rc * DEC_ROUND)) : 0;
-            const auto &P = s_pos[rc & 3];
-            auto &E = s_edge[rc & 3];
-            if (mine > 0 && rc == 0 && shift) {
-                // the batch's first edge is a falling one: the run behind it is judged by the gap threshold as carried
-                const int p = (int)P[1][lane], p1 = (int)P[2][lane];
-                pend = cw::run_aborts(loc.t0 + (double)(p - loc.first + 1), p1 - p - 1, gap_threshold_in, loc.abort_dits, &pend_at);
-            }
-            if (__ballot(mine > 0)) {
-                // rising and falling edges in alternating steps (a listener whose first edge is a falling one sits out the
-                // first rising step): no step selects a polarity
-                cw::EdgeRec next_r = E[max(-shift, 0)][lane].rec, next_f = E[1 - shift][lane].rec;
-                uint32_t next_pr = P[max(1 - shift, 0)][lane], next_pf = P[2 - shift][lane];
-#pragma unroll 1
-                for (int j = 0; j <= DEC_ROUND / 2; j++) {  // (unrolled twice the character wave spills)
-                    const int kr = 2 * j - shift, kf = kr + 1;
-                    const cw::EdgeRec rec_r = next_r, rec_f = next_f;
-                    const uint32_t pos_r = next_pr, pos_f = next_pf;
-                    // (the next step's, on their way while this one computes; past the round's end: never used)
-                    next_r = E[min(kr + 2, DEC_ROUND - 1)][lane].rec;
-                    next_f = E[min(kf + 2, DEC_ROUND - 1)][lane].rec;
-                    next_pr = P[min(kr + 3, DEC_POS_ROWS - 1)][lane];
-                    next_pf = P[min(kf + 3, DEC_POS_ROWS - 1)][lane];
-                    uint32_t key_edge;
-                    bool space;
-                    if (kr >= 0 && kr < mine) {
-                        cw::assemble_edge(dec, true, rec_r, &key_edge, &space);
-                        const uint32_t key_abort = cw::assemble_abort(dec, (rec_r.flags & cw::ER_ABORT) != 0);
-                        E[kr][lane].events = cw::edge_events(key_edge, space, key_abort, g.frame_base + pos_r, rec_r.abort_at);
-                        pend = rec_r.flags & cw::ER_ABORT_NEXT;
-                        pend_at = rec_r.rise.abort_next_at;
-                    }
-                    if (kf < mine) {
-                        cw::assemble_edge(dec, false, rec_f, &key_edge, &space);
-                        const uint32_t key_abort = cw::assemble_abort(dec, pend);
-                        E[kf][lane].events = cw::edge_events(key_edge, false, key_abort, g.frame_base + pos_f, pend_at);
-                    }
-                }
-            }
         } else if (helper >= 0) {
             // ---- stage B, round t - 1
             const int rb = t - 1;
@@ -529,49 +495,118 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void k_listen_decode(ListenerSlot *
                     E[kk][li].rec = rec;
                 }
             }
-            // ---- stage D, round t - 3: a lane per edge, the edges' runes and frames to the text buffer in their order
-            const int rd = t - 3;
-            if (rd >= 0 && rd < rounds) {
+            // ---- stage C + D, round t - 2: half a wave per listener, a lane per edge.  The current character without a chain
+            // (cw_stages.h round_lane: what an edge writes follows from the round's events as bit masks - this half's ballots -
+            // and the character carried into the round); the runes' places by a prefix sum; runes and frames to the text buffer
+            const int rd = t - 2;
+            if (cd_wave >= 0 && rd >= 0 && rd < rounds) {
+                const auto &P = s_pos[rd & 3];
                 const auto &E = s_edge[rd & 3];
 #pragma unroll
                 for (int n = 0; n < D_PER_WAVE; n++) {
-                    const int li = d_listener(n), kk = lane & 31;
-                    cw::EdgeEvents ev{0u, 0u, 0u, 0u};
-                    if (li >= 0 && rd * DEC_ROUND + kk < s_loc[li].n_edges)
-                        ev = E[kk][li].events;
-                    const uint32_t key_edge = ev.keys & 0xFFFFu, key_abort = ev.keys >> 16;
-                    const int cnt = (key_edge ? 1 : 0) + (ev.space ? 1 : 0) + (key_abort ? 1 : 0);
-                    if (!__ballot(cnt != 0))
+                    const int li = d_listener(n), k = lane & 31, half = lane >> 5;
+                    const int cnt = li >= 0 ? max(0, min(DEC_ROUND, s_loc[li].n_edges - rd * DEC_ROUND)) : 0;
+                    if (!__ballot(cnt > 0))
                         continue;
-                    int incl = cnt;
+                    const bool valid = k < cnt;
+                    cw::EdgeRec rec{};
+                    CharState cs{};
+                    uint32_t frame = 0;
+                    if (cnt > 0)
+                        cs = s_char[li];
+                    if (valid) {
+                        rec = E[k][li].rec;
+                        frame = g.frame_base + P[k + 1][li];
+                    }
+                    const bool rising = valid && (rec.flags & cw::ER_STATE);
+                    // the abort of the run behind a falling edge: the rising edge before it said (the lane below; the round's
+                    // first edge: carried - the batch's first: the gap threshold as carried)
+                    if (cnt > 0 && rd == 0 && !s_loc[li].state0) {
+                        const int p = (int)P[1][li], p1 = (int)P[2][li];
+                        uint32_t at = 0;
+                        cs.pend = cw::run_aborts(s_loc[li].t0 + (double)(p - s_loc[li].first + 1), p1 - p - 1, cs.gap_threshold_in, s_loc[li].abort_dits, &at);
+                        cs.pend_at = at;
+                    }
+                    // (cross-lane values come from ballots and from LDS, not from lane shuffles: a shuffle is a trip through the
+                    // LDS crossbar, and a dozen dependent ones were most of this stage's time)
+                    const int sh = 32 * half;
+                    const uint32_t next_aborts = (uint32_t)(__ballot(rising && (rec.flags & cw::ER_ABORT_NEXT)) >> sh);
+                    int below_abort = k > 0 ? (int)((next_aborts >> (k - 1)) & 1u) : cs.pend;
+                    uint32_t below_at = cs.pend_at;
+                    if (valid && k > 0 && !rising)
+                        below_at = E[k - 1][li].rec.rise.abort_next_at;
+                    const bool abort = valid && (rising ? (rec.flags & cw::ER_ABORT) != 0 : below_abort != 0);
+                    const uint32_t abort_at = rising ? rec.abort_at : below_at;
+                    const bool falling = valid && !rising;
+                    cw::RoundMasks m;
+                    m.take = (uint32_t)(__ballot(rising && (rec.flags & cw::ER_TAKE)) >> sh);
+                    m.abort = (uint32_t)(__ballot(abort) >> sh);
+                    m.invalid = (uint32_t)(__ballot(falling && (rec.flags & cw::ER_INVALID)) >> sh);
+                    m.symbol = (uint32_t)(__ballot(falling && (rec.flags & cw::ER_SYMBOL)) >> sh);
+                    m.da = (uint32_t)(__ballot(falling && (rec.flags & cw::ER_SYMBOL) && (rec.flags & cw::ER_DA)) >> sh);
+                    const cw::CharCarry carry{cs.len, cs.bits, cs.invalid};
+                    cw::RoundLane r{0u, 0u, 0};
+                    if (valid)
+                        r = cw::round_lane(k, rising, m, carry);
+                    const uint32_t writes = (uint32_t)(__ballot(r.key_edge != 0 || r.key_abort != 0) >> sh);
+                    if (valid)
+                        cw::round_lane_invalid(k, r, writes, m, carry);
+                    const bool space = rising && (rec.flags & cw::ER_SPACE);
+                    // the speed average (:291), the one loop left: over the round's das (their terms straight from LDS, eight
+                    // requested at a time), every lane of the half alike
+                    double wpm = cs.wpm;
+                    for (uint32_t das = m.da; __ballot(das != 0);) {
+                        double term[8];
+                        bool have[8];
 #pragma unroll
-                    for (int d = 1; d < 32; d <<= 1) {
-                        const int v = __shfl_up(incl, d, 32);
-                        if (kk >= d)
-                            incl += v;
-                    }
-                    const uint32_t total = (uint32_t)__shfl(incl, 31, 32), cap = (uint32_t)g.text_cap;
-                    uint32_t at = text_at[n] + (uint32_t)(incl - cnt);
-                    if (li >= 0) {
-                        uint32_t *buf = text + (size_t)(group0 + li) * g.text_cap, *frm = text_frames + (size_t)(group0 + li) * g.text_cap;
-                        if (key_edge && at < cap) {
-                            buf[at] = cw::key_to_rune(key_edge, morse);
-                            frm[at] = ev.frame;
+                        for (int i = 0; i < 8; i++) {
+                            have[i] = das != 0;
+                            const int j = das ? cw::bottom_bit(das) : 0;
+                            das &= das - 1u;  // (0 & anything: stays 0)
+                            term[i] = E[j][max(li, 0)].rec.wpm_term;
                         }
-                        at += key_edge ? 1u : 0u;
-                        if (ev.space && at < cap) {
-                            buf[at] = ' ';
-                            frm[at] = ev.frame;
-                        }
-                        at += ev.space ? 1u : 0u;
-                        if (key_abort && at < cap) {
-                            buf[at] = cw::key_to_rune(key_abort, morse);
-                            frm[at] = ev.abort_frame;
+#pragma unroll
+                        for (int i = 0; i < 8; i++) {
+                            const double next = (wpm + term[i]) / 2.0;
+                            wpm = have[i] ? next : wpm;
                         }
                     }
-                    const uint32_t room = cap - min(text_at[n], cap);
-                    text_cap_hit[n] += total > room ? total - room : 0u;
-                    text_at[n] += min(total, room);
+                    // D: the runes' places, from three ballots
+                    const uint32_t e_mask = (uint32_t)(__ballot(r.key_edge != 0) >> sh), s_mask = (uint32_t)(__ballot(space) >> sh),
+                                   a_mask = (uint32_t)(__ballot(r.key_abort != 0) >> sh);
+                    if (__ballot((e_mask | s_mask | a_mask) != 0)) {
+                        const uint32_t lower = cw::low_mask32(k);
+                        const uint32_t total = (uint32_t)(cw::count_bits32(e_mask) + cw::count_bits32(s_mask) + cw::count_bits32(a_mask)), cap = (uint32_t)g.text_cap;
+                        uint32_t at = text_at[n] + (uint32_t)(cw::count_bits32(e_mask & lower) + cw::count_bits32(s_mask & lower) + cw::count_bits32(a_mask & lower));
+                        if (li >= 0) {
+                            uint32_t *buf = text + (size_t)(group0 + li) * g.text_cap, *frm = text_frames + (size_t)(group0 + li) * g.text_cap;
+                            if (r.key_edge && at < cap) {
+                                buf[at] = cw::key_to_rune(r.key_edge, morse);
+                                frm[at] = frame;
+                            }
+                            at += r.key_edge ? 1u : 0u;
+                            if (space && at < cap) {
+                                buf[at] = ' ';
+                                frm[at] = frame;
+                            }
+                            at += space ? 1u : 0u;
+                            if (r.key_abort && at < cap) {
+                                buf[at] = cw::key_to_rune(r.key_abort, morse);
+                                frm[at] = frame + 1u + abort_at;
+                            }
+                        }
+                        const uint32_t room = cap - min(text_at[n], cap);
+                        text_cap_hit[n] += total > room ? total - room : 0u;
+                        text_at[n] += min(total, room);
+                    }
+                    // the character carried into the next round
+                    if (cnt > 0 && k == 0) {
+                        const cw::CharCarry out = cw::round_carry(cnt, writes, m, carry);
+                        const int last = cnt - 1;
+                        const bool last_next_abort = (next_aborts >> last) & 1u;
+                        s_char[li] = CharState{wpm, cs.gap_threshold_in, out.len, out.bits, out.invalid, last_next_abort ? 1 : 0,
+                                               last_next_abort ? E[last][li].rec.rise.abort_next_at : 0u, ((m.abort >> last) & 1u) ? 0 : 1};
+                    }
                 }
             }
         }
@@ -614,18 +649,17 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void k_listen_decode(ListenerSlot *
                 slot->dec.offStart = last_now;  // :231
         }
     }
-    if (on && wave_c) {
-        slot->dec.decoding = dec.decoding;
-        slot->dec.currentCharInvalid = dec.currentCharInvalid;
-        slot->dec.charLen = dec.charLen;
-        slot->dec.charBits = dec.charBits;
-        slot->dec.wpm = dec.wpm;
-    }
 #pragma unroll
     for (int n = 0; n < D_PER_WAVE; n++) {
         const int li = d_listener(n);
         if (li >= 0 && (lane & 31) == 0) {
             ListenerSlot *sl = &slots[group0 + li];
+            const CharState cs = s_char[li];
+            sl->dec.decoding = cs.decoding;
+            sl->dec.currentCharInvalid = cs.invalid;
+            sl->dec.charLen = cs.len;
+            sl->dec.charBits = cs.bits;
+            sl->dec.wpm = cs.wpm;
             sl->text_count = text_at[n];
             if (text_cap_hit[n]) {  // nothing is lost silently: counted per listener and bank-wide
                 sl->text_dropped += text_cap_hit[n];
@@ -634,7 +668,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void k_listen_decode(ListenerSlot *
         }
     }
 #if defined(SDR_DEC_CLOCK)
-    if (blockIdx.x == 0 && lane == 0 && wave < 4)  // (tools only: shader cycles of the chain waves, the character wave and a helper)
+    if (blockIdx.x == 0 && lane == 0 && wave < 4)  // (tools only: shader cycles of the chain waves (0, 2) and two helpers)
         printf("decode clocks wave %d: stage0 %llu setup %llu work %llu wait %llu rounds %d\n", wave, ck[0], ck[1], ck[2], ck[3], rounds);
 #endif
 }

@@ -84,7 +84,7 @@ static std::vector<uint8_t> make_stream(int ticks, int kind)
 
 // One batch through the stages.  raw: the batch's raw states, one per frame; first: the listener's first frame in it.
 static void staged_batch(cw::Debouncer &deb, cw::DecoderState &dec, const std::vector<uint8_t> &raw, int first, uint32_t frame_base,
-                         const uint16_t *table, std::vector<uint64_t> &eff_words, std::vector<Edge> &edges, std::vector<Rec> &runes, bool split_chains)
+                         const uint16_t *table, std::vector<uint64_t> &eff_words, std::vector<Edge> &edges, std::vector<Rec> &runes, bool split_chains, bool parallel_chars)
 {
     const int n = (int)raw.size(), n_words = (n + 63) / 64;
     const cw::TickSpan span{first < n ? first : n, n};
@@ -191,30 +191,84 @@ static void staged_batch(cw::Debouncer &deb, cw::DecoderState &dec, const std::v
         else
             recs[(size_t)k] = cw::classify_falling(dec.tickSeconds, duration, lows[(size_t)k], highs[(size_t)k]);
     }
-    // ---- stage C
+    // ---- stage C: edge after edge (assemble_edge), or - every other stream - round by round without a chain (round_lane)
     bool pend = false;
     uint32_t pend_at = 0;
     if (n_edges && !state0)  // the batch's first edge is a falling one: the run behind it is judged by the carried gap threshold
         pend = cw::run_aborts(now_of(0), run_behind(0), gap_threshold_in, dec.abortDecodeAfterDits, &pend_at);
-    for (int k = 0; k < n_edges; k++) {
-        const cw::EdgeRec &r = recs[(size_t)k];
-        const bool rising = r.flags & cw::ER_STATE;
-        const uint32_t frame = frame_base + pos[(size_t)k], at = rising ? r.abort_at : pend_at;
-        uint32_t key_edge;
-        bool space;
-        cw::assemble_edge(dec, rising, r, &key_edge, &space);
-        const uint32_t key_abort = cw::assemble_abort(dec, rising ? (r.flags & cw::ER_ABORT) != 0 : pend);
-        const cw::EdgeEvents ev = cw::edge_events(key_edge, space, key_abort, frame, at);
-        if (ev.keys & 0xFFFFu)
-            emit(ev.keys & 0xFFFFu, ev.frame);
-        if (ev.space)
-            emit(cw::kSpaceKey, ev.frame);
-        if (ev.keys >> 16)
-            emit(ev.keys >> 16, ev.abort_frame);
-        if (rising) {
-            pend = r.flags & cw::ER_ABORT_NEXT;
-            pend_at = r.rise.abort_next_at;
+    if (!parallel_chars) {
+        for (int k = 0; k < n_edges; k++) {
+            const cw::EdgeRec &r = recs[(size_t)k];
+            const bool rising = r.flags & cw::ER_STATE;
+            const uint32_t frame = frame_base + pos[(size_t)k], at = rising ? r.abort_at : pend_at;
+            uint32_t key_edge;
+            bool space;
+            cw::assemble_edge(dec, rising, r, &key_edge, &space);
+            const uint32_t key_abort = cw::assemble_abort(dec, rising ? (r.flags & cw::ER_ABORT) != 0 : pend);
+            const cw::EdgeEvents ev = cw::edge_events(key_edge, space, key_abort, frame, at);
+            if (ev.keys & 0xFFFFu)
+                emit(ev.keys & 0xFFFFu, ev.frame);
+            if (ev.space)
+                emit(cw::kSpaceKey, ev.frame);
+            if (ev.keys >> 16)
+                emit(ev.keys >> 16, ev.abort_frame);
+            if (rising) {
+                pend = r.flags & cw::ER_ABORT_NEXT;
+                pend_at = r.rise.abort_next_at;
+            }
         }
+    } else {
+        cw::CharCarry carry{dec.charLen, dec.charBits, dec.currentCharInvalid};
+        for (int k0 = 0; k0 < n_edges; k0 += 32) {
+            const int cnt = n_edges - k0 < 32 ? n_edges - k0 : 32;
+            cw::RoundMasks m{0u, 0u, 0u, 0u, 0u};
+            bool rising[32], ab[32];
+            uint32_t ab_at[32];
+            for (int k = 0; k < cnt; k++) {  // (the kernel: a lane per edge, ballots)
+                const cw::EdgeRec &r = recs[(size_t)(k0 + k)];
+                rising[k] = r.flags & cw::ER_STATE;
+                if (rising[k]) {
+                    ab[k] = r.flags & cw::ER_ABORT;
+                    ab_at[k] = r.abort_at;
+                } else {  // the rising edge before it said (the lane below; the round's first edge: carried)
+                    ab[k] = pend;
+                    ab_at[k] = pend_at;
+                }
+                if (rising[k]) {
+                    pend = r.flags & cw::ER_ABORT_NEXT;
+                    pend_at = r.rise.abort_next_at;
+                }
+                m.take |= (uint32_t)(rising[k] && (r.flags & cw::ER_TAKE)) << k;
+                m.abort |= (uint32_t)ab[k] << k;
+                m.invalid |= (uint32_t)(!rising[k] && (r.flags & cw::ER_INVALID)) << k;
+                m.symbol |= (uint32_t)(!rising[k] && (r.flags & cw::ER_SYMBOL)) << k;
+                m.da |= (uint32_t)(!rising[k] && (r.flags & cw::ER_SYMBOL) && (r.flags & cw::ER_DA)) << k;
+            }
+            cw::RoundLane lanes[32];
+            uint32_t writes = 0;
+            for (int k = 0; k < cnt; k++) {
+                lanes[k] = cw::round_lane(k, rising[k], m, carry);
+                writes |= (uint32_t)(lanes[k].key_edge != 0 || lanes[k].key_abort != 0) << k;
+            }
+            for (int k = 0; k < cnt; k++) {
+                cw::round_lane_invalid(k, lanes[k], writes, m, carry);
+                const cw::EdgeRec &r = recs[(size_t)(k0 + k)];
+                const uint32_t frame = frame_base + pos[(size_t)(k0 + k)];
+                if (lanes[k].key_edge)
+                    emit(lanes[k].key_edge, frame);
+                if (rising[k] && (r.flags & cw::ER_SPACE))
+                    emit(cw::kSpaceKey, frame);
+                if (lanes[k].key_abort)
+                    emit(lanes[k].key_abort, frame + 1u + ab_at[k]);
+                if ((m.da >> k) & 1u)  // the speed average (:291): the one loop left
+                    dec.wpm = (dec.wpm + r.wpm_term) / 2.0;
+            }
+            carry = cw::round_carry(cnt, writes, m, carry);
+            dec.decoding = ab[cnt - 1] ? 0 : 1;
+        }
+        dec.charLen = carry.len;
+        dec.charBits = carry.bits;
+        dec.currentCharInvalid = carry.invalid;
     }
     cw::chain_store(chain, dec);
     dec.ticks = t0 + (double)(span.end - span.first);
@@ -266,7 +320,7 @@ int main()
             std::vector<uint64_t> eff;
             std::vector<Edge> edges;
             std::vector<Rec> runes;
-            staged_batch(sdeb, sdec, raw, first, (uint32_t)at, table, eff, edges, runes, ((it >> 2) & 1) != 0);
+            staged_batch(sdeb, sdec, raw, first, (uint32_t)at, table, eff, edges, runes, ((it >> 2) & 1) != 0, ((it >> 3) & 1) != 0);
             bool bad = false;
             if (eff != ref_eff) {
                 if (mismatches < 8)
