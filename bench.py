@@ -399,7 +399,7 @@ def main():
         """wait: until everything enqueued so far has been delivered AND counted by the consumer thread (the library
         reports a batch delivered inside sdr_poll, a moment before the consumer adds it to `got`)."""
         while wait and (bank.results_pending > 0 or got["batches"] < enqueued[0]):
-            time.sleep(20e-6)
+            time.sleep(0)  # (yields the GIL to the consumer thread; a timed sleep here rounds up to 60 - 100 us of harness time inside the timed region)
 
     enqueued = [0]  # batches handed to the bank so far
 
