@@ -1018,17 +1018,21 @@ hipError_t launch_mfma_order_probe(unsigned *mismatches, int order, hipStream_t 
 hipError_t launch_window_means(const float *psd, double *win_mean, NoiseGeom g, int n_frames, int n_bands, int stride,
                                hipStream_t stream)
 {
-    // a workgroup fills its CU: enough of them to cover the chip, but no more than two rounds.  (Config 3: 160
-    // workgroups of one window each.  Two windows back to back per workgroup, 80 workgroups: 0.050 instead of
-    // 0.030 ms standalone and 0.226-0.238 instead of 0.222-0.225 ms per pipelined step - the noise stream is as long
-    // as the others by now; four windows: 0.093 ms, 0.253.  Round 4, SDR_WM_WPB on one box each: config 3 at 8192 frames
-    // per batch, 1 / 2 / 5 / 10 windows per workgroup 158.4 / 159.0 / 161.4 / 160.5 GS/s - fewer, longer-lived workgroups
-    // hold less CU time, within the noise of a run; config 5's share, whose noise stream is the longest of its four,
-    // 184.1 with one window against 174.2 with two.  One window stays.)
+    // (rounds 2 - 3, 2048-frame batches: config 3's 160 workgroups of one window each; two windows back to back per
+    // workgroup, 80 workgroups: 0.050 instead of 0.030 ms standalone and 0.226 - 0.238 instead of 0.222 - 0.225 ms per
+    // pipelined step; four windows: 0.093 ms, 0.253)
     const bool half = g.n <= 8192;  // the FFT kernel's workgroups are 512 threads or fewer: see WM_GROUPS_HALF
     const int groups = half ? WM_GROUPS_HALF : WM_GROUPS;
     const int per_band = ((n_frames + TILE - 1) / TILE + groups - 1) / groups;
-    int wpb = (per_band * n_bands * g.n_windows) / (512 * WM_GROUPS / groups);
+    // windows per workgroup.  Whole-CU workgroups (N = 16384): fewer, longer-lived ones hold less CU time as long as there
+    // are enough of them for the kernel's latency - about 64: config 3 at 8192 frames per batch (320 window-groups), one box,
+    // interleaved twice, 1 / 2 / 5 / 10 windows per workgroup 166.0 / 167.5 / 168.8 / 167.7 and 166.2 / 167.7 / 168.8 / 168.0
+    // GS/s; at 2048 frames (80 window-groups) five windows per workgroup leave 16 workgroups: 105 against 162.5.  Half-size
+    // workgroups (config 5's share: 1280 of them) stay at one window each: two cost 5 % there (round 4, first half).
+    // (4096 frames: two windows per workgroup 171.1 against 172.3 with one - several only pay from about four on)
+    int wpb = half ? (per_band * n_bands * g.n_windows) / (512 * WM_GROUPS / groups) : (per_band * n_bands * g.n_windows) / 64;
+    if (!half && wpb < 4)
+        wpb = 1;
     wpb = wpb < 1 ? 1 : (wpb > g.n_windows ? g.n_windows : wpb);
     static const int wpb_env = getenv("SDR_WM_WPB") ? atoi(getenv("SDR_WM_WPB")) : 0;  // (development)
     if (wpb_env > 0)
