@@ -12,15 +12,16 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libsdrainer_hip.so")
-SOURCES = ["k_fft_psd.hip", "k_noise.hip", "k_listen.hip", "k_peaks.hip", "k_unpack.hip", "k_results.hip", "capi_bank.hip", "capi_process.hip", "capi_results.hip", "capi_graph.hip", "capi_read.hip", "sdr_audio.hip"]
-HEADERS = ["sdr_device.h", "bank.h", "host/delivery.h", "fft_f64.h", "gomath.h", "cw_decoder.h", "cw_stages.h", "twiddles.h", "host/frequency_mapping.h",
+SOURCES = ["k_fft_psd.hip", "k_fft_r32.hip", "k_noise.hip", "k_listen.hip", "k_peaks.hip", "k_unpack.hip", "k_results.hip", "capi_bank.hip", "capi_process.hip", "capi_results.hip", "capi_graph.hip", "capi_read.hip", "sdr_audio.hip"]
+HEADERS = ["sdr_device.h", "bank.h", "host/delivery.h", "fft_f64.h", "fft_r32.h", "gomath.h", "cw_decoder.h", "cw_stages.h", "twiddles.h", "host/frequency_mapping.h",
            "../../include/sdrainer_hip.h"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
          "-DSDR_BUILD"]
 # k_fft_psd: machine-LICM parks literal constants in VGPRs for the whole kernel; the FFT needs all 128
 # registers a 1024-thread workgroup leaves it, and four parked constants are four spilled data registers.
-EXTRA_FLAGS = {"k_fft_psd.hip": ["-mllvm", "-disable-machine-licm", "-Wno-unused-lambda-capture"]}
+EXTRA_FLAGS = {"k_fft_psd.hip": ["-mllvm", "-disable-machine-licm", "-Wno-unused-lambda-capture"],
+               "k_fft_r32.hip": ["-mllvm", "-disable-machine-licm", "-Wno-unused-lambda-capture"]}
 
 
 def hipcc() -> str:

@@ -1005,9 +1005,28 @@ static hipError_t launch_fft_t(const float *iq, const BatchCursor *cur, const ff
     }
 }
 
+// N = 16384 has two kernels: this file's 16-point one and k_fft_r32.hip (512 threads x 32 points, the next frame
+// prefetched into registers), whose workgroups take several frames each.  SDR_FFT_R32 = 0 / 1 forces one of them (tests);
+// by default the 32-point kernel runs whenever every CU can be given a workgroup of at least two frames.  The bank's
+// twiddle buffer holds both kernels' tables, the 32-point kernel's behind the other.
+static int r32_mode()
+{
+    static const int v = [] {
+        if (const char *e = getenv("SDR_FFT_R32"))
+            return atoi(e) ? 1 : 0;
+        return -1;
+    }();
+    return v;
+}
+
 hipError_t launch_fft(int logn, const float *iq, const BatchCursor *cur, const fft64::cplx *tw, float *psd, int n_frames,
                       int n_bands, int in_stride, int out_stride, FftTap tap, hipStream_t stream)
 {
+    if (logn == 14) {
+        const int mode = r32_mode();
+        if (mode == 1 || (mode < 0 && (long)n_frames * n_bands >= 512))
+            return launch_fft_r32(iq, cur, tw + fft64::Plan<14>::TW_TOTAL, psd, n_frames, n_bands, in_stride, out_stride, tap, stream);
+    }
     switch (logn) {
     case 9: return launch_fft_t<9>(iq, cur, tw, psd, n_frames, n_bands, in_stride, out_stride, tap, stream);
     case 10: return launch_fft_t<10>(iq, cur, tw, psd, n_frames, n_bands, in_stride, out_stride, tap, stream);
@@ -1027,7 +1046,7 @@ int twiddle_count(int logn)
     case 11: return fft64::Plan<11>::TW_TOTAL;
     case 12: return fft64::Plan<12>::TW_TOTAL;
     case 13: return fft64::Plan<13>::TW_TOTAL;
-    case 14: return fft64::Plan<14>::TW_TOTAL;
+    case 14: return fft64::Plan<14>::TW_TOTAL + r32_twiddle_count();
     default: return 0;
     }
 }
@@ -1040,7 +1059,10 @@ void build_twiddles(int logn, const double *wre, const double *wim, fft64::cplx 
     case 11: fft64::build_pass_twiddles<11>(wre, wim, out); break;
     case 12: fft64::build_pass_twiddles<12>(wre, wim, out); break;
     case 13: fft64::build_pass_twiddles<13>(wre, wim, out); break;
-    case 14: fft64::build_pass_twiddles<14>(wre, wim, out); break;
+    case 14:
+        fft64::build_pass_twiddles<14>(wre, wim, out);
+        r32_build_twiddles(wre, wim, out + fft64::Plan<14>::TW_TOTAL);
+        break;
     default: break;
     }
 }

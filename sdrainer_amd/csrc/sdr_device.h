@@ -128,6 +128,11 @@ hipError_t launch_fft(int logn, const float *iq, const BatchCursor *cur, const f
                       int n_bands, int in_stride, int out_stride, FftTap tap, hipStream_t stream);
 int twiddle_count(int logn);
 void build_twiddles(int logn, const double *wre, const double *wim, fft64::cplx *out);
+// k_fft_r32.hip: N = 16384 as 512 threads x 32 points with the next frame prefetched into registers (own twiddle layout)
+hipError_t launch_fft_r32(const float *iq, const BatchCursor *cur, const fft64::cplx *tw, float *psd, int n_frames, int n_bands,
+                          int in_stride, int out_stride, FftTap tap, hipStream_t stream);
+int r32_twiddle_count();
+void r32_build_twiddles(const double *wre, const double *wim, fft64::cplx *out);
 hipError_t launch_window_means(const float *psd, double *win_mean, NoiseGeom g, int n_frames, int n_bands, int stride,
                                hipStream_t stream);
 hipError_t launch_noise_stats(const float *psd, const double *win_mean, sdr_frame_rec *recs, NoiseGeom g, int n_frames,

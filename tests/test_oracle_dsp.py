@@ -376,6 +376,23 @@ def test_fft_phase_functions_match_oracle_bit_for_bit(tmp_path, layout_b_from):
     assert ("layout B" in out.stdout) == (layout_b_from <= 14)
 
 
+def test_fft_r32_plan_matches_oracle_bit_for_bit(tmp_path):
+    """The 32-points-per-thread plan of the N = 16384 FFT (fft_r32.h: 512 threads, 5 + 5 + 4 stages, the cross-wave exchange
+    behind pass 0, a wave-local one behind pass 1, the psd row through LDS), emulated thread by thread on the CPU against
+    the oracle's stage-by-stage radix-2 FFT; every LDS map audited against the MI355X banking rules, the input loads and
+    pass-2 twiddle rows for contiguity per wave instruction."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "emu_fft_r32")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-o", exe,
+                           os.path.join(root, "tests", "emu", "emu_fft_r32.cpp"), "-ldl"])
+    out = subprocess.run([exe, orc.build()], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count(": 0 mismatches") == 2
+    assert out.stdout.count("worst write 1-way, worst read 1-way") == 2
+
+
 def test_kiwi_iq_bytes_decode():
     # kiwi/client.go:298-308: big-endian int16 / 32767 in float32, after a 17-byte header
     vals = np.array([0, 1, -1, 32767, -32768, 12345, -12345, 256, 255], np.int16)

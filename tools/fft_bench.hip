@@ -31,6 +31,7 @@ __device__ unsigned long long g_fft_wg[2048][4];
 }  // namespace sdr
 #endif
 #include "../sdrainer_amd/csrc/k_fft_psd.hip"
+#include "../sdrainer_amd/csrc/k_fft_r32.hip"  // (launch_fft routes N = 16384 to it; SDR_FFT_R32=0 keeps the 16-point kernel)
 #include "../sdrainer_amd/csrc/twiddles.h"
 
 static unsigned long long fnv(const void *p, size_t n)
