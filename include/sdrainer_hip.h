@@ -289,7 +289,8 @@ int sdr_read_drop_counters(sdr_bank *bank, uint64_t *runes_dropped, uint64_t *ed
  * their own (allocated at capture), so that consecutive replays overlap stage by stage like consecutive eager batches.
  * Needs a bank on a real stream (sdr_set_stream with a non-null stream) and, once captured, all processing to go
  * through sdr_graph_launch (sdr_process_* return SDR_ERR_STATE until sdr_graph_release).  Attaching or detaching a
- * listener invalidates the capture (capture again).  Results are read / polled exactly as after sdr_process_device;
+ * listener, sdr_enable_results and sdr_set_find_peaks invalidate the capture (sdr_graph_launch returns SDR_ERR_STATE:
+ * capture again).  Results are read / polled exactly as after sdr_process_device;
  * the "last batch" of the read calls is the last replay's last. */
 int sdr_graph_batches(sdr_bank *bank);
 int sdr_graph_capture(sdr_bank *bank, int n_frames);

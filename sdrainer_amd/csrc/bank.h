@@ -199,6 +199,10 @@ struct sdr_bank {
     bool graph_ready = false;
     int graph_frames = 0, graph_slots = 0;
     uint64_t attach_gen = 0, graph_attach_gen = 0;  // sdr_attach / sdr_detach calls so far; as of the capture
+    // what the captured graphs have baked in besides the listeners: the packing kernels exist only if results were on, the
+    // refinement / peak-scan nodes only if find_peaks was
+    bool graph_results_on = false;
+    int graph_find_peaks = 0;
     // deferred listen half (sdr_defer_listen): the batch whose spectra exist and whose listeners have not run yet
     bool defer_listen = false, listen_pending = false;
     struct PendingListen {

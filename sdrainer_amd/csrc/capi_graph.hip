@@ -229,6 +229,8 @@ int sdr_graph_capture(sdr_bank *b, int n_frames)
     b->graph_frames = n_frames;
     b->graph_slots = max_slots;
     b->graph_attach_gen = b->attach_gen;
+    b->graph_results_on = b->results_on;
+    b->graph_find_peaks = b->find_peaks;
     return SDR_OK;
 }
 
@@ -245,6 +247,10 @@ int sdr_graph_launch(sdr_bank *b, const float *const *iq_dev)
         max_slots = std::max(max_slots, b->n_slots[i]);
     if (max_slots != b->graph_slots || b->attach_gen != b->graph_attach_gen)
         return fail(SDR_ERR_STATE, "listeners were attached or detached since the capture: capture again");
+    // the kernels that pack results, refine the cumulation and scan for peaks are nodes of the captured graphs or they are
+    // not: a replay after sdr_enable_results / sdr_set_find_peaks changed either would publish batches no kernel fills
+    if (b->results_on != b->graph_results_on || b->find_peaks != b->graph_find_peaks)
+        return fail(SDR_ERR_STATE, "sdr_enable_results / sdr_set_find_peaks changed since the capture: capture again");
     HIP_TRY(hipSetDevice(b->device));
     static const bool dbg = getenv("SDR_GRAPH_DEBUG") != nullptr;
     double tdbg[8] = {};

@@ -237,8 +237,14 @@ SDR_HD inline void load_chunk(TW &tw, double (&wr)[CHMAX], double (&wi)[CHMAX])
     }
 }
 
-template <int NST, bool P0, int CHUNK, int Q, int C, int CHMAX>
-SDR_HD inline void compute_chunk(double *xr, double *xi, const double (&wr)[CHMAX], const double (&wi)[CHMAX])
+struct NoButterflyHook {
+    SDR_HD void operator()(int, int) const {}
+};
+
+// bf(a, b) is called behind each butterfly (a, b) of the pass's LAST stage: slots a and b are final for the pass from
+// then on (the kernel writes them into the exchange that follows while the stage's other butterflies compute)
+template <int NST, bool P0, int CHUNK, int Q, int C, int CHMAX, class BF>
+SDR_HD inline void compute_chunk(double *xr, double *xi, const double (&wr)[CHMAX], const double (&wi)[CHMAX], BF &bf)
 {
     constexpr int ROWS = 1 << Q;
     constexpr int GROUPS = R >> NST;
@@ -274,14 +280,17 @@ SDR_HD inline void compute_chunk(double *xr, double *xi, const double (&wr)[CHMA
             xi[a] = ai + ti;
             xr[b] = ar - tr;
             xi[b] = ai - ti;
+            if constexpr (Q == NST - 1)
+                bf(a, b);
         }
     }
 }
 
 // chunk (Q, C) with its twiddles in (wr, wi): request the NEXT chunk's twiddles, compute this one, fence, go on.  The
 // requests of a chunk are thus one chunk's arithmetic ahead of their use, in program order, whatever the scheduler does.
-template <int NST, bool P0, int CHUNK, int Q, int C, int CHMAX, class TW, class HOOK>
-SDR_HD inline void pass_chunks_from(double *xr, double *xi, TW &tw, HOOK &hook, const double (&wr)[CHMAX], const double (&wi)[CHMAX])
+template <int NST, bool P0, int CHUNK, int Q, int C, int CHMAX, class TW, class HOOK, class BF>
+SDR_HD inline void pass_chunks_from(double *xr, double *xi, TW &tw, HOOK &hook, BF &bf, const double (&wr)[CHMAX],
+                                    const double (&wi)[CHMAX])
 {
     constexpr int ROWS = 1 << Q;
     constexpr int GROUPS = R >> NST;
@@ -292,23 +301,90 @@ SDR_HD inline void pass_chunks_from(double *xr, double *xi, TW &tw, HOOK &hook, 
     double nwr[CHMAX], nwi[CHMAX];
     if constexpr (NQ < NST)
         load_chunk<NST, P0, CHUNK, NQ, NC, CHMAX>(tw, nwr, nwi);
-    compute_chunk<NST, P0, CHUNK, Q, C, CHMAX>(xr, xi, wr, wi);
+    compute_chunk<NST, P0, CHUNK, Q, C, CHMAX>(xr, xi, wr, wi, bf);
     if constexpr (LAST)
         hook(Q);
     if (CHUNK > 0)
         SDR_R32_FENCE();
     if constexpr (NQ < NST)
-        pass_chunks_from<NST, P0, CHUNK, NQ, NC, CHMAX>(xr, xi, tw, hook, nwr, nwi);
+        pass_chunks_from<NST, P0, CHUNK, NQ, NC, CHMAX>(xr, xi, tw, hook, bf, nwr, nwi);
+}
+
+// The same two chunks deep (pass 2: a chunk's arithmetic - four butterflies, 160 clocks - is a quarter of the L2 round
+// trip its successor's twiddles need): chunk (Q, C) in (wr, wi), its successor in (nwr, nwi), the one after that is
+// requested here.
+struct ChunkId {
+    int q, c;
+};
+template <int NST, int CHUNK>
+SDR_HD constexpr ChunkId next_chunk(ChunkId k)
+{
+    const int total = (1 << k.q) * (R >> NST);
+    const int ch = (CHUNK > 0 && CHUNK < total) ? CHUNK : total;
+    return (k.c + 1 == total / ch) ? ChunkId{k.q + 1, 0} : ChunkId{k.q, k.c + 1};
+}
+template <int NST, bool P0, int CHUNK, int Q, int C, int CHMAX, class TW, class HOOK, class BF>
+SDR_HD inline void pass_chunks2_from(double *xr, double *xi, TW &tw, HOOK &hook, BF &bf, const double (&wr)[CHMAX],
+                                     const double (&wi)[CHMAX], const double (&nwr)[CHMAX], const double (&nwi)[CHMAX])
+{
+    constexpr ChunkId N1 = next_chunk<NST, CHUNK>(ChunkId{Q, C});
+    constexpr ChunkId N2 = next_chunk<NST, CHUNK>(N1);
+    double nnwr[CHMAX], nnwi[CHMAX];
+    if constexpr (N1.q < NST && N2.q < NST)
+        load_chunk<NST, P0, CHUNK, N2.q, N2.c, CHMAX>(tw, nnwr, nnwi);
+    compute_chunk<NST, P0, CHUNK, Q, C, CHMAX>(xr, xi, wr, wi, bf);
+    if constexpr (N1.q != Q)
+        hook(Q);
+    if (CHUNK > 0)
+        SDR_R32_FENCE();
+    if constexpr (N1.q < NST)
+        pass_chunks2_from<NST, P0, CHUNK, N1.q, N1.c, CHMAX>(xr, xi, tw, hook, bf, nwr, nwi, nnwr, nnwi);
 }
 
 // hook(q) is called behind the last butterfly of stage q (the kernel hangs its input prefetch there)
-template <int NST, bool P0, int CHUNK = 0, class TW, class HOOK = NoStageHook>
-SDR_HD inline void run_pass(double *xr, double *xi, TW tw, HOOK hook = HOOK{})
+template <int NST, int CHUNK>
+inline constexpr int kChunkMax = CHUNK > 0 ? CHUNK : (R >> NST) << (NST - 1);
+
+// The pass's first chunk of twiddles can be requested ahead of the pass (pass 2's come from L2: behind the exchange in
+// front of it the wave would sit out a full round trip): first_chunk() in front of the exchange, run_pass_with() behind.
+template <int NST, int CHUNK>
+struct FirstChunk {
+    double wr[kChunkMax<NST, CHUNK>], wi[kChunkMax<NST, CHUNK>];
+};
+template <int NST, bool P0, int CHUNK, class TW>
+SDR_HD inline void first_chunk(TW tw, FirstChunk<NST, CHUNK> &f)
 {
-    constexpr int CHMAX = CHUNK > 0 ? CHUNK : (R >> NST) << (NST - 1);
-    double wr[CHMAX], wi[CHMAX];
-    load_chunk<NST, P0, CHUNK, 0, 0, CHMAX>(tw, wr, wi);
-    pass_chunks_from<NST, P0, CHUNK, 0, 0, CHMAX>(xr, xi, tw, hook, wr, wi);
+    load_chunk<NST, P0, CHUNK, 0, 0, kChunkMax<NST, CHUNK>>(tw, f.wr, f.wi);
+}
+template <int NST, bool P0, int CHUNK, class TW, class HOOK = NoStageHook, class BF = NoButterflyHook>
+SDR_HD inline void run_pass_with(double *xr, double *xi, const FirstChunk<NST, CHUNK> &f, TW tw, HOOK hook = HOOK{}, BF bf = BF{})
+{
+    pass_chunks_from<NST, P0, CHUNK, 0, 0, kChunkMax<NST, CHUNK>>(xr, xi, tw, hook, bf, f.wr, f.wi);
+}
+// two chunks deep
+template <int NST, int CHUNK>
+struct FirstChunks2 {
+    double wr[kChunkMax<NST, CHUNK>], wi[kChunkMax<NST, CHUNK>], nwr[kChunkMax<NST, CHUNK>], nwi[kChunkMax<NST, CHUNK>];
+};
+template <int NST, bool P0, int CHUNK, class TW>
+SDR_HD inline void first_chunks2(TW tw, FirstChunks2<NST, CHUNK> &f)
+{
+    constexpr ChunkId N1 = next_chunk<NST, CHUNK>(ChunkId{0, 0});
+    static_assert(N1.q < NST, "a pass of one chunk has no second one");
+    load_chunk<NST, P0, CHUNK, 0, 0, kChunkMax<NST, CHUNK>>(tw, f.wr, f.wi);
+    load_chunk<NST, P0, CHUNK, N1.q, N1.c, kChunkMax<NST, CHUNK>>(tw, f.nwr, f.nwi);
+}
+template <int NST, bool P0, int CHUNK, class TW, class HOOK = NoStageHook, class BF = NoButterflyHook>
+SDR_HD inline void run_pass2_with(double *xr, double *xi, const FirstChunks2<NST, CHUNK> &f, TW tw, HOOK hook = HOOK{}, BF bf = BF{})
+{
+    pass_chunks2_from<NST, P0, CHUNK, 0, 0, kChunkMax<NST, CHUNK>>(xr, xi, tw, hook, bf, f.wr, f.wi, f.nwr, f.nwi);
+}
+template <int NST, bool P0, int CHUNK = 0, class TW, class HOOK = NoStageHook, class BF = NoButterflyHook>
+SDR_HD inline void run_pass(double *xr, double *xi, TW tw, HOOK hook = HOOK{}, BF bf = BF{})
+{
+    FirstChunk<NST, CHUNK> f;
+    first_chunk<NST, P0, CHUNK>(tw, f);
+    run_pass_with<NST, P0, CHUNK>(xr, xi, f, tw, hook, bf);
 }
 
 // element (of the pass-1 twiddle block) a pass-1 thread reads for row r: its index bits 0-4

@@ -12,6 +12,7 @@
 #include "../../include/sdrainer_hip.h"
 #include "cw_decoder.h"
 #include "fft_f64.h"
+#include "fft_r32.h"
 #include "gomath.h"
 #include "sdr_device.h"
 
@@ -1024,7 +1025,7 @@ hipError_t launch_fft(int logn, const float *iq, const BatchCursor *cur, const f
 {
     if (logn == 14) {
         const int mode = r32_mode();
-        if (mode == 1 || (mode < 0 && (long)n_frames * n_bands >= 512))
+        if (tap.n <= fft32::T && (mode == 1 || (mode < 0 && (long)n_frames * n_bands >= 512)))
             return launch_fft_r32(iq, cur, tw + fft64::Plan<14>::TW_TOTAL, psd, n_frames, n_bands, in_stride, out_stride, tap, stream);
     }
     switch (logn) {

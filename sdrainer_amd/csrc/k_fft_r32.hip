@@ -41,10 +41,22 @@
 // (first build: 13 000 of a frame's 44 000 clocks went into issuing them).  Nothing after pass 1's stage 3: the last
 // group needs time to land before pass 2's twiddle loads, which return behind it (vector memory retires in order).
 #if !defined(SDR_R32_PF_PLAN)
-#define SDR_R32_PF_PLAN {4, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2}
+#define SDR_R32_PF_PLAN {4, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 0, 0}
+#endif
+// Issue priority, alternating between the two waves of a SIMD stage by stage (1; 0 = leave it to the hardware).  The
+// arbiter serves the OLDER of two waves first: waves 0-3 ran a pass at the pace of a wave alone on its SIMD (6.3 clocks per
+// float64 instruction) while their partners got 40 % of that, finished the frame 6 000 clocks early and sat at the row's
+// barrier while the partners finished alone, again at the single-wave pace.  Two waves issuing side by side manage 4.5 -
+// 4.8 clocks per instruction between them (tools/ubench_f64: 29 against 22 T lane-operations/s), but only while both have
+// arithmetic to issue: taking turns at the higher priority keeps them within a stage of each other.
+#if !defined(SDR_R32_PRIO)
+#define SDR_R32_PRIO 1
+#endif
+#if !defined(SDR_R32_DEPTH2)
+#define SDR_R32_DEPTH2 1  // pass 2: twiddles requested this many chunks ahead of their butterflies (1 or 2)
 #endif
 #if !defined(SDR_R32_CHUNK1)
-#define SDR_R32_CHUNK1 4  // twiddles fetched per chunk in pass 1 (0: the compiler decides - and spills)
+#define SDR_R32_CHUNK1 2  // twiddles fetched per chunk in pass 1 (0: the compiler decides - and spills; 4 / 4 / 4 spills prefetched samples)
 #endif
 #if !defined(SDR_R32_CHUNK2)
 #define SDR_R32_CHUNK2 4
@@ -103,7 +115,7 @@ struct R32Stamps {
     } while (0)
 #endif
 
-constexpr int kPfPoints = 15;
+constexpr int kPfPoints = 17;
 constexpr int kPfPlan[kPfPoints] = SDR_R32_PF_PLAN;
 constexpr int pf_begin(int point)
 {
@@ -113,13 +125,82 @@ constexpr int pf_begin(int point)
     return b;
 }
 static_assert(pf_begin(kPfPoints) == fft32::R, "the prefetch plan must cover the frame's 32 slots");
-enum PfPoint { PF_WIDENED = 0, PF_PASS0 = 1 /* +q */, PF_E0 = 6 /* +step */, PF_PRE1 = 10, PF_PASS1 = 11 /* +q */ };
+// the previous frame's eight row stores per thread, dealt over the first program points
+constexpr int kStorePoints = 7;
+#if !defined(SDR_R32_ST_PLAN)
+#define SDR_R32_ST_PLAN {2, 1, 1, 1, 1, 1, 1}
+#endif
+constexpr int kStPlan[kStorePoints] = SDR_R32_ST_PLAN;
+constexpr int st_begin(int point)
+{
+    int b = 0;
+    for (int i = 0; i < point; i++)
+        b += kStPlan[i];
+    return b;
+}
+static_assert(st_begin(kStorePoints) == fft32::N / 4 / fft32::T, "the store plan must cover the row's eight runs per thread");
+enum PfPoint { PF_WIDENED = 0, PF_PASS0 = 1 /* +q */, PF_E0 = 6 /* +step */, PF_PRE1 = 10, PF_PASS1 = 11 /* +q */, PF_POST2 = 15, PF_ROW = 16 };
 
 constexpr int kTw1LdsBytes = fft32::kTw1Entries * 16;
-constexpr int kLdsBytes = fft32::kExchangeBytes + kTw1LdsBytes;
-static_assert(kLdsBytes <= 160 * 1024, "LDS of one workgroup");
-static_assert(fft32::kExchangeBytes % 16 == 0, "the twiddle block is read with ds_read_b128");
-static_assert(fft32::N * 4 <= fft32::kExchangeBytes, "the psd row lives in the exchange area");
+constexpr int kSoftCounters = 4;
+constexpr int kLdsBytes = fft32::kExchangeBytes + kTw1LdsBytes + kSoftCounters * 4;
+// "Soft" barriers for the write-after-read hazards of the shared exchange area: a wave ARRIVES (one LDS add) when it has
+// read what it wanted and WAITS (polls the counter) right before it writes - a whole pass later, when everybody has long
+// arrived.  An s_barrier there would make the wave that is ahead sit out the other's pass: with two waves per SIMD the
+// overlap of one wave's exchange with the other's arithmetic is all the latency hiding there is.  The counters only
+// grow: eight arrivals per frame.
+enum SoftId { SOFT_ROW = 0, SOFT_E0 = 1, SOFT_E1 = 2 };
+// (Both are single asm statements: as C++ - a poll loop, a one-lane branch around the add - they cut the unrolled frame
+// into basic blocks, and the register allocator answered with 72 spilled registers, the prefetched samples first.)
+__device__ __forceinline__ void soft_arrive(unsigned *cnt)
+{
+    // this wave's LDS reads have returned their data (lgkmcnt(0)); then one lane adds 1
+    unsigned long long save;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                 "s_mov_b64 %0, exec\n\t"
+                 "s_mov_b64 exec, 1\n\t"
+                 "ds_add_u32 %1, %2\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(save)
+                 : "v"((unsigned)(unsigned long long)cnt), "v"(1u)
+                 : "memory");
+}
+__device__ __forceinline__ void soft_wait(unsigned *cnt, unsigned target)
+{
+    unsigned seen;
+    asm volatile("1:\n\t"
+                 "ds_read_b32 %0, %1\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "v_cmp_lt_u32_e32 vcc, %0, %2\n\t"
+                 "s_cbranch_vccz 2f\n\t"
+                 "s_sleep 1\n\t"
+                 "s_branch 1b\n\t"
+                 "2:"
+                 : "=&v"(seen)
+                 : "v"((unsigned)(unsigned long long)cnt), "v"(target)
+                 : "vcc", "memory");
+}
+
+// s_setprio takes an immediate, so the choice is a scalar branch - inside ONE asm statement (a C++ branch would cut the
+// frame into blocks) and on M0, which the kernel loads with 0 (waves 0-3) or 1 (waves 4-7) at its top: an SGPR operand
+// per call kept two more scalar registers live through a frame that has none to spare (90 vector registers spilled).
+// Nothing else in this kernel uses M0; should that ever change, the priorities would be off, nothing else.
+// SCC is saved and restored inside the statement instead of being declared clobbered: with the clobber the same build
+// spilled 79 vector registers (with it the compiler... whatever it does, the prefetched samples went to scratch).
+__device__ __forceinline__ void set_prio(int stage)  // (a constant wherever it is called: the test folds)
+{
+#if SDR_R32_PRIO
+    unsigned keep;
+    if (stage & 1)
+        asm volatile("s_cselect_b32 %0, 1, 0\n\ts_cmp_lg_u32 m0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 1\n\ts_branch 2f\n\t1:\n\ts_setprio 0\n\t2:\n\t"
+                     "s_cmp_lg_u32 %0, 0"
+                     : "=&s"(keep));
+    else
+        asm volatile("s_cselect_b32 %0, 1, 0\n\ts_cmp_eq_u32 m0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 1\n\ts_branch 2f\n\t1:\n\ts_setprio 0\n\t2:\n\t"
+                     "s_cmp_lg_u32 %0, 0"
+                     : "=&s"(keep));
+#endif
+}
 
 template <int E, int P>
 __device__ __forceinline__ void ex_write(const double (&x)[32], int t, double *area)
@@ -174,19 +255,56 @@ __global__ __launch_bounds__(fft32::T, 2) void k_fft_r32(const float *__restrict
         const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(twr, (unsigned)i * 16u, kTw1 * 16, 0);
         *reinterpret_cast<u32x4 *>(smem + kExchangeBytes + i * 16) = w;
     }
-    // the listeners' bins: slot l of the band belongs to thread l (more than 512: the loop at the end of a frame)
-    const int *bins = tap_bins + (size_t)blockIdx.y * tap_stride;
+    // the listeners' bins: slot l of the band belongs to thread l (launch_fft_r32 refuses more than 512 slots in use: those
+    // banks run the 16-point kernel)
     const bool reg_tap = n_tap > 0 && n_tap <= T;
-    const int my_bin = (reg_tap && tid < n_tap) ? bins[tid] : -1;
+    const int my_bin = (reg_tap && tid < n_tap) ? tap_bins[(size_t)blockIdx.y * tap_stride + tid] : -1;
+    unsigned *soft = reinterpret_cast<unsigned *>(smem + kExchangeBytes + kTw1LdsBytes);  // arrival counters, see soft_wait
+    if (tid < kSoftCounters)
+        soft[tid] = 0;
     __syncthreads();
     R32Stamps st;
 #if defined(SDR_R32_PHASES)
     st.on = false;
     st.v = 0;
 #endif
+    // A frame's psd row leaves the CU at the top of the NEXT frame: its eight 16-byte runs per thread (and the thread's
+    // tap value) wait in registers while the next frame's samples are widened - a phase bound by the conversions' issue
+    // rate, with the memory pipeline idle - instead of holding every wave at the end of the frame (first build: 2 700
+    // clocks per frame for the CU to take 64 KB of stores).
+    u32x4 sv[N / 4 / T];
+    float tapv = 0.f;
+#pragma unroll
+    for (int j = 0; j < N / 4 / T; j++)
+        sv[j] = u32x4{0u, 0u, 0u, 0u};
+    // (frame < frame0: descriptors of zero bytes, nothing is stored.  The run's offset goes into the VECTOR offset, the
+    // scalar offset stays the literal 0: a 16-byte buffer store reads its data registers some cycles after it issues; with
+    // an immediate scalar offset hipcc pads a following VALU write of those registers with wait states, with an SGPR
+    // offset it assumes no hazard - and on gfx950 there is one: built that way, 0.3 % of the psd words of every launch
+    // came out as the next run's LDS address, which the compiler had put into the first data register behind the store.)
+    // stores [j0, j1) of the eight (tap: the tap value with the last one)
+    auto flush_row = [&](int frame, int t, int j0, int j1) {
+        const bool live = frame >= frame0;
+        const rsrc_t pdr = make_rsrc(psd + (out_band + (live ? frame : frame0)) * (size_t)N, live ? N * 4u : 0u);
+#pragma unroll
+        for (int j = 0; j < N / 4 / T; j++)
+            if (j >= j0 && j < j1)
+                __builtin_amdgcn_raw_buffer_store_b128(sv[j], pdr, (unsigned)(t + T * j) * 16u, 0, 0);
+        if (j1 == N / 4 / T) {
+            // the tap (rx/receiver.go:393-394: spectrum[SignalBin] per listener and frame; the dB projection is applied
+            // where it is consumed, k_listen.hip): slot l's value from thread l; lanes past n_tap fall outside the descriptor
+            const rsrc_t tpr = make_rsrc(tap_out + (out_band + (live ? frame : frame0)) * (size_t)tap_stride,
+                                         (live && reg_tap) ? (unsigned)n_tap * 4u : 0u);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tapv), tpr, (unsigned)t * 4u, 0, 0);
+        }
+    };
 
+#if SDR_R32_PRIO
+    asm volatile("s_mov_b32 m0, %0" ::"s"(__builtin_amdgcn_readfirstlane(tid >> 8)) : "m0");  // waves 0-3 / 4-7: a SIMD has one of each
+#endif
+    int it = 0;  // frames this workgroup has finished (the soft barriers' targets count in it)
 #pragma nounroll
-    for (int frame = frame0; frame < frame_end; frame++) {
+    for (int frame = frame0; frame < frame_end; frame++, it++) {
         // (everything derived from the thread id is loop-invariant; hoisted, it would sit in registers the frame needs)
         int t = tid;
         asm volatile("" : "+v"(t));
@@ -204,26 +322,46 @@ __global__ __launch_bounds__(fft32::T, 2) void k_fft_r32(const float *__restrict
             xr[m] = (double)__uint_as_float(pf[m].x);
             xi[m] = (double)__uint_as_float(pf[m].y);
         }
-        // (the requests go out BEHIND the conversions: hoisted above them - they depend on nothing - both frames' samples
-        // would be live at once, 64 registers more than there are; the pins keep the conversions from being sunk below
-        // the branch around the requests)
+        // (the next frame's requests go out BEHIND the conversions: hoisted above them - they depend on nothing - both
+        // frames' samples would be live at once, 64 registers more than there are; the pins keep the conversions from
+        // being sunk below them)
 #pragma unroll
         for (int m = 0; m < R; m++)
             asm volatile("" : "+v"(xr[m]), "+v"(xi[m]));
+        __builtin_amdgcn_sched_barrier(0);
+        // (the previous frame's row goes out a store or two at a time, at the first prefetch points: issued in one go,
+        // the CU takes 5 000 clocks to accept a frame's 72 stores, and the waves that come second sit that out)
         auto pf_point = [&](int point) {
             __builtin_amdgcn_sched_barrier(0);
+            if (point < kStorePoints)
+                flush_row(frame - 1, t, st_begin(point), st_begin(point + 1));
             fetch(frame + 1, t, pf_begin(point), pf_begin(point + 1));
             __builtin_amdgcn_sched_barrier(0);
         };
         pf_point(PF_WIDENED);
         SDR_R32_STAMP(st, RS_WIDENED);
 
-        run_pass<5, true, SDR_R32_CHUNK0>(xr, xi, [tw](int row, int) { return tw[kTw0 + row]; }, [&](int q) { pf_point(PF_PASS0 + q); });
+        // pass 0; behind its stage 3 everybody must be out of the previous frame's psd row (it shares the area with E0):
+        // they said so long ago (SOFT_ROW); the last stage then writes each finished pair's real parts into E0 while
+        // the other butterflies compute
+        {
+            const int wbase = map_addr_thread<0, 0>(t);
+            run_pass<5, true, SDR_R32_CHUNK0>(
+                xr, xi, [tw](int row, int) { return tw[kTw0 + row]; },
+                [&](int q) {
+                    set_prio(q);
+                    pf_point(PF_PASS0 + q);
+                    if (q == 3)
+                        soft_wait(soft + SOFT_ROW, (unsigned)(NWAVES * it));
+                },
+                [&](int a, int b) {
+                    ex[wbase + map_addr_slot<0>(0, a)] = xr[a];
+                    ex[wbase + map_addr_slot<0>(0, b)] = xr[b];
+                });
+        }
         SDR_R32_STAMP(st, RS_PASS0);
 
-        // E0: everybody is out of the previous frame's psd row (it shares the area), then real / imaginary rounds
-        __syncthreads();
-        ex_write<0, 0>(xr, t, ex);
+        // E0: real parts (written above) read, imaginary parts written and read
         pf_point(PF_E0 + 0);
         __syncthreads();
         ex_read<0, 1>(xr, t, ex);
@@ -234,47 +372,72 @@ __global__ __launch_bounds__(fft32::T, 2) void k_fft_r32(const float *__restrict
         __syncthreads();
         ex_read<0, 1>(xi, t, ex);
         pf_point(PF_E0 + 3);
-        __syncthreads();  // E1 writes the wave's own block, which other waves have just read from
+        soft_arrive(soft + SOFT_E0);  // this wave has what it wanted from E0 (E1 writes blocks other waves read here)
         SDR_R32_STAMP(st, RS_E0);
         pf_point(PF_PRE1);
 
+        // pass 1 (twiddles from LDS); its last stage writes the real parts into E1, the wave's own block - once every
+        // wave has left E0 (SOFT_E0, waited for behind stage 3)
         {
             const unsigned char *row0 = tw1_lds + tw1_lo(t) * 16;
+            const int wbase = map_addr_thread<1, 1>(t);
             run_pass<5, false, SDR_R32_CHUNK1>(
                 xr, xi, [row0](int row, int) { return *reinterpret_cast<const cplx *>(row0 + row * 512); },
                 [&](int q) {
+                    set_prio(q);
                     if (q < 4)
                         pf_point(PF_PASS1 + q);
+                    if (q == 3)
+                        soft_wait(soft + SOFT_E0, (unsigned)(NWAVES * (it + 1)));
+                },
+                [&](int a, int b) {
+                    ex[wbase + map_addr_slot<1>(1, a)] = xr[a];
+                    ex[wbase + map_addr_slot<1>(1, b)] = xr[b];
                 });
         }
-
         SDR_R32_STAMP(st, RS_PASS1);
+        // pass 2's twiddles stream from L2; its first two are requested here, in front of E1
+        const unsigned tw2_off = (unsigned)tw2_pos(t, 0) * 16u;
+        auto tw2 = [twr, tw2_off](int row, int u) {
+            const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(twr, tw2_off, (kTw2 + row * 1024 + u * 512) * 16, 0);
+            cplx r;
+            r.x = __hiloint2double((int)w.y, (int)w.x);
+            r.y = __hiloint2double((int)w.w, (int)w.z);
+            return r;
+        };
+#if SDR_R32_DEPTH2 == 2
+        FirstChunks2<4, SDR_R32_CHUNK2> tw2_first;
+        first_chunks2<4, false, SDR_R32_CHUNK2>(tw2, tw2_first);
+#else
+        FirstChunk<4, SDR_R32_CHUNK2> tw2_first;
+        first_chunk<4, false, SDR_R32_CHUNK2>(tw2, tw2_first);
+#endif
         // E1: inside the wave's own block
-        ex_write<1, 1>(xr, t, ex);
         wave_sync();
         ex_read<1, 2>(xr, t, ex);
         wave_sync();
         ex_write<1, 1>(xi, t, ex);
         wave_sync();
         ex_read<1, 2>(xi, t, ex);
+        soft_arrive(soft + SOFT_E1);  // this wave is out of E1 (the psd row is written all over the area)
         SDR_R32_STAMP(st, RS_E1);
 
-        {
-            const unsigned p0 = (unsigned)tw2_pos(t, 0) * 16u;
-            run_pass<4, false, SDR_R32_CHUNK2>(xr, xi, [twr, p0](int row, int u) {
-                const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(twr, p0, (kTw2 + row * 1024 + u * 512) * 16, 0);
-                cplx r;
-                r.x = __hiloint2double((int)w.y, (int)w.x);
-                r.y = __hiloint2double((int)w.w, (int)w.z);
-                return r;
-            });
-        }
-
+#if SDR_R32_DEPTH2 == 2
+        run_pass2_with<4, false, SDR_R32_CHUNK2>(xr, xi, tw2_first, tw2, [&](int q) { set_prio(q); });
+#else
+        run_pass_with<4, false, SDR_R32_CHUNK2>(xr, xi, tw2_first, tw2, [&](int q) { set_prio(q); });
+#endif
+        pf_point(PF_POST2);
         SDR_R32_STAMP(st, RS_PASS2);
+
         // Epilogue (dsp/fft.go:54-57 fftshift, :71-73 PSD[float32]): psd[k] = float32(re^2 + im^2), two multiplies and
-        // an add in float64, rounded once; into the LDS row at spectrum index k = bin ^ N/2
-        __syncthreads();  // every wave is out of E1
+        // an add in float64, rounded once; into the LDS row at spectrum index k = bin ^ N/2 once every wave is out of E1
         {
+            float p[R];
+#pragma unroll
+            for (int s = 0; s < R; s++)
+                p[s] = (float)(xr[s] * xr[s] + xi[s] * xi[s]);
+            soft_wait(soft + SOFT_E1, (unsigned)(NWAVES * (it + 1)));
             constexpr int SLOT_MASK = slot_part(2, R - 1);
             static_assert((SLOT_MASK & 0xfc) == 0, "the row swizzle reads thread bits only");
             const int tk = thread_part<2>(t) ^ ((N / 2) & ~SLOT_MASK);
@@ -282,46 +445,31 @@ __global__ __launch_bounds__(fft32::T, 2) void k_fft_r32(const float *__restrict
 #pragma unroll
             for (int s = 0; s < R; s++) {
                 const int sk = slot_part(2, s) ^ ((N / 2) & SLOT_MASK);
-                const float p = (float)(xr[s] * xr[s] + xi[s] * xi[s]);
-                *reinterpret_cast<float *>(rowp + sk * 4) = p;
+                *reinterpret_cast<float *>(rowp + sk * 4) = p[s];
             }
         }
         __syncthreads();
         SDR_R32_STAMP(st, RS_ROW);
+        pf_point(PF_ROW);
         {
-            const rsrc_t pdr = make_rsrc(psd + (out_band + frame) * (size_t)N, N * 4u);
+            // this thread's eight 16-byte runs of the row and its listener's bin, into registers; they leave at the top
+            // of the next frame (or behind the loop)
 #pragma unroll
-            for (int j = 0; j < N / 4 / T; j++) {
-                const int c = t + T * j;  // 16-byte chunk of the row
-                const u32x4 v = *reinterpret_cast<const u32x4 *>(smem + row_word(4 * c) * 4);
-                // (the chunk's offset goes into the VECTOR offset, the scalar offset stays the literal 0.  A 16-byte buffer
-                // store reads its data registers some cycles after it issues; with an immediate scalar offset hipcc pads
-                // a following VALU write of those registers with wait states, with an SGPR offset it assumes no hazard -
-                // and on gfx950 there is one: built that way, 0.3 % of the psd words of every launch came out as the
-                // next chunk's LDS address, which the compiler had put into the first data register right behind the
-                // store.)
-                __builtin_amdgcn_raw_buffer_store_b128(v, pdr, (unsigned)c * 16u, 0, 0);
-            }
-            // the tap (rx/receiver.go:393-394: spectrum[SignalBin] per listener and frame; the dB projection is applied
-            // where it is consumed, k_listen.hip)
+            for (int j = 0; j < N / 4 / T; j++)
+                sv[j] = *reinterpret_cast<const u32x4 *>(smem + row_word(4 * (t + T * j)) * 4);
             const float *row = reinterpret_cast<const float *>(smem);
-            float *out = tap_out + (out_band + frame) * (size_t)tap_stride;
-            if (reg_tap) {
-                if (tid < n_tap)
-                    out[tid] = my_bin >= 0 ? row[row_word(my_bin)] : 0.0f;
-            } else {
-                for (int l = tid; l < n_tap; l += T) {
-                    const int bin = bins[l];
-                    out[l] = bin >= 0 ? row[row_word(bin)] : 0.0f;
-                }
-            }
+            // (a free slot, bin -1, reads word 0 and stores 0)
+            const float tv = row[row_word(my_bin & (N - 1))];
+            tapv = my_bin >= 0 ? tv : 0.0f;
         }
+        soft_arrive(soft + SOFT_ROW);  // this wave is out of the row
         SDR_R32_STAMP(st, RS_STORED);
 #if defined(SDR_R32_PHASES)
         if (st.on && (threadIdx.x & 63) < RS_COUNT)
             g_r32_phases[threadIdx.x >> 6][threadIdx.x & 63] = st.v;
 #endif
     }
+    flush_row(frame_end - 1, tid, 0, N / 4 / T);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -361,6 +509,8 @@ hipError_t launch_fft_r32(const float *iq, const BatchCursor *cur, const fft64::
         return attr_err;
     if (n_frames <= 0 || n_bands <= 0)
         return hipSuccess;
+    if (tap.n > fft32::T)
+        return hipErrorInvalidValue;  // (launch_fft never asks: one listener slot per thread)
     // a workgroup's frames are consecutive; never fewer workgroups than the chip has CUs
     int fpw = r32_fpw();
     while (fpw > 1 && (long)((n_frames + fpw - 1) / fpw) * n_bands < 256)

@@ -215,8 +215,11 @@ static int check(orc_iq_fft_t orc_fft, unsigned seed)
     }
     for (int t = 0; t < T; t++) {
         const int p0 = tw2_pos(t, 0), p1 = tw2_pos(t, 1);
-        run_pass<4, false, 4>(&xr[(size_t)t * R], &xi[(size_t)t * R],
-                              [twp, p0, p1](int row, int u) { return twp[kTw2 + row * 1024 + (u ? p1 : p0)]; });
+        // (as the kernel runs it: twiddles requested two chunks ahead of their butterflies)
+        auto tw2 = [twp, p0, p1](int row, int u) { return twp[kTw2 + row * 1024 + (u ? p1 : p0)]; };
+        FirstChunks2<4, 4> first;
+        first_chunks2<4, false, 4>(tw2, first);
+        run_pass2_with<4, false, 4>(&xr[(size_t)t * R], &xi[(size_t)t * R], first, tw2);
     }
     std::vector<double> yre((size_t)N), yim((size_t)N);
     std::vector<char> seen((size_t)N, 0);

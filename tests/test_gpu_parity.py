@@ -760,6 +760,54 @@ def test_graph_mode_bit_exact(capi):
     bank.close()
 
 
+def test_graph_refuses_replay_after_results_or_find_peaks_changed(capi):
+    """Round 4's advice: the captured graphs bake in whether results are delivered (the packing kernels are nodes or they
+    are not) and whether peaks are searched (refinement / peak-scan nodes).  sdr_enable_results or sdr_set_find_peaks
+    after the capture must make sdr_graph_launch refuse (SDR_ERR_STATE: capture again) instead of publishing batches no
+    kernel fills; after a new capture the replays deliver again."""
+    import torch
+
+    n, rate, tones, per = 1024, 96000, 3, 120
+    edge = synth.default_edge_width(n)
+    bank = capi.Bank(rate, n, edge_width=edge, max_batch_frames=per, max_listeners=tones, max_peaks=128)
+    K = bank.graph_batches
+    iq, bins, _ = synth.make_band(2 * K * per, rate, n, tones, seed=909)
+    ref = orc.Receiver(rate, n, edge, 15.0, 1, center_frequency=10100000)
+    bank.set_center_frequency(0, 10100000)
+    stream = torch.cuda.Stream()
+    bank.set_stream(stream.cuda_stream)
+    for b in bins:
+        assert bank.attach(0, int(b)) == ref.attach(int(b))
+    out = ref.process(iq)
+    dev = torch.from_numpy(iq).cuda()
+    torch.cuda.synchronize()
+    bank.graph_capture(per)  # captured WITHOUT results
+    bank.enable_results(True)
+    ptrs = [dev[k * per].data_ptr() for k in range(K)]
+    with pytest.raises(capi.SdrError) as ei:
+        bank.graph_launch(ptrs)
+    assert ei.value.code == capi.ERR_STATE
+    bank.graph_release()
+    bank.graph_capture(per)  # now with them
+    bank.set_find_peaks(False)
+    with pytest.raises(capi.SdrError) as ei:
+        bank.graph_launch(ptrs)
+    assert ei.value.code == capi.ERR_STATE
+    bank.set_find_peaks(True)
+    text = ["" for _ in range(tones)]
+    for rep in range(2):
+        bank.graph_launch([dev[(rep * K + k) * per].data_ptr() for k in range(K)])
+        for k in range(K):
+            res = bank.poll(wait=True)
+            a = (rep * K + k) * per
+            _check_delivery(res, out, a, a + per, tones, text)
+    bank.sync()
+    for lid in range(tones):
+        assert text[lid] == ref.text(lid)
+    bank.graph_release()
+    bank.close()
+
+
 def test_graph_release_with_many_unpolled_replays(capi):
     """Round 3's review: more than GRAPH_PHASES * RING (24) undelivered batches at sdr_graph_release used to be parked out of
     order (the set index wraps) and delivery stalled with 'results ... not where they should be'.  Five replays (30

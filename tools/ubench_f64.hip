@@ -141,6 +141,7 @@ int main()
                (double)h * 10.0 / (65536.0 * 16) * 2.4);
     }
     throughput(out, cyc, 256, 1024);
+    throughput(out, cyc, 256, 512);
     throughput(out, cyc, 256, 256);
     throughput(out, cyc, 64, 1024);
     for (int rep = 0; rep < 2; rep++) {
