@@ -92,7 +92,8 @@ enum Stage { S_FFT = 0, S_NOISE, S_LISTEN, S_PEAKS, N_STAGES };  // the bank's s
 struct BatchSet {
     DevBuf<float> psd;                // [band][max_batch][N] float32(re^2 + im^2), fft-shifted
     DevBuf<float> tap;                // [band][max_batch][L] psd of each listener slot's bin
-    DevBuf<double> win_mean;          // [band][max_batch][10]
+    DevBuf<double> win_mean;          // [band][max_batch][20]: k_psd_scan's S1, S2 per window (the chain kernels: 10 window means)
+    DevBuf<unsigned> exact_list;      // [1 + band * max_batch]: frames whose FindNoiseFloor takes the literal loops (count first)
     DevBuf<sdr_frame_rec> recs;       // [band][max_batch]
     DevBuf<uint64_t> raw_bits, bits;  // [band][L][bit_words] before / after the debouncer
     DevBuf<sdr_edge> edges;           // [band][L][edge_cap]
@@ -111,6 +112,7 @@ struct BatchSet {
         psd.release();
         tap.release();
         win_mean.release();
+        exact_list.release();
         recs.release();
         raw_bits.release();
         bits.release();

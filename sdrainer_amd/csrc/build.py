@@ -12,8 +12,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libsdrainer_hip.so")
-SOURCES = ["k_fft_psd.hip", "k_fft_r32.hip", "k_noise.hip", "k_listen.hip", "k_peaks.hip", "k_unpack.hip", "k_results.hip", "capi_bank.hip", "capi_process.hip", "capi_results.hip", "capi_graph.hip", "capi_read.hip", "sdr_audio.hip"]
-HEADERS = ["sdr_device.h", "bank.h", "host/delivery.h", "fft_f64.h", "fft_r32.h", "gomath.h", "cw_decoder.h", "cw_stages.h", "twiddles.h", "host/frequency_mapping.h",
+SOURCES = ["k_fft_psd.hip", "k_fft_r32.hip", "k_noise.hip", "k_noise_scan.hip", "k_listen.hip", "k_peaks.hip", "k_unpack.hip", "k_results.hip", "capi_bank.hip", "capi_process.hip", "capi_results.hip", "capi_graph.hip", "capi_read.hip", "sdr_audio.hip"]
+HEADERS = ["sdr_device.h", "bank.h", "host/delivery.h", "fft_f64.h", "fft_r32.h", "noise_cert.h", "gomath.h", "cw_decoder.h", "cw_stages.h", "twiddles.h", "host/frequency_mapping.h",
            "../../include/sdrainer_hip.h"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",

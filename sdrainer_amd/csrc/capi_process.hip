@@ -21,6 +21,8 @@
 // deferred listen half (sdr_defer_listen ...: the spectral stages of a batch first, listeners bound to frames inside it,
 // then the listen stages) and from the staged host input (sdr_push_* / sdr_process_staged: three pinned staging sets,
 // uploads on a copy stream).
+#include <string>
+
 #include "bank.h"
 
 using namespace sdrcapi;
@@ -263,21 +265,45 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     }
     SDR_DONE(sdr::K_FFT);
 
-    // noise floor (stateless per batch), then the rolling means -> thresholds, in batch order
+    // noise floor (stateless per batch), then the rolling means -> thresholds, in batch order.
+    // Two ways (SDR_NOISE_PATH = scan | chains; scan unless told otherwise):
+    //   scan    k_noise_scan.hip: ONE pass over the psd for FindNoiseFloor's sums and - where it pays - the bounds of the
+    //           cumulations the batch completes; the reference's values where they are consumed (noise_cert.h), the
+    //           literal loops for the few frames that cannot be certified;
+    //   chains  k_noise.hip: the ordered float64 chains of rounds 1-4 (and k_cum_bound on the peaks stream).
+    static const bool scan_path = !(getenv("SDR_NOISE_PATH") && std::string(getenv("SDR_NOISE_PATH")) == "chains");
+    static const int force_exact = getenv("SDR_NOISE_FORCE_EXACT") ? atoi(getenv("SDR_NOISE_FORCE_EXACT")) : 0;  // (tests)
+    const int scan_count0 = b->cum_count;
+    int scan_slots = 1;
+    if (n_frames >= SDR_CUMULATION_SIZE - scan_count0)
+        scan_slots = 1 + (n_frames - (SDR_CUMULATION_SIZE - scan_count0) + SDR_CUMULATION_SIZE - 1) / SDR_CUMULATION_SIZE;  // (the last one may stay open)
+    if (cap)  // whatever cumulationCount the replayed batch starts at
+        scan_slots = sdr::chunks_completed(SDR_CUMULATION_SIZE - 1, n_frames) + 1;
+    const bool scan_bound = scan_path && sdr::cum_bound_pays(n_frames, B, N);
     SDR_AFTER(sdr::K_WINDOW_MEANS, sdr::K_FFT);
     {
         ProfScope ps(b, sdr::K_WINDOW_MEANS, stream_of(sdr::K_WINDOW_MEANS));
         SDR_ARM(sdr::K_WINDOW_MEANS);
-        SDR_LAUNCH(sdr::K_WINDOW_MEANS, sdr::launch_window_means(S.psd.p, S.win_mean.p, ng, n_frames, B, stride,
+        if (scan_path) {
+            const sdr::CumGeom scg{N, stride, n_frames, scan_count0, b->max_chunks};
+            SDR_LAUNCH(sdr::K_WINDOW_MEANS, sdr::launch_psd_scan(S.psd.p, S.win_mean.p, S.cum_out.p, cur, ng, scg, scan_slots, B, scan_bound,
                                                                  stream_of(sdr::K_WINDOW_MEANS)));
+        } else {
+            SDR_LAUNCH(sdr::K_WINDOW_MEANS, sdr::launch_window_means(S.psd.p, S.win_mean.p, ng, n_frames, B, stride,
+                                                                     stream_of(sdr::K_WINDOW_MEANS)));
+        }
     }
     SDR_DONE(sdr::K_WINDOW_MEANS);
     SDR_AFTER(sdr::K_NOISE_STATS, sdr::K_WINDOW_MEANS);
     {
         ProfScope ps(b, sdr::K_NOISE_STATS, stream_of(sdr::K_NOISE_STATS));
         SDR_ARM(sdr::K_NOISE_STATS);
-        SDR_LAUNCH(sdr::K_NOISE_STATS, sdr::launch_noise_stats(S.psd.p, S.win_mean.p, S.recs.p, ng, n_frames, B, stride,
-                                                               stream_of(sdr::K_NOISE_STATS)));
+        if (scan_path)
+            SDR_LAUNCH(sdr::K_NOISE_STATS, sdr::launch_noise_finish(S.psd.p, S.win_mean.p, S.recs.p, ng, n_frames, B, stride, S.exact_list.p,
+                                                                    force_exact, stream_of(sdr::K_NOISE_STATS)));
+        else
+            SDR_LAUNCH(sdr::K_NOISE_STATS, sdr::launch_noise_stats(S.psd.p, S.win_mean.p, S.recs.p, ng, n_frames, B, stride,
+                                                                   stream_of(sdr::K_NOISE_STATS)));
     }
     SDR_DONE(sdr::K_NOISE_STATS);
     SDR_AFTER(sdr::K_THRESHOLDS, sdr::K_NOISE_STATS);
@@ -356,13 +382,18 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         n_chunks = sdr::chunks_completed(SDR_CUMULATION_SIZE - 1, n_frames);
         n_slots_c = n_chunks + 1;
     }
+    // (the scan wrote the bounds of the completed cumulations on the noise stream: the carry is added to slot 0's here)
+    static const bool scan_path_c = !(getenv("SDR_NOISE_PATH") && std::string(getenv("SDR_NOISE_PATH")) == "chains");
+    const bool scan_bound_done = scan_path_c && sdr::cum_bound_pays(n_frames, B, N);
     SDR_AFTER(sdr::K_CUMULATE, sdr::K_FFT);
+    if (scan_bound_done)
+        SDR_AFTER(sdr::K_CUMULATE, sdr::K_WINDOW_MEANS);
     {
         ProfScope ps(b, sdr::K_CUMULATE, stream_of(sdr::K_CUMULATE));
         SDR_ARM(sdr::K_CUMULATE);
         sdr::CumGeom cg{N, stride, n_frames, count0, b->max_chunks};
         SDR_LAUNCH(sdr::K_CUMULATE, sdr::launch_cumulate(S.psd.p, b->db_tab.p, b->carry[0].p, b->carry[1].p, b->carry_cur,
-                                                         S.cum_out.p, cur, cg, n_slots_c, B, stream_of(sdr::K_CUMULATE)));
+                                                         S.cum_out.p, cur, cg, n_slots_c, B, scan_bound_done, stream_of(sdr::K_CUMULATE)));
     }
     SDR_DONE(sdr::K_CUMULATE);
     const int new_count = (count0 + n_frames) % SDR_CUMULATION_SIZE;

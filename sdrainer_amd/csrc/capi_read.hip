@@ -1,5 +1,7 @@
 // capi_read.hip — per-batch / per-listener reads of what the last batch left on the device (tests, one-off reads: they
 // drain the pipeline) and the scope tap (scope/scope.go:14-37).  Part of the C ABI, see bank.h.
+#include <string>
+
 #include "bank.h"
 #include "twiddles.h"
 
@@ -193,9 +195,30 @@ int sdr_read_frame_records(sdr_bank *b, int band, sdr_frame_rec *out, int max)
     if (rc)
         return rc;
     const int n = std::min(b->last_frames, max);
-    if (n > 0 && out)
-        HIP_TRY(hipMemcpy(out, b->set[b->last_set].recs.p + (size_t)band * b->cfg.max_batch_frames,
-                          sizeof(sdr_frame_rec) * (size_t)n, hipMemcpyDeviceToHost));
+    if (n > 0 && out) {
+        BatchSet &S = b->set[b->last_set];
+        sdr_frame_rec *recs = S.recs.p + (size_t)band * b->cfg.max_batch_frames;
+        // The hot path (k_noise_scan.hip) produces FindNoiseFloor's CONSUMED values and only brackets the float64 variance,
+        // which nothing consumes.  A read gets the reference's variance - the literal loops run here, for every frame of
+        // the batch - and the same pass compares the consumed values with the literal ones: a difference is an error.
+        static const bool scan_path = !(getenv("SDR_NOISE_PATH") && std::string(getenv("SDR_NOISE_PATH")) == "chains");
+        if (scan_path) {
+            unsigned *mism = nullptr, h = 0;
+            HIP_TRY(hipMalloc(&mism, sizeof(unsigned)));
+            hipError_t e = hipMemset(mism, 0, sizeof(unsigned));
+            if (e == hipSuccess)
+                e = sdr::launch_noise_exact_check(S.psd.p + (size_t)band * b->cfg.max_batch_frames * b->cfg.block_size, recs, b->noise_geom(),
+                                                  b->last_frames, mism, nullptr);
+            if (e == hipSuccess)
+                e = hipMemcpy(&h, mism, sizeof h, hipMemcpyDeviceToHost);
+            (void)hipFree(mism);
+            if (e != hipSuccess)
+                return fail(SDR_ERR_HIP, std::string("exact FindNoiseFloor: ") + hipGetErrorString(e));
+            if (h)
+                return fail(SDR_ERR_HIP, std::to_string(h) + " frame(s) whose certified FindNoiseFloor values differ from the literal algorithm's");
+        }
+        HIP_TRY(hipMemcpy(out, recs, sizeof(sdr_frame_rec) * (size_t)n, hipMemcpyDeviceToHost));
+    }
     return SDR_OK;
 }
 

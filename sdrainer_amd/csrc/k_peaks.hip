@@ -523,7 +523,7 @@ __global__ __launch_bounds__(kPeakThreadsMax) void k_find_peaks(const float *__r
 // stream the longest of the four: config 3 at 2048 frames per batch 135-143 GS/s against 150 with every slot exact.  From
 // 64 M samples per batch on it pays (config 3 at 8192 frames, config 5's share of 8 x 2048 x 8192).  SDR_CUM_BOUND=0 / 1
 // forces one (development).
-static bool cum_bound_pays(int n_frames, int n_bands, int n)
+bool cum_bound_pays(int n_frames, int n_bands, int n)
 {
     static const int force = getenv("SDR_CUM_BOUND") ? atoi(getenv("SDR_CUM_BOUND")) : -1;
     if (force >= 0)
@@ -531,10 +531,33 @@ static bool cum_bound_pays(int n_frames, int n_bands, int n)
     return (double)n_frames * (double)n_bands * (double)n >= 64.0 * 1024.0 * 1024.0;
 }
 
+// k_bound_slot0 - the bound of the cumulation a batch completes FIRST (slot 0: it continues the one carried in) from the
+// unit count k_psd_scan left in its row and the carry: gomath::cum_bound, as k_cum_bound forms it.
+__global__ __launch_bounds__(256) void k_bound_slot0(float *__restrict__ cum_out, const float *__restrict__ carry0, const float *__restrict__ carry1,
+                                                     int carry_in_arg, const BatchCursor *__restrict__ cur, CumGeom g, double a128, double per_frame)
+{
+    int carry_sel = carry_in_arg;
+    if (cur) {
+        g.count0 = cur->count0;
+        carry_sel = cur->carry_in;
+    }
+    const int len = SDR_CUMULATION_SIZE - g.count0;
+    if (len > g.n_frames)
+        return;  // the batch does not complete it
+    const int bin = blockIdx.x * blockDim.x + threadIdx.x, band = blockIdx.y;
+    if (bin >= g.n)
+        return;
+    const float *__restrict__ carry_in = carry_sel ? carry1 : carry0;
+    float *o = cum_out + ((size_t)band * g.max_chunks) * g.n + bin;
+    const unsigned units = __float_as_uint(*o);
+    const double c0 = g.count0 > 0 ? (double)carry_in[(size_t)band * g.n + bin] : 0.0;
+    *o = gomath::cum_bound(c0, units, len, a128, per_frame, units == 0xffffffffu);
+}
+
 // One batch's cumulation work, on `stream`: bounds of the cumulations it completes, the exact carry of the one it leaves
 // open.  (A stage event armed by the caller rides on the last launch.)
 hipError_t launch_cumulate(const float *psd, const void *db_tab, float *carry0, float *carry1, int carry_in, float *cum_out,
-                           const BatchCursor *cur, CumGeom g, int n_slots, int n_bands, hipStream_t stream)
+                           const BatchCursor *cur, CumGeom g, int n_slots, int n_bands, bool bound_done, hipStream_t stream)
 {
     const double inv_n2 = 1.0 / ((double)g.n * (double)g.n);
     const int threads = g.n < SDR_CUM_THREADS ? g.n : SDR_CUM_THREADS;
@@ -547,7 +570,10 @@ hipError_t launch_cumulate(const float *psd, const void *db_tab, float *carry0, 
     gomath::cum_bound_constants(g.n, &a128, &per_frame);
     const hipEvent_t done = t_done_event;
     t_done_event = nullptr;
-    {
+    if (bound_done) {
+        hipLaunchKernelGGL(k_bound_slot0, dim3((g.n + 255) / 256, n_bands), dim3(256), 0, stream, cum_out, carry0, carry1, carry_in, cur, g, a128,
+                           per_frame);
+    } else {
         static std::once_flag attr_once[64];
         int dev = 0;
         hipError_t e = hipGetDevice(&dev);

@@ -79,6 +79,14 @@ struct CumGeom {
     int n, stride, n_frames, count0, max_chunks;
 };
 
+// k_noise_scan.hip: one pass over a batch's psd for FindNoiseFloor's sums and the cumulations' bounds
+struct ScanGeom {
+    int n, edge, window, n_windows;          // NoiseGeom
+    int stride, n_frames, count0, max_chunks;  // CumGeom
+    int piece;                               // edge pieces hold at most this many bins (64 per-lane slots)
+    int do_bound;                            // also the bound of every cumulation the batch completes
+};
+
 struct PeakGeom {
     int n, stride, count0, max_chunks, max_peaks;
 };
@@ -150,8 +158,17 @@ hipError_t launch_listen_decode(ListenerSlot *slots, const uint16_t *morse, cons
 hipError_t launch_listener_stop(ListenerSlot *slot, const uint16_t *morse, uint32_t *text, uint32_t *text_frames, int text_cap,
                                 uint32_t frame, DropCounters *drops, hipStream_t stream);
 hipError_t launch_set_debounce(ListenerSlot *slots, int n, int threshold, hipStream_t stream);
+// bound_done: k_psd_scan has written the bounds of the completed cumulations (slot 0's as its raw unit count: the carry
+// is added here, on the stream the carry is produced on)
 hipError_t launch_cumulate(const float *psd, const void *db_tab, float *carry0, float *carry1, int carry_in, float *cum_out,
-                           const BatchCursor *cur, CumGeom g, int n_slots, int n_bands, hipStream_t stream);
+                           const BatchCursor *cur, CumGeom g, int n_slots, int n_bands, bool bound_done, hipStream_t stream);
+bool cum_bound_pays(int n_frames, int n_bands, int n);
+hipError_t launch_psd_scan(const float *psd, double *wsum, float *cum_out, const BatchCursor *cur, NoiseGeom ng, CumGeom cg, int n_slots,
+                           int n_bands, bool do_bound, hipStream_t stream);
+hipError_t launch_noise_exact_check(const float *psd_band, sdr_frame_rec *recs_band, NoiseGeom ng, int n_frames, unsigned *mismatches,
+                                    hipStream_t stream);
+hipError_t launch_noise_finish(const float *psd, const double *wsum, sdr_frame_rec *recs, NoiseGeom ng, int n_frames, int n_bands,
+                               int stride, unsigned *exact_list, int force_exact, hipStream_t stream);
 hipError_t launch_spectrum_row(const float *psd_row, float *out, int n, hipStream_t stream);
 hipError_t launch_pack_listen(ListenerSlot *slots, const sdr_edge *edges, const uint32_t *edge_counts, const uint32_t *text,
                               const uint32_t *text_frames, const DropCounters *drops, ResultsLayout lay, int n_slots, int n_bands, unsigned char *host,

@@ -3,7 +3,13 @@ batches; an upper bound of every completed cumulation + the exact value only whe
 batch on: k_peaks.hip) and FindNoiseFloor's variance chains (the float64 matrix pipe for short batches, two vector-ALU
 chain groups per workgroup for long ones: k_noise.hip).  The parity tests run each at the sizes that pick it; here each is
 FORCED onto the sizes that would not (SDR_CUM_BOUND / SDR_VAR_MFMA), in a process of its own, so that carries, partial
-slots, nine-window geometries, batch splits and the bench-size batches all go through both."""
+slots, nine-window geometries, batch splits and the bench-size batches all go through both.
+
+Round 5: FindNoiseFloor has two paths as well - the one-pass scan with values certified where they are consumed
+(k_noise_scan.hip, noise_cert.h; the default) and the ordered chains of rounds 1-4 (SDR_NOISE_PATH=chains).  The chains run
+the same parity tests here; and the scan is run with its literal fallback FORCED for every frame and for every third one
+(SDR_NOISE_FORCE_EXACT), so that the list of flagged frames, the exact kernel behind it and the mix of both are exercised
+(a frame is flagged by itself about three times in 10^5)."""
 import os
 import subprocess
 import sys
@@ -19,6 +25,12 @@ SMALL = "test_receiver_run_bit_exact or test_nine_window_geometry or test_config
 @pytest.mark.parametrize("env, files, sel", [
     ({"SDR_CUM_BOUND": "1", "SDR_VAR_MFMA": "0"}, ["tests/test_gpu_parity.py", "tests/test_dsp_golden.py"], SMALL + " or golden"),
     ({"SDR_CUM_BOUND": "0", "SDR_VAR_MFMA": "1"}, ["tests/test_gpu_parity_bench_sizes.py"], "config3 or config5 or config2"),
+    ({"SDR_NOISE_PATH": "chains"}, ["tests/test_gpu_parity.py", "tests/test_dsp_golden.py", "tests/test_gpu_parity_bench_sizes.py"],
+     SMALL + " or golden or config3 or config2"),
+    ({"SDR_NOISE_PATH": "chains", "SDR_CUM_BOUND": "1", "SDR_VAR_MFMA": "0"}, ["tests/test_gpu_parity.py"], SMALL),
+    ({"SDR_NOISE_FORCE_EXACT": "1"}, ["tests/test_gpu_parity.py", "tests/test_dsp_golden.py"], SMALL + " or golden"),
+    ({"SDR_NOISE_FORCE_EXACT": "3", "SDR_CUM_BOUND": "1"}, ["tests/test_gpu_parity.py", "tests/test_gpu_parity_bench_sizes.py"],
+     SMALL + " or config5 or config2"),
 ])
 def test_parity_with_the_other_implementation_forced(env, files, sel):
     p = subprocess.run([sys.executable, "-m", "pytest", *[os.path.join(ROOT, f) for f in files], "-q", "-x", "-m", "gpu", "-k", sel,

@@ -376,6 +376,21 @@ def test_fft_phase_functions_match_oracle_bit_for_bit(tmp_path, layout_b_from):
     assert ("layout B" in out.stdout) == (layout_b_from <= 14)
 
 
+def test_noise_floor_certification_against_the_literal_algorithm(tmp_path):
+    """noise_cert.h: FindNoiseFloor's consumed values (float32 minimum mean, the two rolling-mean inputs, the winning
+    window) from order-free sums, accepted only where the brackets around what the reference's ordered sums can be round
+    and compare one way.  On the CPU, against the literal loops: noise, carriers, constant rows, means planted on float32
+    rounding boundaries, tied windows, zeros / subnormals / a huge value, infinities and NaNs, eight geometries - an accepted
+    frame has the reference's bits, specials are never accepted, ordinary rows nearly always are."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "emu_noise_cert")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe, os.path.join(root, "tests", "emu", "emu_noise_cert.cpp")])
+    out = subprocess.run([exe, "200"], capture_output=True, text=True)
+    assert out.returncode == 0 and "\n0 violations" in out.stdout, out.stdout + out.stderr
+
+
 def test_fft_r32_plan_matches_oracle_bit_for_bit(tmp_path):
     """The 32-points-per-thread plan of the N = 16384 FFT (fft_r32.h: 512 threads, 5 + 5 + 4 stages, the cross-wave exchange
     behind pass 0, a wave-local one behind pass 1, the psd row through LDS), emulated thread by thread on the CPU against
