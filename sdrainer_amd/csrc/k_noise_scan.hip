@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <mutex>
 
 #include "../../include/sdrainer_hip.h"
 #include "cw_decoder.h"
@@ -37,6 +38,29 @@ __device__ __forceinline__ void scan_slot_frames(int slot, int count0, int *begi
     const int first_len = SDR_CUMULATION_SIZE - count0;
     *begin = slot == 0 ? 0 : first_len + (slot - 1) * SDR_CUMULATION_SIZE;
     *len = slot == 0 ? first_len : SDR_CUMULATION_SIZE;
+}
+
+// Sum of a float64 over the wave, in lane 63, by DPP moves (no LDS round trips: as twelve ds_bpermute pairs per frame the
+// reduction WAS the kernel - 0.27 ms for a batch whose loads and additions need 0.07).  The classic sequence: row_shr 1, 2,
+// 3 (-> every fourth lane holds its group of four... ) is replaced by the shift / broadcast ladder below; lanes a step
+// does not write receive 0.0 (old = 0 with the row / bank masks), which adds nothing.  Six additions per lane deep, like
+// the butterfly it replaces (noise_cert.h kScanTerms).
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_moved(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, BANK_MASK, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, BANK_MASK, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_to_lane63(double x)
+{
+    x += dpp_moved<0x111, 0xf, 0xf>(x);  // row_shr:1
+    x += dpp_moved<0x112, 0xf, 0xf>(x);  // row_shr:2
+    x += dpp_moved<0x114, 0xf, 0xe>(x);  // row_shr:4, banks 1-3
+    x += dpp_moved<0x118, 0xf, 0xc>(x);  // row_shr:8, banks 2-3: lane 15 of every row holds the row's sum
+    x += dpp_moved<0x142, 0xa, 0xf>(x);  // row_bcast:15 into rows 1 and 3
+    x += dpp_moved<0x143, 0xc, 0xf>(x);  // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's sum
+    return x;
 }
 
 template <int JMAX>
@@ -118,12 +142,9 @@ __global__ __launch_bounds__(64 * kScanMaxWaves) void k_psd_scan(const float *__
                     }
                 }
                 if (w >= 0) {
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        s1 += __shfl_xor(s1, o);
-                        s2 += __shfl_xor(s2, o);
-                    }
-                    if (lane == 0) {
+                    s1 = wave_sum_to_lane63(s1);
+                    s2 = wave_sum_to_lane63(s2);
+                    if (lane == 63) {
                         double *o = wsum + ((size_t)band * g.stride + f) * (2 * noise::kMaxWindows) + 2 * w;
                         o[0] = s1;
                         o[1] = s2;
@@ -185,29 +206,67 @@ __global__ __launch_bounds__(256) void k_noise_finish(const float *__restrict__ 
 // k_noise_exact_list - the literal FindNoiseFloor (noise_cert.h exact_frame: the oracle's loops) for the listed frames,
 // one wave each: the window sums are independent chains (a lane each), the rest runs on lane 0.  Overwrites the four
 // FindNoiseFloor fields of the frame's record; the thresholds kernel runs behind it.
-__global__ __launch_bounds__(64) void k_noise_exact_list(const float *__restrict__ psd, sdr_frame_rec *__restrict__ recs, noise::Geom g,
-                                                         const unsigned *__restrict__ exact_list)
+// (First version: a wave per frame straight from global memory, lane 0 walking 12 000 dependent loads and additions -
+// a millisecond per flagged frame, a quarter of a millisecond per batch on average, on the stream every threshold waits
+// for.  Now a workgroup per frame: the row is staged in LDS once, the ten window chains run side by side from there, and
+// the variance chain's terms - fl(fl(x - mean)^2), each its own rounding, any thread can form them - are produced chunk
+// by chunk into an LDS double buffer by three waves while thread 0 adds the previous chunk in order: the chain runs at the
+// pace of a dependent float64 add with its operand already on chip, 45 us for 12 000 terms.)
+constexpr int kExactThreads = 256, kExactChunk = 2048;
+__global__ __launch_bounds__(kExactThreads) void k_noise_exact_list(const float *__restrict__ psd, sdr_frame_rec *__restrict__ recs, noise::Geom g,
+                                                                    const unsigned *__restrict__ exact_list)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *row = reinterpret_cast<float *>(smem);                                  // [n]
+    double *terms = reinterpret_cast<double *>(smem + (size_t)g.n * sizeof(float));  // [2][kExactChunk]
+    __shared__ double s_sums[noise::kMaxWindows];
+    __shared__ noise::Selection s_sel;
     const unsigned count = exact_list[0];
-    const int lane = threadIdx.x;
-    for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {
+    const int tid = threadIdx.x;
+    for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {  // (workgroup-uniform)
         const size_t frame = exact_list[1 + k];
-        const float *__restrict__ row = psd + frame * g.n;
+        const float *__restrict__ src = psd + frame * g.n;
+        for (int i = tid; i < g.n; i += kExactThreads)
+            row[i] = src[i];
+        __syncthreads();
         auto x_at = [row](int i) { return (double)row[i]; };
-        double mine = 0.0;
-        if (lane < g.n_windows)
-            mine = noise::window_sum(g, x_at, lane);
-        double sums[noise::kMaxWindows];
-#pragma unroll
-        for (int w = 0; w < noise::kMaxWindows; w++)
-            sums[w] = __shfl(mine, w);
-        if (lane == 0) {
-            const noise::Result r = noise::exact_frame(g, x_at, sums);
+        if (tid < g.n_windows)
+            s_sums[tid] = noise::window_sum(g, x_at, tid);
+        __syncthreads();
+        if (tid == 0)
+            s_sel = noise::select_window(g, x_at(0), s_sums);
+        __syncthreads();
+        const noise::Selection sel = s_sel;
+        const int total = noise::result_to(g, sel.window) - g.edge + 1, n_chunks = (total + kExactChunk - 1) / kExactChunk;
+        auto produce = [&](int c) {  // chunk c of the terms, by the threads of waves 1-3
+            double *dst = terms + (size_t)(c & 1) * kExactChunk;
+            const int base = c * kExactChunk, len = min(kExactChunk, total - base);
+            for (int i = tid - 64; i < len; i += kExactThreads - 64)
+                dst[i] = noise::variance_term(x_at(g.edge + base + i), sel.result_mean);
+        };
+        if (tid >= 64)
+            produce(0);
+        __syncthreads();
+        double sum = 0;
+        for (int c = 0; c < n_chunks; c++) {
+            if (tid >= 64 && c + 1 < n_chunks)
+                produce(c + 1);
+            if (tid == 0) {
+                const double *src_t = terms + (size_t)(c & 1) * kExactChunk;
+                const int len = min(kExactChunk, total - c * kExactChunk);
+                for (int i = 0; i < len; i++)
+                    sum += src_t[i];  // :246-247, in order
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const noise::Result r = noise::finish_frame(g, sel, sum);
             recs[frame].min_mean = r.min_mean;
             recs[frame].variance = r.variance;
             recs[frame].dev_in = r.dev_in;
             recs[frame].nf_in = r.nf_in;
         }
+        __syncthreads();  // (the next frame's staging overwrites the row)
     }
 }
 
@@ -312,9 +371,24 @@ hipError_t launch_noise_finish(const float *psd, const double *wsum, sdr_frame_r
     hipLaunchKernelGGL(k_noise_finish, dim3((n_frames + 255) / 256, n_bands), dim3(256), 0, stream, psd, wsum, recs, g, n_frames, stride,
                        exact_list, force_exact);
     t_done_event = done;
-    // a wave per flagged frame, at most 2048 workgroups (every frame flagged: they loop)
-    const int wgs = force_exact == 1 ? 2048 : 64;
-    launch_kernel(k_noise_exact_list, dim3(wgs), dim3(64), 0, stream, psd, recs, g, static_cast<const unsigned *>(exact_list));
+    // a workgroup per flagged frame (they loop when there are more frames than workgroups: every frame flagged, in tests)
+    const unsigned lds = (unsigned)((size_t)ng.n * sizeof(float) + 2u * kExactChunk * sizeof(double));
+    static std::once_flag attr_once[64];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess)
+        return e;
+    if (dev < 0 || dev >= 64)
+        return hipErrorInvalidDevice;
+    hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once[dev], [&] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_noise_exact_list), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       16384 * (int)sizeof(float) + 2 * kExactChunk * (int)sizeof(double));
+    });
+    if (attr_err != hipSuccess)
+        return attr_err;
+    const int wgs = force_exact == 1 ? 1024 : 32;
+    launch_kernel(k_noise_exact_list, dim3(wgs), dim3(kExactThreads), lds, stream, psd, recs, g, static_cast<const unsigned *>(exact_list));
     return hipGetLastError();
 }
 

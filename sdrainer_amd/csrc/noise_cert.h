@@ -140,38 +140,56 @@ SDR_HD inline Result certify(const double *s1, const double *s2, const Geom &g, 
     return r;
 }
 
-// The literal algorithm (dsp/fft.go:215-252 + rx/receiver.go:383-384) for one frame; x_at(i) = float64(psd[i]).
-// (The window sums of a frame are independent chains: sum_of(w) may run them on different lanes.)
-template <class XAT>
-SDR_HD inline Result exact_frame(const Geom &g, XAT x_at, const double *window_sums)
+// The literal algorithm (dsp/fft.go:215-252 + rx/receiver.go:383-384) for one frame, in the three pieces the device's
+// fallback kernel runs on different threads: the window sums (independent chains: window_sum below), the first minimum of
+// their means (select_window), the variance chain and what is made of it (variance_term, finish_frame).
+struct Selection {
+    double min_value, result_mean;
+    int window;
+};
+SDR_HD inline Selection select_window(const Geom &g, double x0, const double *window_sums)
 {
-    Result r{};
-    double minValue = x_at(0);  // :217, overridden by `first`
+    Selection s{x0, 0.0, 0};  // :217 minValue := float64(psd[0]), overridden by `first`
     bool first = true;
-    double resultMean = 0;
-    int win = 0;
     for (int w = 0; w < g.n_windows; w++) {
         const double mean = window_sums[w] / (double)g.window;
-        if (mean < minValue || first) {  // :232
-            minValue = mean;
+        if (mean < s.min_value || first) {  // :232
+            s.min_value = mean;
             first = false;
-            resultMean = mean;
-            win = w;
+            s.result_mean = mean;
+            s.window = w;
         }
     }
-    double sum = 0;
-    const int to = g.edge + (win + 1) * g.window;  // resultTo; resultFrom = edge (App. C1 of the survey)
-    for (int i = g.edge; i <= to; i++) {
-        const double d = x_at(i) - resultMean;
-        sum += d * d;
-    }
-    r.variance = sum / (double)g.window;
-    r.window = win;
-    r.min_mean = (float)minValue;
+    return s;
+}
+// :246 math.Pow(float64(psd[i]) - resultMean, 2)
+SDR_HD inline double variance_term(double x, double result_mean)
+{
+    const double d = x - result_mean;
+    return d * d;
+}
+// resultFrom = edge (App. C1 of the survey), resultTo = edge + (window + 1) W, both inclusive
+SDR_HD inline int result_to(const Geom &g, int window) { return g.edge + (window + 1) * g.window; }
+SDR_HD inline Result finish_frame(const Geom &g, const Selection &s, double term_sum)
+{
+    Result r{};
+    r.variance = term_sum / (double)g.window;
+    r.window = s.window;
+    r.min_mean = (float)s.min_value;
     r.nf_in = nf_in_of(r.min_mean, g.inv_n2);
     r.dev_in = dev_in_of((float)::sqrt(r.variance), g.inv_n2);
     r.ok = true;
     return r;
+}
+template <class XAT>
+SDR_HD inline Result exact_frame(const Geom &g, XAT x_at, const double *window_sums)
+{
+    const Selection s = select_window(g, x_at(0), window_sums);
+    double sum = 0;
+    const int to = result_to(g, s.window);
+    for (int i = g.edge; i <= to; i++)
+        sum += variance_term(x_at(i), s.result_mean);
+    return finish_frame(g, s, sum);
 }
 
 // sequential float64 sum of window w (dsp/fft.go:239-241)
