@@ -92,8 +92,7 @@ enum Stage { S_FFT = 0, S_NOISE, S_LISTEN, S_PEAKS, N_STAGES };  // the bank's s
 struct BatchSet {
     DevBuf<float> psd;                // [band][max_batch][N] float32(re^2 + im^2), fft-shifted
     DevBuf<float> tap;                // [band][max_batch][L] psd of each listener slot's bin
-    DevBuf<double> win_mean;          // [band][max_batch][20]: k_psd_scan's S1, S2 per window (the chain kernels: 10 window means)
-    DevBuf<unsigned> exact_list;      // [1 + band * max_batch]: frames whose FindNoiseFloor takes the literal loops (count first)
+    DevBuf<double> win_mean;          // [band][max_batch][10] (the chain kernels of SDR_NOISE_PATH=chains only)
     DevBuf<sdr_frame_rec> recs;       // [band][max_batch]
     DevBuf<uint64_t> raw_bits, bits;  // [band][L][bit_words] before / after the debouncer
     DevBuf<sdr_edge> edges;           // [band][L][edge_cap]
@@ -102,6 +101,7 @@ struct BatchSet {
     DevBuf<uint8_t> tr_raw, tr_deb;
     DevBuf<sdr::ListenerSlot> slots_before;  // [band][L] the slots as the batch's decoders found them (trace only: sdr_scope_read_decode)
     DevBuf<float> cum_out;            // [band][max_chunks][N]
+    DevBuf<float> cum_part;           // [band][max_chunks][N]: the second partial unit count of k_psd_scan (a slot's frames over two workgroups)
     DevBuf<sdr::DevPeak> dev_peaks;   // [band][max_chunks][max_peaks]
     DevBuf<int> peak_counts;          // [band][max_chunks]
     hipEvent_t done[sdr::K_COUNT] = {};  // recorded behind each kernel of the batch that used this set
@@ -112,7 +112,7 @@ struct BatchSet {
         psd.release();
         tap.release();
         win_mean.release();
-        exact_list.release();
+        cum_part.release();
         recs.release();
         raw_bits.release();
         bits.release();

@@ -75,8 +75,7 @@ hipError_t alloc_set(sdr_bank *b, BatchSet &S)
     } while (0)
     SET_ALLOC(S.psd, B * F * N);
     SET_ALLOC(S.tap, B * F * std::max<size_t>(L, 1));
-    SET_ALLOC(S.win_mean, B * F * 20);
-    SET_ALLOC(S.exact_list, B * F + 1);
+    SET_ALLOC(S.win_mean, B * F * 10);
     SET_ALLOC(S.recs, B * F);
     SET_ALLOC(S.raw_bits, B * L * (size_t)b->bit_words);
     SET_ALLOC(S.bits, B * L * (size_t)b->bit_words);
@@ -89,6 +88,7 @@ hipError_t alloc_set(sdr_bank *b, BatchSet &S)
         SET_ALLOC(S.slots_before, B * L);
     }
     SET_ALLOC(S.cum_out, B * (size_t)b->max_chunks * N);
+    SET_ALLOC(S.cum_part, B * (size_t)b->max_chunks * N);
     SET_ALLOC(S.dev_peaks, B * (size_t)b->max_chunks * (size_t)c.max_peaks);
     SET_ALLOC(S.peak_counts, B * (size_t)b->max_chunks);
 #undef SET_ALLOC

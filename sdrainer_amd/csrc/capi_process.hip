@@ -286,8 +286,8 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         SDR_ARM(sdr::K_WINDOW_MEANS);
         if (scan_path) {
             const sdr::CumGeom scg{N, stride, n_frames, scan_count0, b->max_chunks};
-            SDR_LAUNCH(sdr::K_WINDOW_MEANS, sdr::launch_psd_scan(S.psd.p, S.win_mean.p, S.cum_out.p, cur, ng, scg, scan_slots, B, scan_bound,
-                                                                 stream_of(sdr::K_WINDOW_MEANS)));
+            SDR_LAUNCH(sdr::K_WINDOW_MEANS, sdr::launch_psd_scan(S.psd.p, S.recs.p, S.cum_out.p, S.cum_part.p, cur, ng, scg, scan_slots, B, scan_bound,
+                                                                 force_exact, stream_of(sdr::K_WINDOW_MEANS)));
         } else {
             SDR_LAUNCH(sdr::K_WINDOW_MEANS, sdr::launch_window_means(S.psd.p, S.win_mean.p, ng, n_frames, B, stride,
                                                                      stream_of(sdr::K_WINDOW_MEANS)));
@@ -298,10 +298,7 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     {
         ProfScope ps(b, sdr::K_NOISE_STATS, stream_of(sdr::K_NOISE_STATS));
         SDR_ARM(sdr::K_NOISE_STATS);
-        if (scan_path)
-            SDR_LAUNCH(sdr::K_NOISE_STATS, sdr::launch_noise_finish(S.psd.p, S.win_mean.p, S.recs.p, ng, n_frames, B, stride, S.exact_list.p,
-                                                                    force_exact, stream_of(sdr::K_NOISE_STATS)));
-        else
+        if (!scan_path)  // (the scan kernel has finished the records itself: this stage launches nothing, its event is recorded below)
             SDR_LAUNCH(sdr::K_NOISE_STATS, sdr::launch_noise_stats(S.psd.p, S.win_mean.p, S.recs.p, ng, n_frames, B, stride,
                                                                    stream_of(sdr::K_NOISE_STATS)));
     }
@@ -393,7 +390,7 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         SDR_ARM(sdr::K_CUMULATE);
         sdr::CumGeom cg{N, stride, n_frames, count0, b->max_chunks};
         SDR_LAUNCH(sdr::K_CUMULATE, sdr::launch_cumulate(S.psd.p, b->db_tab.p, b->carry[0].p, b->carry[1].p, b->carry_cur,
-                                                         S.cum_out.p, cur, cg, n_slots_c, B, scan_bound_done, stream_of(sdr::K_CUMULATE)));
+                                                         S.cum_out.p, S.cum_part.p, cur, cg, n_slots_c, B, scan_bound_done, stream_of(sdr::K_CUMULATE)));
     }
     SDR_DONE(sdr::K_CUMULATE);
     const int new_count = (count0 + n_frames) % SDR_CUMULATION_SIZE;

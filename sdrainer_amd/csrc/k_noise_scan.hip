@@ -1,20 +1,24 @@
-// k_noise_scan.hip — ONE pass over a batch's psd rows for everything the tail needs from all of them:
-//   * dsp.FindNoiseFloor (dsp/fft.go:215-252): per frame and window the order-free sums S1 = sum x, S2 = sum x^2, from
-//     which k_noise_finish takes the reference's minimum mean, variance and rolling-mean inputs exactly where they are
-//     consumed (noise_cert.h: brackets around what the reference's ORDERED sums can be; a frame whose brackets straddle a
-//     float32 rounding boundary or another window's mean is flagged and k_noise_exact_list runs the literal loops);
-//   * the cumulation (rx/receiver.go:404-407): the upper bound of every cumulation the batch completes, from the psd words'
-//     top halves (k_peaks.hip, gomath.h cum_bound_*), which k_cum_refine / k_find_peaks turn into the exact peak list.
+// k_noise_scan.hip — ONE pass over a batch's psd rows for everything the tail needs from all of them, in ONE kernel:
+//   * dsp.FindNoiseFloor (dsp/fft.go:215-252): per frame and window the order-free sums S1 = sum x, S2 = sum x^2, from which
+//     the same workgroup takes the reference's minimum mean, variance and rolling-mean inputs exactly where they are
+//     consumed (noise_cert.h: brackets around what the reference's ORDERED sums can be); a frame whose brackets straddle a
+//     float32 rounding boundary or another window's mean - three in 10^5 - gets the literal loops, there and then;
+//   * the cumulation (rx/receiver.go:404-407): the unit counts behind the upper bound of every cumulation the batch completes
+//     (the psd words' top halves: gomath.h cum_bound_*), which k_bound_finish / k_cum_refine / k_find_peaks (k_peaks.hip)
+//     turn into the exact peak list.
 // Rounds 1-4 read the psd three times for this (window chains 73 % of it, variance chains up to 73 %, the bound all of it:
 // 31 of a step's 181 CU-ms; a stage costs the CU time it HOLDS, and these hold it for bytes / what a CU's memory pipeline
 // delivers) and ran 24 000 strictly ordered float64 additions per frame that nothing downstream can tell from any other
-// order except three times in 10^5.
+// order.  And one kernel, not four: the FFT's workgroups own whole CUs, so every launch of the tail waits for CUs to come
+// free - a one-thread kernel took 14 us in the running pipeline - and the noise floor sits on the path every threshold,
+// and with it every listener, waits for.
 //
 // Geometry.  A row is cut into SEGMENTS: the reference's windows (W values each) and pieces of the two edges (at most
-// 64 JMAX values).  A WAVE owns one segment of one cumulation slot (up to 100 consecutive frames): lane l holds the bins
-// begin + l + 64 j; per frame it adds its values into the frame's S1 / S2 (a lane's <= JMAX values in sequence, then six
-// butterfly levels across the lanes: noise_cert.h kScanTerms) and into its bins' running unit counts, which become the
-// slot's bound after the last frame.  A workgroup = the segments of one (band, slot): 14 waves at N = 16384.
+// 64 JMAX values).  A WAVE owns one segment of one run of consecutive frames (a cumulation slot, or a share of one): lane l
+// holds the bins begin + l + 64 j; per frame it adds its values into the frame's S1 / S2 (a lane's <= JMAX values in
+// sequence, then a six-step ladder across the lanes: noise_cert.h kScanTerms) and into its bins' running unit counts.
+// A workgroup = the segments of one run: 14 waves at N = 16384.  Behind a barrier its threads then finish one frame each
+// (certify), and the workgroup as a whole walks the literal loops of the frames that were not accepted.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -29,6 +33,8 @@
 namespace sdr {
 
 constexpr int kScanMaxWaves = 16;
+constexpr int kScanMaxFrames = SDR_CUMULATION_SIZE;  // frames a workgroup walks at most
+constexpr int kExactChunk = 2048;                    // terms of the variance chain per LDS buffer
 #if !defined(SDR_SCAN_AHEAD)
 #define SDR_SCAN_AHEAD 2  // frames whose loads are in flight ahead of the one being added up
 #endif
@@ -41,10 +47,9 @@ __device__ __forceinline__ void scan_slot_frames(int slot, int count0, int *begi
 }
 
 // Sum of a float64 over the wave, in lane 63, by DPP moves (no LDS round trips: as twelve ds_bpermute pairs per frame the
-// reduction WAS the kernel - 0.27 ms for a batch whose loads and additions need 0.07).  The classic sequence: row_shr 1, 2,
-// 3 (-> every fourth lane holds its group of four... ) is replaced by the shift / broadcast ladder below; lanes a step
-// does not write receive 0.0 (old = 0 with the row / bank masks), which adds nothing.  Six additions per lane deep, like
-// the butterfly it replaces (noise_cert.h kScanTerms).
+// reduction WAS the kernel - 0.27 ms for a batch whose loads and additions need 0.07).  A shift / broadcast ladder; lanes a
+// step does not write receive 0.0 (old = 0 under the row / bank masks), which adds nothing.  Six additions deep
+// (noise_cert.h kScanTerms).
 template <int CTRL, int ROW_MASK, int BANK_MASK>
 __device__ __forceinline__ double dpp_moved(double x)
 {
@@ -63,27 +68,110 @@ __device__ __forceinline__ double wave_sum_to_lane63(double x)
     return x;
 }
 
-template <int JMAX>
-__global__ __launch_bounds__(64 * kScanMaxWaves) void k_psd_scan(const float *__restrict__ psd, double *__restrict__ wsum,
-                                                                  float *__restrict__ cum_out, const BatchCursor *__restrict__ cur,
-                                                                  ScanGeom g, double a128, double per_frame)
+// LDS of a scan workgroup: the run's sums [frame][window][S1, S2], the list of frames for the literal loops, and - used
+// by those only - a staged psd row and the double buffer of the variance chain's terms
+struct ScanLds {
+    double sums[kScanMaxFrames][2 * noise::kMaxWindows];
+    double win_sums[noise::kMaxWindows];
+    noise::Selection sel;
+    int n_flagged;
+    unsigned short flagged[kScanMaxFrames];
+};
+constexpr int scan_lds_bytes(int n) { return (int)((sizeof(ScanLds) + 15) / 16 * 16) + n * (int)sizeof(float) + 2 * kExactChunk * (int)sizeof(double); }
+
+// The literal FindNoiseFloor (noise_cert.h: the oracle's loops) of one frame by a whole workgroup: the row is staged in
+// LDS once, the ten window chains run side by side from there (a thread each), and the variance chain's terms -
+// fl(fl(x - mean)^2), each its own rounding: any thread can form them - are produced chunk by chunk into an LDS double
+// buffer by the other waves while thread 0 adds the previous chunk in order: the chain runs at the pace of a dependent
+// float64 add with its operand on chip, 45 us for 12 000 terms.  (First version: a wave per frame straight from global
+// memory, lane 0 walking 12 000 dependent loads - a millisecond per frame.)
+__device__ void exact_frame_block(ScanLds &sh, float *row, double *terms, const float *__restrict__ src, sdr_frame_rec *rec, const noise::Geom &g)
 {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < g.n; i += nt)
+        row[i] = src[i];
+    __syncthreads();
+    auto x_at = [row](int i) { return (double)row[i]; };
+    if (tid < g.n_windows)
+        sh.win_sums[tid] = noise::window_sum(g, x_at, tid);
+    __syncthreads();
+    if (tid == 0)
+        sh.sel = noise::select_window(g, x_at(0), sh.win_sums);
+    __syncthreads();
+    const noise::Selection sel = sh.sel;
+    const int total = noise::result_to(g, sel.window) - g.edge + 1, n_chunks = (total + kExactChunk - 1) / kExactChunk;
+    auto produce = [&](int c) {  // chunk c of the terms, by the threads of waves 1 ..
+        double *dst = terms + (size_t)(c & 1) * kExactChunk;
+        const int base = c * kExactChunk, len = min(kExactChunk, total - base);
+        for (int i = tid - 64; i < len; i += nt - 64)
+            dst[i] = noise::variance_term(x_at(g.edge + base + i), sel.result_mean);
+    };
+    if (tid >= 64)
+        produce(0);
+    __syncthreads();
+    double sum = 0;
+    for (int c = 0; c < n_chunks; c++) {
+        if (tid >= 64 && c + 1 < n_chunks)
+            produce(c + 1);
+        if (tid == 0) {
+            const double *src_t = terms + (size_t)(c & 1) * kExactChunk;
+            const int len = min(kExactChunk, total - c * kExactChunk);
+            for (int i = 0; i < len; i++)
+                sum += src_t[i];  // :246-247, in order
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const noise::Result r = noise::finish_frame(g, sel, sum);
+        rec->min_mean = r.min_mean;
+        rec->variance = r.variance;
+        rec->dev_in = r.dev_in;
+        rec->nf_in = r.nf_in;
+    }
+    __syncthreads();  // (the next frame's staging overwrites the row)
+}
+
+template <int JMAX>
+__global__ __launch_bounds__(64 * kScanMaxWaves) void k_psd_scan(const float *__restrict__ psd, sdr_frame_rec *__restrict__ recs,
+                                                                  float *__restrict__ cum_out, float *__restrict__ cum_part,
+                                                                  const BatchCursor *__restrict__ cur, ScanGeom g, double inv_n2,
+                                                                  int force_exact)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ScanLds &sh = *reinterpret_cast<ScanLds *>(smem);
     int count0 = g.count0;
     if (cur)  // graph replay: this batch's cumulation phase comes from device memory
         count0 = cur->count0;
-    const int slot = blockIdx.x, band = blockIdx.y;
+    // with bounds: blockIdx.x = slot * parts + part, a part = an equal share of the slot's frames (two parts where there are
+    // too few slots for the chip: a workgroup walks its frames one after the other, 2.4 us each)
+    const int slot = g.do_bound ? (int)blockIdx.x / g.parts : 0, part = g.do_bound ? (int)blockIdx.x % g.parts : 0, band = blockIdx.y;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int n_waves = (int)blockDim.x >> 6;
     int f_begin, f_len;
-    scan_slot_frames(slot, count0, &f_begin, &f_len);
+    if (g.do_bound) {
+        scan_slot_frames(slot, count0, &f_begin, &f_len);
+    } else {
+        // no bounds wanted (short batches: k_cumulate keeps every slot exact): the cumulation slots mean nothing here, a
+        // workgroup takes g.fpw consecutive frames - a 2048-frame batch has 21 slots, and 21 workgroups walking a hundred
+        // frames each took longer than the batch's FFT (config 3 at 2048 frames per batch: 105 GS/s instead of 160)
+        f_begin = (int)blockIdx.x * g.fpw;
+        f_len = g.fpw;
+    }
     if (f_begin >= g.n_frames)
         return;  // (workgroup-uniform)
-    const int f_end = min(f_begin + f_len, g.n_frames);
     const bool complete = f_begin + f_len <= g.n_frames;  // the batch completes this cumulation: its bound is wanted
-    const int edge_hi = g.edge + g.n_windows * g.window;   // first bin behind the last evaluated window
+    if (g.do_bound && g.parts > 1) {
+        const int share = (f_len + g.parts - 1) / g.parts;
+        f_begin += part * share;
+        f_len = max(0, min(share, f_len - part * share));
+    }
+    const int f_end = min(f_begin + f_len, g.n_frames);
+    const int edge_hi = g.edge + g.n_windows * g.window;  // first bin behind the last evaluated window
     const int n_left = (g.edge + g.piece - 1) / g.piece, n_right = (g.n - edge_hi + g.piece - 1) / g.piece;
     const int n_items = g.n_windows + ((g.do_bound && complete) ? n_left + n_right : 0);
     const float *__restrict__ rows = psd + ((size_t)band * g.stride + f_begin) * g.n;
+    if (threadIdx.x == 0)
+        sh.n_flagged = 0;
     for (int item = wave; item < n_items; item += n_waves) {  // (wave-uniform)
         int b0, len, w = -1;
         if (item < g.n_windows) {
@@ -102,8 +190,7 @@ __global__ __launch_bounds__(64 * kScanMaxWaves) void k_psd_scan(const float *__
 #pragma unroll
         for (int j = 0; j < JMAX; j++)
             units[j] = special[j] = 0u;
-        // lane's bins: b0 + lane + 64 j, j < JMAX, valid while < b0 + len (an invalid one re-reads the lane's first bin
-        // and is masked out of every sum)
+        // lane's bins: b0 + lane + 64 j, j < JMAX, valid while < b0 + len (an invalid one is not loaded and adds 0)
         const unsigned off0 = (unsigned)(b0 + (lane < len ? lane : 0));
         float v[SDR_SCAN_AHEAD + 1][JMAX];
         auto fetch = [&](int f, int k) {
@@ -130,7 +217,7 @@ __global__ __launch_bounds__(64 * kScanMaxWaves) void k_psd_scan(const float *__
 #pragma unroll
                 for (int j = 0; j < JMAX; j++) {
                     const float x = v[k][j];
-                    if (w >= 0) {  // (an invalid slot holds 0: it adds nothing)
+                    if (w >= 0) {
                         const double xd = (double)x;
                         s1 += xd;
                         s2 += xd * xd;  // (exact: a float32 squared has 48 bits)
@@ -145,9 +232,8 @@ __global__ __launch_bounds__(64 * kScanMaxWaves) void k_psd_scan(const float *__
                     s1 = wave_sum_to_lane63(s1);
                     s2 = wave_sum_to_lane63(s2);
                     if (lane == 63) {
-                        double *o = wsum + ((size_t)band * g.stride + f) * (2 * noise::kMaxWindows) + 2 * w;
-                        o[0] = s1;
-                        o[1] = s2;
+                        sh.sums[f - f_begin][2 * w] = s1;
+                        sh.sums[f - f_begin][2 * w + 1] = s2;
                     }
                 }
             }
@@ -158,119 +244,52 @@ __global__ __launch_bounds__(64 * kScanMaxWaves) void k_psd_scan(const float *__
                 if (lane + 64 * j < len) {
                     const int bin = b0 + lane + 64 * j;
                     const bool sp = (special[j] >> 16) != 0u;
-                    // slot 0 continues the cumulation carried in from the previous batch, and that carry is produced on
-                    // another stream (k_cumulate, behind this batch's predecessor): the raw unit count goes out instead
-                    // (all ones: a special value in the column) and k_bound_slot0 adds the carry where it is known
-                    cum_out[((size_t)band * g.max_chunks + slot) * g.n + bin] =
-                        slot == 0 ? __uint_as_float(sp ? 0xffffffffu : units[j]) : gomath::cum_bound(0.0, units[j], f_len, a128, per_frame, sp);
+                    // The raw unit count goes out (all ones: a special value in the column), part 0's into the slot's row,
+                    // part 1's into the second buffer: k_bound_finish (k_peaks.hip) adds the parts and - slot 0 continues the
+                    // cumulation carried in from the previous batch, and that carry is produced on the peaks stream - the
+                    // carry, and forms the bound there.
+                    (part == 0 ? cum_out : cum_part)[((size_t)band * g.max_chunks + slot) * g.n + bin] = __uint_as_float(sp ? 0xffffffffu : units[j]);
                 }
             }
         }
     }
-}
-
-// k_noise_finish - one thread per frame: the reference's minimum mean, variance and rolling-mean inputs from the scan's
-// sums where they can be had for certain (noise_cert.h certify), the frame's number onto the list of the others.
-__global__ __launch_bounds__(256) void k_noise_finish(const float *__restrict__ psd, const double *__restrict__ wsum,
-                                                      sdr_frame_rec *__restrict__ recs, noise::Geom g, int n_frames, int stride,
-                                                      unsigned *__restrict__ exact_list, int force_exact)
-{
-    const int f = blockIdx.x * blockDim.x + threadIdx.x, band = blockIdx.y;
-    if (f >= n_frames)
-        return;
-    const size_t frame = (size_t)band * stride + f;
-    const float *__restrict__ row = psd + frame * g.n;
-    const double *s = wsum + frame * (2 * noise::kMaxWindows);
-    double s1[noise::kMaxWindows], s2[noise::kMaxWindows];
+    __syncthreads();
+    // one frame per thread: the reference's values where they can be had for certain, the frame onto the list otherwise
+    // (force_exact, tests: 1 = every frame, k > 1 = every k-th takes the literal loops)
+    const noise::Geom ng{g.n, g.edge, g.window, g.n_windows, inv_n2};
+    for (int i = threadIdx.x; i < f_end - f_begin; i += blockDim.x) {
+        const int f = f_begin + i;
+        const size_t frame = (size_t)band * g.stride + f;
+        const float *__restrict__ row = psd + frame * g.n;
+        double s1[noise::kMaxWindows], s2[noise::kMaxWindows];
 #pragma unroll
-    for (int w = 0; w < noise::kMaxWindows; w++) {
-        s1[w] = w < g.n_windows ? s[2 * w] : 0.0;
-        s2[w] = w < g.n_windows ? s[2 * w + 1] : 0.0;
+        for (int w = 0; w < noise::kMaxWindows; w++) {
+            s1[w] = w < g.n_windows ? sh.sums[i][2 * w] : 0.0;
+            s2[w] = w < g.n_windows ? sh.sums[i][2 * w + 1] : 0.0;
+        }
+        const noise::Result r = noise::certify(s1, s2, ng, [row](int k) { return (double)row[k]; });
+        sdr_frame_rec rec;
+        rec.min_mean = r.min_mean;
+        rec.variance = r.variance;
+        rec.dev_in = r.dev_in;
+        rec.nf_in = r.nf_in;
+        rec.noise_dev = rec.noise_floor = rec.peak_thr = rec.listen_thr = 0;
+        rec.pad = r.ok ? 0.0f : (float)r.why;  // (diagnostic: why the frame went to the literal loops, noise_cert.h)
+        recs[frame] = rec;
+        if (!r.ok || force_exact == 1 || (force_exact > 1 && f % force_exact == 0))
+            sh.flagged[atomicAdd(&sh.n_flagged, 1)] = (unsigned short)i;
     }
-    const noise::Result r = noise::certify(s1, s2, g, [row](int i) { return (double)row[i]; });
-    sdr_frame_rec rec;
-    rec.min_mean = r.min_mean;
-    rec.variance = r.variance;
-    rec.dev_in = r.dev_in;
-    rec.nf_in = r.nf_in;
-    rec.noise_dev = rec.noise_floor = rec.peak_thr = rec.listen_thr = 0;
-    rec.pad = 0;
-    recs[frame] = rec;
-    // (force_exact: 1 = every frame, k > 1 = every k-th - tests and sdr_read_frame_records' exact variances)
-    if (!r.ok || force_exact == 1 || (force_exact > 1 && f % force_exact == 0)) {
-        const unsigned at = atomicAdd(exact_list, 1u);
-        exact_list[1 + at] = (unsigned)frame;
+    __syncthreads();
+    const int n_flagged = sh.n_flagged;  // (workgroup-uniform)
+    if (n_flagged == 0)
+        return;
+    float *row_lds = reinterpret_cast<float *>(smem + (sizeof(ScanLds) + 15) / 16 * 16);
+    double *terms = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(row_lds) + (size_t)g.n * sizeof(float));
+    for (int k = 0; k < n_flagged; k++) {
+        const size_t frame = (size_t)band * g.stride + f_begin + sh.flagged[k];
+        exact_frame_block(sh, row_lds, terms, psd + frame * g.n, recs + frame, ng);
     }
 }
-
-// k_noise_exact_list - the literal FindNoiseFloor (noise_cert.h exact_frame: the oracle's loops) for the listed frames,
-// one wave each: the window sums are independent chains (a lane each), the rest runs on lane 0.  Overwrites the four
-// FindNoiseFloor fields of the frame's record; the thresholds kernel runs behind it.
-// (First version: a wave per frame straight from global memory, lane 0 walking 12 000 dependent loads and additions -
-// a millisecond per flagged frame, a quarter of a millisecond per batch on average, on the stream every threshold waits
-// for.  Now a workgroup per frame: the row is staged in LDS once, the ten window chains run side by side from there, and
-// the variance chain's terms - fl(fl(x - mean)^2), each its own rounding, any thread can form them - are produced chunk
-// by chunk into an LDS double buffer by three waves while thread 0 adds the previous chunk in order: the chain runs at the
-// pace of a dependent float64 add with its operand already on chip, 45 us for 12 000 terms.)
-constexpr int kExactThreads = 256, kExactChunk = 2048;
-__global__ __launch_bounds__(kExactThreads) void k_noise_exact_list(const float *__restrict__ psd, sdr_frame_rec *__restrict__ recs, noise::Geom g,
-                                                                    const unsigned *__restrict__ exact_list)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *row = reinterpret_cast<float *>(smem);                                  // [n]
-    double *terms = reinterpret_cast<double *>(smem + (size_t)g.n * sizeof(float));  // [2][kExactChunk]
-    __shared__ double s_sums[noise::kMaxWindows];
-    __shared__ noise::Selection s_sel;
-    const unsigned count = exact_list[0];
-    const int tid = threadIdx.x;
-    for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {  // (workgroup-uniform)
-        const size_t frame = exact_list[1 + k];
-        const float *__restrict__ src = psd + frame * g.n;
-        for (int i = tid; i < g.n; i += kExactThreads)
-            row[i] = src[i];
-        __syncthreads();
-        auto x_at = [row](int i) { return (double)row[i]; };
-        if (tid < g.n_windows)
-            s_sums[tid] = noise::window_sum(g, x_at, tid);
-        __syncthreads();
-        if (tid == 0)
-            s_sel = noise::select_window(g, x_at(0), s_sums);
-        __syncthreads();
-        const noise::Selection sel = s_sel;
-        const int total = noise::result_to(g, sel.window) - g.edge + 1, n_chunks = (total + kExactChunk - 1) / kExactChunk;
-        auto produce = [&](int c) {  // chunk c of the terms, by the threads of waves 1-3
-            double *dst = terms + (size_t)(c & 1) * kExactChunk;
-            const int base = c * kExactChunk, len = min(kExactChunk, total - base);
-            for (int i = tid - 64; i < len; i += kExactThreads - 64)
-                dst[i] = noise::variance_term(x_at(g.edge + base + i), sel.result_mean);
-        };
-        if (tid >= 64)
-            produce(0);
-        __syncthreads();
-        double sum = 0;
-        for (int c = 0; c < n_chunks; c++) {
-            if (tid >= 64 && c + 1 < n_chunks)
-                produce(c + 1);
-            if (tid == 0) {
-                const double *src_t = terms + (size_t)(c & 1) * kExactChunk;
-                const int len = min(kExactChunk, total - c * kExactChunk);
-                for (int i = 0; i < len; i++)
-                    sum += src_t[i];  // :246-247, in order
-            }
-            __syncthreads();
-        }
-        if (tid == 0) {
-            const noise::Result r = noise::finish_frame(g, sel, sum);
-            recs[frame].min_mean = r.min_mean;
-            recs[frame].variance = r.variance;
-            recs[frame].dev_in = r.dev_in;
-            recs[frame].nf_in = r.nf_in;
-        }
-        __syncthreads();  // (the next frame's staging overwrites the row)
-    }
-}
-
-__global__ void k_noise_list_reset(unsigned *exact_list) { exact_list[0] = 0u; }
 
 // k_noise_exact_check - the literal FindNoiseFloor for EVERY frame of one band's batch, a wave per frame (reads that drain
 // the pipeline: sdr_read_frame_records).  The record's variance - which the hot path only brackets: nothing consumes its
@@ -313,15 +332,20 @@ hipError_t launch_noise_exact_check(const float *psd_band, sdr_frame_rec *recs_b
     return hipGetLastError();
 }
 
+// parts a slot's frames are dealt over (k_peaks.hip's k_bound_finish must add as many)
+int scan_parts(int n_slots, int n_bands) { return (long)n_slots * n_bands < 160 ? 2 : 1; }
+
 static int scan_jmax(int window)
 {
     const int j = (window + 63) / 64;
     return j <= 2 ? 2 : j <= 5 ? 5 : j <= 10 ? 10 : j <= 19 ? 19 : 26;
 }
 
-// One batch's scan: S1 / S2 of every frame and window, and (do_bound) the bound of every cumulation the batch completes.
-hipError_t launch_psd_scan(const float *psd, double *wsum, float *cum_out, const BatchCursor *cur, NoiseGeom ng, CumGeom cg, int n_slots,
-                           int n_bands, bool do_bound, hipStream_t stream)
+// One batch's noise floor: the FindNoiseFloor fields of every frame's record and (do_bound) the unit counts of every
+// cumulation the batch completes.  force_exact: see k_psd_scan (tests).  (A stage event armed by the caller rides on
+// the launch.)
+hipError_t launch_psd_scan(const float *psd, sdr_frame_rec *recs, float *cum_out, float *cum_part, const BatchCursor *cur, NoiseGeom ng,
+                           CumGeom cg, int n_slots, int n_bands, bool do_bound, int force_exact, hipStream_t stream)
 {
     if (cg.n_frames <= 0 || n_bands <= 0)
         return hipSuccess;
@@ -342,37 +366,16 @@ hipError_t launch_psd_scan(const float *psd, double *wsum, float *cum_out, const
     const int edge_hi = g.edge + g.n_windows * g.window;
     const int n_items = g.n_windows + (do_bound ? (g.edge + g.piece - 1) / g.piece + (g.n - edge_hi + g.piece - 1) / g.piece : 0);
     const int waves = n_items < kScanMaxWaves ? n_items : kScanMaxWaves;
-    double a128, per_frame;
-    gomath::cum_bound_constants(g.n, &a128, &per_frame);
-    // (graph mode: the grid must cover the slots of any cumulation phase - the kernel returns for slots beyond the batch)
-    const dim3 grid(n_slots, n_bands), block(64 * waves);
-    switch (jmax) {
-    case 2: launch_kernel(k_psd_scan<2>, grid, block, 0, stream, psd, wsum, cum_out, cur, g, a128, per_frame); break;
-    case 5: launch_kernel(k_psd_scan<5>, grid, block, 0, stream, psd, wsum, cum_out, cur, g, a128, per_frame); break;
-    case 10: launch_kernel(k_psd_scan<10>, grid, block, 0, stream, psd, wsum, cum_out, cur, g, a128, per_frame); break;
-    case 19: launch_kernel(k_psd_scan<19>, grid, block, 0, stream, psd, wsum, cum_out, cur, g, a128, per_frame); break;
-    default: launch_kernel(k_psd_scan<26>, grid, block, 0, stream, psd, wsum, cum_out, cur, g, a128, per_frame); break;
+    g.parts = scan_parts(n_slots, n_bands);
+    // without bounds: as many frames per workgroup as leave the chip about two workgroups per CU, at least eight
+    g.fpw = 0;
+    if (!do_bound) {
+        const long total = (long)cg.n_frames * n_bands;
+        g.fpw = (int)(total / 512);
+        g.fpw = g.fpw < 8 ? 8 : (g.fpw > kScanMaxFrames ? kScanMaxFrames : g.fpw);
     }
-    return hipGetLastError();
-}
-
-// The frame records' FindNoiseFloor fields from the scan's sums (certified, or the literal loops for the flagged frames).
-// exact_list: 1 + n_bands * stride words.  force_exact: see k_noise_finish.  (A stage event armed by the caller rides on
-// the last launch.)
-hipError_t launch_noise_finish(const float *psd, const double *wsum, sdr_frame_rec *recs, NoiseGeom ng, int n_frames, int n_bands,
-                               int stride, unsigned *exact_list, int force_exact, hipStream_t stream)
-{
-    if (n_frames <= 0 || n_bands <= 0)
-        return hipSuccess;
-    noise::Geom g{ng.n, ng.edge, ng.window, ng.n_windows, ng.inv_n2};
-    const hipEvent_t done = t_done_event;
-    t_done_event = nullptr;
-    hipLaunchKernelGGL(k_noise_list_reset, dim3(1), dim3(1), 0, stream, exact_list);
-    hipLaunchKernelGGL(k_noise_finish, dim3((n_frames + 255) / 256, n_bands), dim3(256), 0, stream, psd, wsum, recs, g, n_frames, stride,
-                       exact_list, force_exact);
-    t_done_event = done;
-    // a workgroup per flagged frame (they loop when there are more frames than workgroups: every frame flagged, in tests)
-    const unsigned lds = (unsigned)((size_t)ng.n * sizeof(float) + 2u * kExactChunk * sizeof(double));
+    const unsigned lds = (unsigned)scan_lds_bytes(ng.n);
+    // more than 64 KB of dynamic LDS needs the attribute, once per device and instantiation
     static std::once_flag attr_once[64];
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -382,13 +385,26 @@ hipError_t launch_noise_finish(const float *psd, const double *wsum, sdr_frame_r
         return hipErrorInvalidDevice;
     hipError_t attr_err = hipSuccess;
     std::call_once(attr_once[dev], [&] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_noise_exact_list), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       16384 * (int)sizeof(float) + 2 * kExactChunk * (int)sizeof(double));
+        const int max_lds = scan_lds_bytes(16384);
+        for (const void *k : {reinterpret_cast<const void *>(&k_psd_scan<2>), reinterpret_cast<const void *>(&k_psd_scan<5>),
+                              reinterpret_cast<const void *>(&k_psd_scan<10>), reinterpret_cast<const void *>(&k_psd_scan<19>),
+                              reinterpret_cast<const void *>(&k_psd_scan<26>)}) {
+            const hipError_t ae = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+            if (ae != hipSuccess)
+                attr_err = ae;
+        }
     });
     if (attr_err != hipSuccess)
         return attr_err;
-    const int wgs = force_exact == 1 ? 1024 : 32;
-    launch_kernel(k_noise_exact_list, dim3(wgs), dim3(kExactThreads), lds, stream, psd, recs, g, static_cast<const unsigned *>(exact_list));
+    // (graph mode: the grid must cover the slots of any cumulation phase - the kernel returns for slots beyond the batch)
+    const dim3 grid(do_bound ? n_slots * g.parts : (cg.n_frames + g.fpw - 1) / g.fpw, n_bands), block(64 * waves);
+    switch (jmax) {
+    case 2: launch_kernel(k_psd_scan<2>, grid, block, lds, stream, psd, recs, cum_out, cum_part, cur, g, ng.inv_n2, force_exact); break;
+    case 5: launch_kernel(k_psd_scan<5>, grid, block, lds, stream, psd, recs, cum_out, cum_part, cur, g, ng.inv_n2, force_exact); break;
+    case 10: launch_kernel(k_psd_scan<10>, grid, block, lds, stream, psd, recs, cum_out, cum_part, cur, g, ng.inv_n2, force_exact); break;
+    case 19: launch_kernel(k_psd_scan<19>, grid, block, lds, stream, psd, recs, cum_out, cum_part, cur, g, ng.inv_n2, force_exact); break;
+    default: launch_kernel(k_psd_scan<26>, grid, block, lds, stream, psd, recs, cum_out, cum_part, cur, g, ng.inv_n2, force_exact); break;
+    }
     return hipGetLastError();
 }
 

@@ -531,33 +531,43 @@ bool cum_bound_pays(int n_frames, int n_bands, int n)
     return (double)n_frames * (double)n_bands * (double)n >= 64.0 * 1024.0 * 1024.0;
 }
 
-// k_bound_slot0 - the bound of the cumulation a batch completes FIRST (slot 0: it continues the one carried in) from the
-// unit count k_psd_scan left in its row and the carry: gomath::cum_bound, as k_cum_bound forms it.
-__global__ __launch_bounds__(256) void k_bound_slot0(float *__restrict__ cum_out, const float *__restrict__ carry0, const float *__restrict__ carry1,
-                                                     int carry_in_arg, const BatchCursor *__restrict__ cur, CumGeom g, double a128, double per_frame)
+// k_bound_finish - the bounds of the cumulations a batch completes from the unit counts k_psd_scan left in their rows
+// (one or two partial counts per bin: a slot's frames may have been dealt over two workgroups) and, for the first one -
+// slot 0 continues the cumulation carried in - the carry: gomath::cum_bound, as k_cum_bound forms it.
+__global__ __launch_bounds__(256) void k_bound_finish(float *__restrict__ cum_out, const float *__restrict__ cum_part, int parts,
+                                                      const float *__restrict__ carry0, const float *__restrict__ carry1, int carry_in_arg,
+                                                      const BatchCursor *__restrict__ cur, CumGeom g, double a128, double per_frame)
 {
     int carry_sel = carry_in_arg;
     if (cur) {
         g.count0 = cur->count0;
         carry_sel = cur->carry_in;
     }
-    const int len = SDR_CUMULATION_SIZE - g.count0;
-    if (len > g.n_frames)
+    const int slot = blockIdx.y, band = blockIdx.z;
+    int begin, len;
+    cum_slot_frames(slot, g.count0, &begin, &len);
+    if (begin + len > g.n_frames)
         return;  // the batch does not complete it
-    const int bin = blockIdx.x * blockDim.x + threadIdx.x, band = blockIdx.y;
+    const int bin = blockIdx.x * blockDim.x + threadIdx.x;
     if (bin >= g.n)
         return;
     const float *__restrict__ carry_in = carry_sel ? carry1 : carry0;
-    float *o = cum_out + ((size_t)band * g.max_chunks) * g.n + bin;
-    const unsigned units = __float_as_uint(*o);
-    const double c0 = g.count0 > 0 ? (double)carry_in[(size_t)band * g.n + bin] : 0.0;
-    *o = gomath::cum_bound(c0, units, len, a128, per_frame, units == 0xffffffffu);
+    const size_t at = ((size_t)band * g.max_chunks + slot) * g.n + bin;
+    unsigned units = __float_as_uint(cum_out[at]);
+    bool special = units == 0xffffffffu;
+    if (parts > 1) {
+        const unsigned u1 = __float_as_uint(cum_part[at]);
+        special = special || u1 == 0xffffffffu;
+        units += u1;
+    }
+    const double c0 = (slot == 0 && g.count0 > 0) ? (double)carry_in[(size_t)band * g.n + bin] : 0.0;
+    cum_out[at] = gomath::cum_bound(c0, units, len, a128, per_frame, special);
 }
 
 // One batch's cumulation work, on `stream`: bounds of the cumulations it completes, the exact carry of the one it leaves
 // open.  (A stage event armed by the caller rides on the last launch.)
 hipError_t launch_cumulate(const float *psd, const void *db_tab, float *carry0, float *carry1, int carry_in, float *cum_out,
-                           const BatchCursor *cur, CumGeom g, int n_slots, int n_bands, bool bound_done, hipStream_t stream)
+                           const float *cum_part, const BatchCursor *cur, CumGeom g, int n_slots, int n_bands, bool bound_done, hipStream_t stream)
 {
     const double inv_n2 = 1.0 / ((double)g.n * (double)g.n);
     const int threads = g.n < SDR_CUM_THREADS ? g.n : SDR_CUM_THREADS;
@@ -571,8 +581,8 @@ hipError_t launch_cumulate(const float *psd, const void *db_tab, float *carry0, 
     const hipEvent_t done = t_done_event;
     t_done_event = nullptr;
     if (bound_done) {
-        hipLaunchKernelGGL(k_bound_slot0, dim3((g.n + 255) / 256, n_bands), dim3(256), 0, stream, cum_out, carry0, carry1, carry_in, cur, g, a128,
-                           per_frame);
+        hipLaunchKernelGGL(k_bound_finish, dim3((g.n + 255) / 256, n_slots, n_bands), dim3(256), 0, stream, cum_out, cum_part,
+                           scan_parts(n_slots, n_bands), carry0, carry1, carry_in, cur, g, a128, per_frame);
     } else {
         static std::once_flag attr_once[64];
         int dev = 0;

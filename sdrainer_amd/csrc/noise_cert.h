@@ -54,6 +54,8 @@ struct Result {
     double variance;  // the reference's variance to within its bracket (exact when `exact`)
     int window;       // winning window
     bool ok;          // accepted: min_mean, dev_in, nf_in are the reference's bits
+    int why;          // not accepted: 1 special sum, 2 means too close to order, 3 minimum on a float32 boundary, 4 / 5 special value,
+                      // 6 variance bracket reaches zero, 7 standard deviation on a float32 boundary
 };
 
 SDR_HD inline double next_up(double x) { return ::nextafter(x, INFINITY); }
@@ -82,7 +84,7 @@ SDR_HD inline Result certify(const double *s1, const double *s2, const Geom &g, 
     for (int w = 0; w < g.n_windows; w++) {
         const double S = s1[w];
         if (!(S >= 0.0) || !(S <= 1.7e308) || !(s2[w] <= 1.7e308))
-            return r;  // NaN, infinity (or a negative sum: there is no such psd): the literal loops decide
+            return (r.why = 1), r;  // NaN, infinity (or a negative sum: there is no such psd): the literal loops decide
         const double lo = next_down(next_down(S * (1.0 - dm)) / W);
         const double hi = next_up(next_up(S * (1.0 + dm)) / W);
         if (win < 0 || hi < min_lo) {  // `first`, or certainly smaller
@@ -90,12 +92,12 @@ SDR_HD inline Result certify(const double *s1, const double *s2, const Geom &g, 
             min_hi = hi;
             win = w;
         } else if (!(lo >= min_hi)) {
-            return r;  // may or may not be smaller than the minimum so far
+            return (r.why = 2), r;  // may or may not be smaller than the minimum so far
         }
     }
     const float mm_lo = (float)min_lo, mm_hi = (float)min_hi;
     if (!(mm_lo == mm_hi))
-        return r;
+        return (r.why = 3), r;
     r.window = win;
     r.min_mean = mm_lo;
     r.nf_in = nf_in_of(mm_lo, g.inv_n2);
@@ -107,12 +109,12 @@ SDR_HD inline Result certify(const double *s1, const double *s2, const Geom &g, 
     }
     const double xl = x_at(g.edge + (win + 1) * g.window);
     if (!(xl >= 0.0) || !(xl <= 1.8e19))
-        return r;
+        return (r.why = 4), r;
     S1 += xl;
     S2 += xl * xl;
     const double nt = (double)(win + 1) * W + 1.0;
     if (!(S2 <= 1.7e308))
-        return r;
+        return (r.why = 5), r;
     // V(m) = sum (x - m)^2 = S2 - 2 m S1 + nt m^2 for the mean m in [min_lo, min_hi]; the evaluation loses at most
     // (kScanTerms + 8) u of the sum of the magnitudes; between the two ends a parabola dips at most nt width^2 below
     // the lower of them
@@ -124,7 +126,7 @@ SDR_HD inline Result certify(const double *s1, const double *s2, const Geom &g, 
     double v_lo = (v_a < v_b ? v_a : v_b) - e_abs;
     double v_hi = (v_a < v_b ? v_b : v_a) + e_abs;
     if (!(v_lo > 0.0) || !(v_hi <= 1.7e308))
-        return r;
+        return (r.why = 6), r;
     // the reference's terms: d = fl(x - m) (1 rounding), fl(d d) (1 more) - within 3 u (1 + tiny) of (x - m)^2 - and
     // their sequential sum, nt - 1 more roundings of a growing non-negative sum
     const double dv = (nt + 3.0) * kU * 1.0001;
@@ -134,7 +136,7 @@ SDR_HD inline Result certify(const double *s1, const double *s2, const Geom &g, 
     const float sd_lo = (float)::sqrt(var_lo), sd_hi = (float)::sqrt(var_hi);  // (IEEE sqrt, float32 rounding: monotone)
     r.variance = 0.5 * (var_lo + var_hi);
     if (!(sd_lo == sd_hi))
-        return r;
+        return (r.why = 7), r;
     r.dev_in = dev_in_of(sd_lo, g.inv_n2);
     r.ok = true;
     return r;

@@ -85,6 +85,8 @@ struct ScanGeom {
     int stride, n_frames, count0, max_chunks;  // CumGeom
     int piece;                               // edge pieces hold at most this many bins (64 per-lane slots)
     int do_bound;                            // also the bound of every cumulation the batch completes
+    int fpw;                                 // do_bound == 0: frames per workgroup (the slots play no part)
+    int parts;                               // do_bound == 1: workgroups a slot's frames are dealt over (1 or 2)
 };
 
 struct PeakGeom {
@@ -161,14 +163,15 @@ hipError_t launch_set_debounce(ListenerSlot *slots, int n, int threshold, hipStr
 // bound_done: k_psd_scan has written the bounds of the completed cumulations (slot 0's as its raw unit count: the carry
 // is added here, on the stream the carry is produced on)
 hipError_t launch_cumulate(const float *psd, const void *db_tab, float *carry0, float *carry1, int carry_in, float *cum_out,
-                           const BatchCursor *cur, CumGeom g, int n_slots, int n_bands, bool bound_done, hipStream_t stream);
+                           const float *cum_part, const BatchCursor *cur, CumGeom g, int n_slots, int n_bands, bool bound_done, hipStream_t stream);
+int scan_parts(int n_slots, int n_bands);
 bool cum_bound_pays(int n_frames, int n_bands, int n);
-hipError_t launch_psd_scan(const float *psd, double *wsum, float *cum_out, const BatchCursor *cur, NoiseGeom ng, CumGeom cg, int n_slots,
-                           int n_bands, bool do_bound, hipStream_t stream);
+// k_noise_scan.hip: the FindNoiseFloor fields of every frame's record, certified or literal, and (do_bound) the unit counts
+// of the completed cumulations - one kernel
+hipError_t launch_psd_scan(const float *psd, sdr_frame_rec *recs, float *cum_out, float *cum_part, const BatchCursor *cur, NoiseGeom ng,
+                           CumGeom cg, int n_slots, int n_bands, bool do_bound, int force_exact, hipStream_t stream);
 hipError_t launch_noise_exact_check(const float *psd_band, sdr_frame_rec *recs_band, NoiseGeom ng, int n_frames, unsigned *mismatches,
                                     hipStream_t stream);
-hipError_t launch_noise_finish(const float *psd, const double *wsum, sdr_frame_rec *recs, NoiseGeom ng, int n_frames, int n_bands,
-                               int stride, unsigned *exact_list, int force_exact, hipStream_t stream);
 hipError_t launch_spectrum_row(const float *psd_row, float *out, int n, hipStream_t stream);
 hipError_t launch_pack_listen(ListenerSlot *slots, const sdr_edge *edges, const uint32_t *edge_counts, const uint32_t *text,
                               const uint32_t *text_frames, const DropCounters *drops, ResultsLayout lay, int n_slots, int n_bands, unsigned char *host,
