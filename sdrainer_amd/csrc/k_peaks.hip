@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void k_spectrum_row(const float *__restrict__ 
 // bound or the exact value, and both classify every bin that is above as above - the list can only differ in bins that
 // need not have been refined.
 // ---------------------------------------------------------------------------------------------
-constexpr int kRefineSpan = 4096, kRefineThreads = 256;
+constexpr int kRefineSpan = 4096, kRefineThreads = 256;  // (the <SPAN, THREADS> of short batches; long ones: whole rows x 1024)
 __device__ __forceinline__ int peak_words(int n) { return n >> 6; }
 
 // exclusive prefix of per-word bit counts over `words` words (one wave: each lane takes `per` consecutive words);
@@ -319,6 +319,7 @@ __device__ __forceinline__ int word_prefix(const unsigned long long *bits, int *
     return total;
 }
 
+template <int kRefineSpan, int kRefineThreads>
 __global__ __launch_bounds__(kRefineThreads) void k_cum_refine(float *__restrict__ cum, const float *__restrict__ psd, const void *__restrict__ db_tab,
                                                                const float *__restrict__ carry0, const float *__restrict__ carry1, int carry_in_arg,
                                                                const sdr_frame_rec *__restrict__ recs, const BatchCursor *__restrict__ cur, PeakGeom g,
@@ -666,8 +667,21 @@ hipError_t launch_find_peaks(float *cum, const float *psd, const void *db_tab, c
     t_done_event = nullptr;
     const double inv_n2 = 1.0 / ((double)g.n * (double)g.n);
     if (cum_bound_pays(n_frames, n_bands, g.n))  // (otherwise k_cumulate left every row exact)
-        hipLaunchKernelGGL(k_cum_refine, dim3(n_chunks, (g.n + kRefineSpan - 1) / kRefineSpan, n_bands), dim3(kRefineThreads), 0, stream, cum, psd,
-                           db_tab, carry0, carry1, carry_in, recs, cur, g, n_frames, inv_n2);
+    {
+        // Spans of 4096 bins x 256 threads keep a cumulation's refinement - a latency chain of a hundred scattered sector
+        // reads - short where the peaks stream's length bounds the step (few cumulations per batch).  With many
+        // cumulations per batch what counts is the CU time the kernel HOLDS: four waves of a small workgroup hold a whole
+        // CU against the FFT's workgroups just as sixteen do, so a workgroup takes the whole row (10.9 -> CU-ms per
+        // 8192-frame step; SDR_REFINE_WIDE = 0 / 1 forces one).
+        static const int wide_env = getenv("SDR_REFINE_WIDE") ? atoi(getenv("SDR_REFINE_WIDE")) : -1;
+        const bool wide = wide_env >= 0 ? wide_env != 0 : (g.n >= 4096 && (long)n_chunks * n_bands >= 64);
+        if (wide)
+            hipLaunchKernelGGL((k_cum_refine<16384, 1024>), dim3(n_chunks, (g.n + 16383) / 16384, n_bands), dim3(1024), 0, stream, cum, psd, db_tab,
+                               carry0, carry1, carry_in, recs, cur, g, n_frames, inv_n2);
+        else
+            hipLaunchKernelGGL((k_cum_refine<kRefineSpan, kRefineThreads>), dim3(n_chunks, (g.n + kRefineSpan - 1) / kRefineSpan, n_bands),
+                               dim3(kRefineThreads), 0, stream, cum, psd, db_tab, carry0, carry1, carry_in, recs, cur, g, n_frames, inv_n2);
+    }
     t_done_event = done;
     const int threads = g.n < kPeakThreadsMax ? g.n : kPeakThreadsMax;
     launch_kernel(k_find_peaks, dim3(n_chunks, n_bands), dim3(threads), lds, stream, static_cast<const float *>(cum), recs, peaks, counts, cur, g,
