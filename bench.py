@@ -340,6 +340,10 @@ def main():
                      peak_threshold=shared.peak_threshold, signal_debounce=shared.signal_debounce,
                      max_listeners=shared.max_listeners, max_batch_frames=frames, max_peaks=1024, find_peaks=True,
                      trace=False, device_id=local_rank)
+    # the bank behind the job-wide setters (sharding.ShardedBank: rank 0's values, applied on every rank at the same batch
+    # boundary) - one collective setter call before the timed region, as a host would make when the operator turns a knob
+    sbank = sharding.ShardedBank(bank, shared, dist, coll_dev, n_bands_total=bands_per_gpu * world)
+    shared = sbank.set_peak_threshold(shared.peak_threshold)
     stream = torch.cuda.current_stream()
     if args.graph:
         stream = torch.cuda.Stream()  # the null stream cannot be captured
@@ -524,11 +528,18 @@ def main():
     else:
         decoded = sum(len(bank.read_text(0, lid)) for lid in range(min(tones, 4)))
     chunks = bank.last_batch_chunks
+    # every band's record on every rank, once, after the timed region: each band of the job must have decoded something
+    last_rec = bank.read_frame_records(0)[-1]
+    local_records = np.stack([sharding.make_record(b, int(bank.total_frames), int(bank.total_frames) * n, chunks, delivered["edges"] if delivery else 0,
+                                                   decoded, float(last_rec["noise_floor"]), float(last_rec["listen_thr"])) for b in my_bands])
+    job_records = sbank.gather(local_records)
+    assert [int(r[0]) for r in job_records] == list(range(bands_per_gpu * world)), job_records[:, 0]
+    assert all(r[5] > 0 for r in job_records), "a band of the job decoded nothing"
     # rehearsal / test hook: what THIS rank worked on (tests/test_bench_ranks.py)
     if os.environ.get("SDR_BENCH_RANK_REPORT"):
         with open(os.environ["SDR_BENCH_RANK_REPORT"], "w") as fh:
             json.dump({"rank": rank, "bands": my_bands, "shared_config": sharding.describe(shared),
-                       "decoded_runes": decoded}, fh)
+                       "decoded_runes": decoded, "job_bands": [int(r[0]) for r in job_records]}, fh)
 
     result = {
         "metric": "IQ MSamples/s through FFT+peak+envelope",

@@ -196,15 +196,26 @@ std::unique_ptr<host::DeliveryBackend> make_results_backend(sdr_bank *b) { retur
 int results_attach_set(sdr_bank *b, int set_idx)
 {
     host::ResultSet &rs = b->results->set(set_idx);
-    if (rs.block || !b->res_layout.bytes)
+    if (!b->res_layout.bytes || (rs.block && rs.ev_listen && rs.ev_peaks))
         return SDR_OK;
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&rs.block), b->res_layout.bytes, hipHostMallocDefault));
-    memset(rs.block, 0, b->res_layout.bytes);
-    hipEvent_t ev = nullptr;
-    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    rs.ev_listen = ev;
-    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    rs.ev_peaks = ev;
+    // (the events first, the block last: a set is "attached" only with all three - a failure half way leaves nothing a
+    // later call would take for complete)
+    if (!rs.ev_listen) {
+        hipEvent_t ev = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        rs.ev_listen = ev;
+    }
+    if (!rs.ev_peaks) {
+        hipEvent_t ev = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        rs.ev_peaks = ev;
+    }
+    if (!rs.block) {
+        unsigned char *blk = nullptr;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&blk), b->res_layout.bytes, hipHostMallocDefault));
+        memset(blk, 0, b->res_layout.bytes);
+        rs.block = blk;
+    }
     return SDR_OK;
 }
 

@@ -77,11 +77,12 @@ public:
     void reset(bool on, int64_t batch_index)  // sdr_enable_results: undelivered batches go with the mode
     {
         std::lock_guard<std::mutex> g(mu_);
-        if (!on) {
-            for (auto &s : sets_)
-                s.meta.batch = -1;
-            parked_.clear();
-        }
+        // whatever the mode was: what was not delivered is discarded (the pipeline is drained, sdr_enable_results said so).
+        // (Round 4's advice: enabling delivery on a bank that already had it on kept the parked entries and the sets'
+        // batches - stale, never at deliver_next_ again - and a real batch parked behind them was never found.)
+        for (auto &s : sets_)
+            s.meta.batch = -1;
+        parked_.clear();
         on_ = on;
         deliver_next_ = batches_enqueued_ = batch_index;
     }

@@ -82,3 +82,59 @@ def gather_records(local: np.ndarray, dist, device) -> np.ndarray:
 
 def describe(cfg: SharedConfig) -> dict:
     return asdict(cfg)
+
+
+class ShardedBank:
+    """One rank's bank plus the job's shared configuration (rx/receiver.go:166-172,208-218: the reference's setters are
+    closures marshalled to the run goroutine and applied between frames; here a job is N processes, one per GPU, each with
+    the bands b = rank (mod world), and a setter is a COLLECTIVE: every rank calls it at the same batch boundary - the
+    ranks run the same program - rank 0's argument wins, it is broadcast (RCCL over xGMI with backend "nccl", gloo in the
+    CPU tests) and every rank applies it to its own bank through sdr_set_*, which takes effect at the next batch, never
+    inside one.  So every band of the job changes its threshold at the same frame.
+
+    `bank` is a sdrainer_amd.capi.Bank (or anything with set_peak_threshold(band, t), set_edge_width(e),
+    set_signal_debounce(band, d) and n_bands); `dist` torch.distributed or None."""
+
+    def __init__(self, bank, cfg: SharedConfig, dist, device, n_bands_total: int | None = None):
+        self.bank, self.dist, self.device = bank, dist, device
+        self.rank = dist.get_rank() if self._distributed() else 0
+        self.world = dist.get_world_size() if self._distributed() else 1
+        self.n_bands_total = n_bands_total if n_bands_total is not None else self.world * bank.n_bands
+        self.bands = bands_of_rank(self.n_bands_total, self.world, self.rank)
+        self.cfg = broadcast_config(cfg, dist, device)
+        self.setter_calls = 0
+        self._apply(self.cfg, None)  # (the bank gets every one of rank 0's values)
+
+    def _distributed(self) -> bool:
+        return self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size() > 1
+
+    def _apply(self, new: SharedConfig, old: SharedConfig | None):
+        for local in range(self.bank.n_bands):
+            if old is None or new.peak_threshold != old.peak_threshold:
+                self.bank.set_peak_threshold(local, float(new.peak_threshold))
+            if old is None or new.signal_debounce != old.signal_debounce:
+                self.bank.set_signal_debounce(local, int(new.signal_debounce))
+        if old is None or new.edge_width != old.edge_width:
+            self.bank.set_edge_width(int(new.edge_width))
+
+    def _collective_set(self, **changes):
+        """Rank 0's `changes` reach every rank's bank; what the other ranks passed is ignored."""
+        proposal = SharedConfig(**{**asdict(self.cfg), **changes})
+        new = broadcast_config(proposal, self.dist, self.device)
+        old, self.cfg = self.cfg, new
+        self._apply(new, old)
+        self.setter_calls += 1
+        return new
+
+    def set_peak_threshold(self, threshold: float):  # rx/receiver.go:208-211
+        return self._collective_set(peak_threshold=float(threshold))
+
+    def set_edge_width(self, edge_width: int):  # rx/receiver.go:217-218
+        return self._collective_set(edge_width=int(edge_width))
+
+    def set_signal_debounce(self, debounce: int):  # rx/receiver.go:212-216
+        return self._collective_set(signal_debounce=int(debounce))
+
+    def gather(self, local_records: np.ndarray) -> np.ndarray:
+        """Every rank's fixed-size per-band records on every rank, by band id."""
+        return gather_records(local_records, self.dist, self.device)

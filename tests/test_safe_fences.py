@@ -1,9 +1,10 @@
-"""The places where the product relies on documented-by-measurement hardware ordering rather than on the memory model
-- k_noise.hip's LDS flags ordered against data by program order only, k_fft_psd.hip's counted vmcnt - have a formally
-fenced build (-DSDR_SAFE_FENCES: workgroup-scope fences, acquire / release flags, full waits), made by
-__graft_entry__.build() beside the product.  The noise-floor chains, the thresholds that follow from them and the
-multi-frame FFT workgroups must give the same bits under it: the parity tests that exercise them are run again, in a
-process of their own, against that library."""
+"""The places where a kernel could rely on documented-by-measurement hardware ordering rather than on the memory model -
+k_noise.hip's LDS flags ordered against data by program order only, k_fft_psd.hip's counted vmcnt - have a formally fenced
+form (-DSDR_SAFE_FENCES: workgroup-scope fences, acquire / release flags, full waits).  Round 5 priced it (under a percent)
+and made it the PRODUCT; the program-order form is kept as a variant (__graft_entry__.build() makes it beside the product)
+so that the price stays measurable.  Both must give the same bits: the parity tests that exercise the chain kernels
+(SDR_NOISE_PATH=chains - the default noise path no longer has flags at all) and the multi-frame FFT workgroups are run
+again, in processes of their own, against each."""
 import os
 import subprocess
 import sys
@@ -15,18 +16,20 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_parity_under_the_fenced_build():
+@pytest.mark.parametrize("variant", [None, "program_order"])
+def test_parity_of_the_chain_kernels_under_both_builds(variant):
     from sdrainer_amd.csrc import build
 
-    lib = build.build_variant("safe_fences")
+    lib = build.build_variant(variant) if variant else build.build()
     assert os.path.exists(lib)
-    env = dict(os.environ, SDR_HIP_LIB=lib, SDR_FFT_FPW="4")  # (multi-frame workgroups: the counted-wait path)
+    # multi-frame 16-point FFT workgroups (the counted-wait path; block sizes below 16384) and the chain kernels
+    env = dict(os.environ, SDR_HIP_LIB=lib, SDR_FFT_FPW="4", SDR_NOISE_PATH="chains", SDR_FFT_R32="0")
     sel = "test_receiver_run_bit_exact or test_nine_window_geometry or test_config5_geometry or test_batch_split_invariance_and_carry"
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
                         "-k", sel, "-p", "no:cacheprovider"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert " passed" in p.stdout and "failed" not in p.stdout
-    # the selection really ran against the variant
+    # the selection really ran against that library
     q = subprocess.run([sys.executable, "-c", "from sdrainer_amd import capi; print(capi.LIB_PATH)"], env=env, cwd=ROOT,
                        capture_output=True, text=True)
     assert q.stdout.strip() == lib
