@@ -33,8 +33,8 @@ SMALL = "test_receiver_run_bit_exact or test_nine_window_geometry or test_config
      SMALL + " or config5 or config2"),
     # the randomised streams and cuts of the fuzz test through the cumulation's bound-and-refine path and the wide
     # refinement workgroups (its batches are far too short to pick either by themselves: round 4's advice)
-    ({"SDR_CUM_BOUND": "1", "SDR_REFINE_WIDE": "1"}, ["tests/test_gpu_fuzz.py"], "fuzz"),
-    ({"SDR_CUM_BOUND": "1", "SDR_REFINE_WIDE": "0", "SDR_NOISE_PATH": "chains", "SDR_VAR_MFMA": "0"}, ["tests/test_gpu_fuzz.py"], "fuzz"),
+    ({"SDR_CUM_BOUND": "1", "SDR_REFINE_WIDE": "1"}, ["tests/test_gpu_fuzz.py"], "random_streams"),
+    ({"SDR_CUM_BOUND": "1", "SDR_REFINE_WIDE": "0", "SDR_NOISE_PATH": "chains", "SDR_VAR_MFMA": "0"}, ["tests/test_gpu_fuzz.py"], "random_streams"),
 ])
 def test_parity_with_the_other_implementation_forced(env, files, sel):
     p = subprocess.run([sys.executable, "-m", "pytest", *[os.path.join(ROOT, f) for f in files], "-q", "-x", "-m", "gpu", "-k", sel,
