@@ -38,6 +38,10 @@ BYTES_PER_SAMPLE = 8   # one complex64 IQ sample read once
 # float64 vector rate without FMA (the bit-exact contract forbids fusing): MI355X's 78.6 TFLOP/s
 # FP64 vector peak counts an FMA as two, so 39.3 T lane-operations per second = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz
 F64_PEAK_TOPS = 39.3
+# what the chip SUSTAINS on independent v_mul_f64 / v_add_f64 streams with every CU full (tools/ubench_f64.hip, round 5,
+# gpurun_out -> profiles/r05_ubench_f64.txt): 30.8 T at four waves per SIMD, 29.1 at two, 22.4 at one - the clock comes
+# down under float64 load (1.8 - 1.9 GHz), so the spec-clock figure above is not reachable by any kernel
+F64_MEASURED_TOPS = 30.0
 
 WORKLOADS = {
     # name: (sample_rate, block_size, tracked signals per band, bands per GPU, free_last_window)
@@ -508,6 +512,9 @@ def main():
     if consumer is not None:
         consumer_stop.set()
         consumer.join(timeout=10)
+    # (the stage is called k_fft_psd in the library's profile whichever kernel serves it: N = 16384 with at most 512 listener
+    # slots in use runs k_fft_r32 - 512 threads x 32 points, the next frame prefetched into registers - unless SDR_FFT_R32=0)
+    fft_kernel_name = "k_fft_r32" if (n == 16384 and tones <= 512 and os.environ.get("SDR_FFT_R32", "1") != "0") else "k_fft_psd"
     fft_ms, fft_n = prof["k_fft_psd"]
     fft_avg_ms = fft_ms / max(fft_n, 1)
     fft_alone_ms = prof_alone["k_fft_psd"][0] / max(prof_alone["k_fft_psd"][1], 1)
@@ -585,7 +592,7 @@ def main():
                        else {"runes_decoded_first_listeners": decoded, "cumulations_per_step": chunks}),
         },
         "roofline": {
-            "bound": "hbm", "kernel": "k_fft_psd", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "bound": "hbm", "kernel": fft_kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "avg_launch_ms": round(fft_avg_ms, 4), "launches_timed": fft_n,
             "standalone": {"avg_launch_ms": round(fft_alone_ms, 4), "launches_timed": prof_alone["k_fft_psd"][1],
@@ -603,7 +610,10 @@ def main():
             # (the spec clock; inside k_fft_psd the shader clock reads 2.25 GHz - profiles/*_fft_standalone.txt - where the
             # same count gives 36.9: fractions of the peak below are about 6 % higher against that)
             "peak_Tops_at_measured_clock": round(F64_PEAK_TOPS * 2.25 / 2.4, 1),
+            "measured_peak_Tops": F64_MEASURED_TOPS,
             "frac": round(tops / F64_PEAK_TOPS, 4),
+            "frac_of_measured_peak": round(tops / F64_MEASURED_TOPS, 4),
+            "ceiling_hbm_frac_at_measured_peak": round(F64_MEASURED_TOPS * 1e12 / ops_fft * BYTES_PER_SAMPLE / (HBM_PEAK_GBS * 1e9), 4),
             "ceiling_hbm_frac": round(F64_PEAK_TOPS * 1e12 / ops_fft * BYTES_PER_SAMPLE / (HBM_PEAK_GBS * 1e9), 4),
             "whole_path_ops_per_sample": ops_path,
             "whole_path_ceiling_hbm_frac": round(F64_PEAK_TOPS * 1e12 / ops_path * BYTES_PER_SAMPLE / (HBM_PEAK_GBS * 1e9), 4),

@@ -38,6 +38,19 @@ constexpr int kExactChunk = 2048;                    // terms of the variance ch
 #if !defined(SDR_SCAN_AHEAD)
 #define SDR_SCAN_AHEAD 2  // frames whose loads are in flight ahead of the one being added up
 #endif
+#if !defined(SDR_SCAN_AUX)
+#define SDR_SCAN_AUX 2  // cache policy bits of the psd loads (2 = nt: the rows are not read again by this kernel)
+#endif
+
+using scan_rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ scan_rsrc_t scan_make_rsrc(const void *base, unsigned bytes)
+{
+    // (inputs made provably wave-uniform, otherwise the descriptor is rebuilt per lane)
+    const unsigned long long b = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes),
+                                             0x00020000);
+}
 
 __device__ __forceinline__ void scan_slot_frames(int slot, int count0, int *begin, int *len)
 {
@@ -57,12 +70,22 @@ __device__ __forceinline__ double dpp_moved(double x)
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, BANK_MASK, true);
     return __hiloint2double(hi, lo);
 }
+// a shift within the rows of sixteen, every lane written: lanes whose source lies outside the row read 0 (bound_ctrl), so
+// the destination needs no initial value (as `old = 0` each move cost a v_mov of its own: 24 of a frame's 60 reduction
+// instructions)
+template <int CTRL>
+__device__ __forceinline__ double dpp_row_shifted(double x)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum_to_lane63(double x)
 {
-    x += dpp_moved<0x111, 0xf, 0xf>(x);  // row_shr:1
-    x += dpp_moved<0x112, 0xf, 0xf>(x);  // row_shr:2
-    x += dpp_moved<0x114, 0xf, 0xe>(x);  // row_shr:4, banks 1-3
-    x += dpp_moved<0x118, 0xf, 0xc>(x);  // row_shr:8, banks 2-3: lane 15 of every row holds the row's sum
+    x += dpp_row_shifted<0x111>(x);      // row_shr:1
+    x += dpp_row_shifted<0x112>(x);      // row_shr:2
+    x += dpp_row_shifted<0x114>(x);      // row_shr:4
+    x += dpp_row_shifted<0x118>(x);      // row_shr:8: lane 15 of every row holds the row's sum (a prefix scan: lane l its first l + 1)
     x += dpp_moved<0x142, 0xa, 0xf>(x);  // row_bcast:15 into rows 1 and 3
     x += dpp_moved<0x143, 0xc, 0xf>(x);  // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's sum
     return x;
@@ -186,18 +209,22 @@ __global__ __launch_bounds__(64 * kScanMaxWaves) void k_psd_scan(const float *__
             len = min(g.piece, g.n - b0);
         }
         const bool bound = g.do_bound && complete;
-        unsigned units[JMAX], special[JMAX];
+        unsigned units[JMAX], hw_max = 0u;
 #pragma unroll
         for (int j = 0; j < JMAX; j++)
-            units[j] = special[j] = 0u;
-        // lane's bins: b0 + lane + 64 j, j < JMAX, valid while < b0 + len (an invalid one is not loaded and adds 0)
-        const unsigned off0 = (unsigned)(b0 + (lane < len ? lane : 0));
-        float v[SDR_SCAN_AHEAD + 1][JMAX];
+            units[j] = 0u;
+        // lane's bins: b0 + lane + 64 j, j < JMAX, valid while < b0 + len.  The loads are BUFFER loads through a descriptor
+        // that spans exactly the segment's bytes of one row: a bin beyond the segment reads as 0.0 without a compare, an exec
+        // mask or a branch, and the address is a scalar base plus one per-lane offset.  (As global loads under per-lane
+        // predicates the loop was 38 instructions per value, five of them the arithmetic.)  What such a bin adds is harmless:
+        // nothing to S1 / S2, something to a unit count that is never stored.
+        const unsigned lane4 = (unsigned)lane * 4u;
+        unsigned v[SDR_SCAN_AHEAD + 1][JMAX];
         auto fetch = [&](int f, int k) {
-            const float *__restrict__ row = rows + (size_t)(f - f_begin) * g.n;
+            const scan_rsrc_t row = scan_make_rsrc(rows + (size_t)(f - f_begin) * g.n + b0, (unsigned)len * 4u);
 #pragma unroll
             for (int j = 0; j < JMAX; j++)
-                v[k][j] = (lane + 64 * j < len) ? __builtin_nontemporal_load(row + off0 + 64 * j) : 0.0f;
+                v[k][j] = __builtin_amdgcn_raw_buffer_load_b32(row, lane4 + 256u * (unsigned)j, 0, SDR_SCAN_AUX);
         };
         // (the frame loop is unrolled over the ring of SDR_SCAN_AHEAD + 1 register sets)
         constexpr int RING = SDR_SCAN_AHEAD + 1;
@@ -213,22 +240,14 @@ __global__ __launch_bounds__(64 * kScanMaxWaves) void k_psd_scan(const float *__
                     break;
                 if (f + SDR_SCAN_AHEAD < f_end)
                     fetch(f + SDR_SCAN_AHEAD, (k + SDR_SCAN_AHEAD) % RING);
-                double s1 = 0.0, s2 = 0.0;
+                if (w >= 0) {  // (wave-uniform)
+                    double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-                for (int j = 0; j < JMAX; j++) {
-                    const float x = v[k][j];
-                    if (w >= 0) {
-                        const double xd = (double)x;
+                    for (int j = 0; j < JMAX; j++) {
+                        const double xd = (double)__uint_as_float(v[k][j]);
                         s1 += xd;
-                        s2 += xd * xd;  // (exact: a float32 squared has 48 bits)
+                        s2 = __builtin_fma(xd, xd, s2);  // (a float32 squared has 48 bits: the product is exact either way)
                     }
-                    if (bound && lane + 64 * j < len) {
-                        const unsigned hw = __float_as_uint(x) >> 16;  // gomath::cum_bound_units / cum_bound_special
-                        units[j] += (hw < 128u ? 128u : hw) + 1u;
-                        special[j] |= hw + 0x8080u;  // bit 16 set  <=>  hw >= 0x7f80: infinity, NaN or a sign bit
-                    }
-                }
-                if (w >= 0) {
                     s1 = wave_sum_to_lane63(s1);
                     s2 = wave_sum_to_lane63(s2);
                     if (lane == 63) {
@@ -236,19 +255,31 @@ __global__ __launch_bounds__(64 * kScanMaxWaves) void k_psd_scan(const float *__
                         sh.sums[f - f_begin][2 * w + 1] = s2;
                     }
                 }
+                if (bound) {  // (wave-uniform)
+#pragma unroll
+                    for (int j = 0; j < JMAX; j++) {
+                        const unsigned hw = v[k][j] >> 16;  // gomath::cum_bound_units without its + 1 (added below, per frame)
+                        units[j] += hw < 128u ? 128u : hw;
+                        hw_max = hw > hw_max ? hw : hw_max;  // gomath::cum_bound_special: hw >= 0x7f80 - infinity, NaN or a sign bit
+                    }
+                }
             }
         }
         if (bound) {
+            // a special value anywhere in a LANE's columns marks all of them (one maximum per value instead of a flag word per
+            // column: the bound of such a column becomes +infinity, which is a bound, and its exact evaluation decides - a
+            // psd row that holds an infinity or a NaN is not a case to be fast in)
+            const bool sp = hw_max >= 0x7f80u;
+            const unsigned n_run = (unsigned)(f_end - f_begin);  // units(psd) = max(hw, 128) + 1: the + 1 of every frame
 #pragma unroll
             for (int j = 0; j < JMAX; j++) {
                 if (lane + 64 * j < len) {
                     const int bin = b0 + lane + 64 * j;
-                    const bool sp = (special[j] >> 16) != 0u;
                     // The raw unit count goes out (all ones: a special value in the column), part 0's into the slot's row,
                     // part 1's into the second buffer: k_bound_finish (k_peaks.hip) adds the parts and - slot 0 continues the
                     // cumulation carried in from the previous batch, and that carry is produced on the peaks stream - the
                     // carry, and forms the bound there.
-                    (part == 0 ? cum_out : cum_part)[((size_t)band * g.max_chunks + slot) * g.n + bin] = __uint_as_float(sp ? 0xffffffffu : units[j]);
+                    (part == 0 ? cum_out : cum_part)[((size_t)band * g.max_chunks + slot) * g.n + bin] = __uint_as_float(sp ? 0xffffffffu : units[j] + n_run);
                 }
             }
         }

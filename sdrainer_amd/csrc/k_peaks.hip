@@ -60,6 +60,9 @@ __device__ __forceinline__ float spectrum_value(float psd, gomath::DbTables t, d
 #if !defined(SDR_REFINE_U)
 #define SDR_REFINE_U 16
 #endif
+#if !defined(SDR_REFINE_Q)
+#define SDR_REFINE_Q 4  // lanes a refined column's frames are dealt over (1: one lane per column, round 4's loop)
+#endif
 #if !defined(SDR_CUM_VGPR)
 #define SDR_CUM_VGPR 32
 #endif
@@ -342,6 +345,18 @@ __global__ __launch_bounds__(kRefineThreads) void k_cum_refine(float *__restrict
     const int n = g.n, T = blockDim.x;
     const int bin0 = span * kRefineSpan;
     const int span_bins = min(kRefineSpan, n - bin0), words = span_bins >> 6;  // (n is a multiple of 64)
+#if defined(SDR_REFINE_CLOCK)  // (tools only: tools/build_abl.sh refclk "-DSDR_REFINE_CLOCK")
+    unsigned long long ck[6] = {}, ck_last = __builtin_amdgcn_s_memtime();
+    int ck_n = 0;
+#define SDR_REFINE_TICK()                                             \
+    do {                                                              \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        ck[ck_n++] = now_ - ck_last;                                  \
+        ck_last = now_;                                               \
+    } while (0)
+#else
+#define SDR_REFINE_TICK()
+#endif
     {
         const uint4 *src = static_cast<const uint4 *>(db_tab);
         uint4 *dst = reinterpret_cast<uint4 *>(s_tab);
@@ -362,6 +377,7 @@ __global__ __launch_bounds__(kRefineThreads) void k_cum_refine(float *__restrict
             s_flags[w] = m;
     }
     __syncthreads();
+    SDR_REFINE_TICK();  // table copy, threshold, flags
     for (int w = tid; w < words; w += T) {
         const unsigned long long f = s_flags[w + 1];
         s_rflags[w] = f | (f << 1) | (f >> 1) | (s_flags[w] >> 63) | (s_flags[w + 2] << 63);
@@ -382,11 +398,13 @@ __global__ __launch_bounds__(kRefineThreads) void k_cum_refine(float *__restrict
         }
     }
     __syncthreads();
+    SDR_REFINE_TICK();  // the list
     const gomath::DbTables tab = gomath::db_tables(s_tab);
     int begin, len;
     cum_slot_frames(chunk, g.count0, &begin, &len);
     const float *__restrict__ carry_in = carry_sel ? carry1 : carry0;
     const float *__restrict__ base = psd + (size_t)band * g.stride * n;
+#if SDR_REFINE_Q == 1
     for (int k0 = 0; k0 < n_exact; k0 += T) {
         const int k = k0 + tid;
         const bool mine = k < n_exact;
@@ -403,6 +421,77 @@ __global__ __launch_bounds__(kRefineThreads) void k_cum_refine(float *__restrict
                 c[bin] = acc;  // the row holds the exact cumulation wherever FindPeaks reads it
         }
     }
+#else
+    // A column is a latency chain only in its SUM: the hundred loads and the hundred projections are independent.  Q
+    // neighbouring lanes take a quarter of a column's frames each - every load of the column in flight at once, one
+    // round trip to memory instead of seven - project their values side by side, and the ordered float32 sum walks
+    // through them lane after lane: carry + frame 0 + frame 1 + ..., the reference's order, one add at a time.
+    constexpr int Q = SDR_REFINE_Q, FR = (SDR_CUMULATION_SIZE + Q - 1) / Q;
+    static_assert(Q == 2 || Q == 4 || Q == 8, "lanes of a column share a wave");
+    const int n_lanes = n_exact * Q;
+    for (int k0 = 0; k0 < n_lanes; k0 += T) {
+        if (k0 + (tid & ~63) >= n_lanes)  // (wave-uniform)
+            break;
+        const int idx = k0 + tid, cand = idx / Q, q = idx % Q;
+        const bool mine = cand < n_exact;  // (lanes without a column repeat the last one and store nothing)
+        const int bin = bin0 + (int)s_list[mine ? cand : n_exact - 1];
+        const int f0 = q * FR, cnt = min(FR, len - f0);  // (may be <= 0 for the short first cumulation of a batch)
+        const unsigned off = (unsigned)(begin + f0) * (unsigned)n + (unsigned)bin;
+        float v[FR], db[FR];
+#pragma unroll
+        for (int k = 0; k < FR; k++)
+            v[k] = k < cnt ? __builtin_nontemporal_load(base + (off + (unsigned)k * (unsigned)n)) : 1.0f;
+        float acc = 0.f;
+        if (q == 0 && chunk == 0 && g.count0 > 0)
+            acc = carry_in[(size_t)band * n + bin];
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < FR; k++)
+            bad |= !gomath::psd_value_in_db_fast(v[k], tab, &db[k]);
+        if (__builtin_amdgcn_ballot_w64(bad)) {
+#pragma unroll 1
+            for (int k = 0; k < FR; k++) {
+                // (dynamic index into registers: select through a rotate of the arrays would cost more than this rare loop
+                // is worth - the values are re-read from memory instead)
+                if (k < cnt) {
+                    const float x = __builtin_nontemporal_load(base + (off + (unsigned)k * (unsigned)n));
+                    float t;
+                    if (!gomath::psd_value_in_db_fast(x, tab, &t)) {
+                        t = db_slow(x, inv_n2);
+#pragma unroll
+                        for (int j = 0; j < FR; j++)
+                            if (j == k)
+                                db[j] = t;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < FR; k++)
+            db[k] += (float)SDR_DBM_SHIFT;  // MagnitudeIndB + dBmShift (float32 add), off the chain
+#pragma unroll
+        for (int s = 0; s < Q; s++) {
+            if (q == s) {
+#pragma unroll
+                for (int k = 0; k < FR; k++)
+                    if (k < cnt)
+                        acc += db[k];  // the ordered sum
+            }
+            if (s + 1 < Q) {
+                const float up = __shfl_up(acc, 1);
+                if (q == s + 1)
+                    acc = up;
+            }
+        }
+        if (mine && q == Q - 1)
+            c[bin] = acc;  // the row holds the exact cumulation wherever FindPeaks reads it
+    }
+#endif
+    SDR_REFINE_TICK();  // the columns
+#if defined(SDR_REFINE_CLOCK)
+    if (chunk == 1 && span == 0 && band == 0 && (tid == 0 || tid == T - 64))
+        printf("refine clocks tid %d: flags %llu list %llu columns %llu candidates %d\n", tid, ck[0], ck[1], ck[2], n_exact);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -6,9 +6,9 @@ name=$1; extra=$2
 src=sdrainer_amd/csrc
 out=tools/abl/obj_$name
 mkdir -p $out
-F="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -DSDR_BUILD $extra"
-for f in k_fft_psd k_noise k_listen k_peaks k_unpack k_results capi_bank capi_process capi_results capi_graph capi_read sdr_audio; do
-  x=""; [ $f = k_fft_psd ] && x="-mllvm -disable-machine-licm"
+F="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -DSDR_BUILD -DSDR_SAFE_FENCES $extra"
+for f in $(python3 -c "from sdrainer_amd.csrc import build; print(' '.join(s[:-4] for s in build.SOURCES))"); do
+  x=""; case $f in k_fft_psd|k_fft_r32) x="-mllvm -disable-machine-licm -Wno-unused-lambda-capture";; esac
   hipcc $F $x -c $src/$f.hip -o $out/$f.o 2>&1 | grep -E "error" &
 done
 wait

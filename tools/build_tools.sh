@@ -5,7 +5,7 @@
 #   tools/build_tools.sh                      the standard set (production, clock, phases, the ablation matrix)
 #   tools/build_tools.sh name "flags" ...     named variants
 cd $(dirname $0)/..
-BASE="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -DSDR_BUILD -mllvm -disable-machine-licm -Iinclude"
+BASE="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -DSDR_BUILD -DSDR_SAFE_FENCES -mllvm -disable-machine-licm -Iinclude"
 HASH=$(python3 -c "from sdrainer_amd.csrc import build; print(build.source_hash())")
 mkdir -p tools/bin
 if [ $# -eq 0 ]; then

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from sdrainer_amd.csrc import build  # noqa: E402
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 key = "c3_f8192"  # bench.py's default batch for config 3
 G = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 P = os.path.join(ROOT, "profiles")
@@ -64,7 +64,7 @@ def traffic(fetch_dir, write_dir, alg):
         tab[k] = {"FETCH_SIZE_KB_raw": round(f[k], 1), "WRITE_SIZE_KB_raw": round(w.get(k, 0), 1),
                   "hbm_read_bytes_corrected": int(f[k] * 1024 * 2), "hbm_write_bytes": int(w.get(k, 0) * 1024),
                   "hbm_bytes_per_launch": int(f[k] * 1024 * 2 + w.get(k, 0) * 1024)}
-    fft = [k for k in tab if k.startswith("k_fft_psd")][0]
+    fft = [k for k in tab if "k_fft" in k][0]  # (k_fft_psd<..> or r32::k_fft_r32)
     step = sum(v["hbm_bytes_per_launch"] for v in tab.values())
     return {"k_fft_psd_hbm_bytes_per_launch": tab[fft]["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": alg,
             "whole_step_hbm_bytes": step, "whole_step_over_algorithmic": round(step / alg, 3),
@@ -91,7 +91,10 @@ copies = [("bench_full.json", f"{tag}_bench_{key}.json"), ("bench_serial.err", f
           ("fft_phases.txt", f"{tag}_fft_phase_order.txt"), ("tool_manifest.txt", f"{tag}_tool_manifest.txt"),
           ("host_input_rate.txt", f"{tag}_host_input_rate.txt"), ("strain_e2e.json", f"{tag}_strain_e2e.json"),
           ("mfma_f64.txt", f"{tag}_mfma_f64_probe.txt"), ("cu_time.txt", f"{tag}_cu_time_per_kernel.txt"),
-          ("noise_trace.txt", f"{tag}_noise_consumer_trace.txt"), ("decode_clocks.txt", f"{tag}_decode_stage_clocks.txt")]
+          ("noise_trace.txt", f"{tag}_noise_consumer_trace.txt"), ("decode_clocks.txt", f"{tag}_decode_stage_clocks.txt"),
+          ("ubench_f64.txt", f"{tag}_ubench_f64.txt"), ("r32_standalone.txt", f"{tag}_fft_r32_standalone.txt"),
+          ("r32_phases.txt", f"{tag}_fft_r32_phase_order.txt"), ("fences.txt", f"{tag}_fences_priced.txt"),
+          ("noise_paths.txt", f"{tag}_noise_scan_vs_chains.txt")]
 for src, dst in copies:
     s = os.path.join(G, src)
     if os.path.exists(s) and os.path.getsize(s) > 0:
@@ -108,7 +111,8 @@ def line(name):
 
 
 other = {}
-names = ["bench_steps20", "bench_f2048", "bench_f2048_steps20", "bench_insitu", "bench_nodelivery", "bench_c5", "bench_c2"] + \
+names = ["bench_steps20", "bench_steps20_b", "bench_steps20_c", "bench_f2048", "bench_f2048_steps20", "bench_f4096", "bench_insitu", "bench_nodelivery", "bench_c5",
+         "bench_c2", "bench_c3_r32off", "bench_c3_chains", "bench_c5_chains"] + \
         [f"bench_graph_c5_{i}" for i in range(1, 6)] + [f"bench_graph_c3_{i}" for i in range(1, 4)]
 for name in names:
     try:
