@@ -513,8 +513,11 @@ def main():
         consumer_stop.set()
         consumer.join(timeout=10)
     # (the stage is called k_fft_psd in the library's profile whichever kernel serves it: N = 16384 with at most 512 listener
-    # slots in use runs k_fft_r32 - 512 threads x 32 points, the next frame prefetched into registers - unless SDR_FFT_R32=0)
-    fft_kernel_name = "k_fft_r32" if (n == 16384 and tones <= 512 and os.environ.get("SDR_FFT_R32", "1") != "0") else "k_fft_psd"
+    # slots in use and at least 1024 frames per launch runs k_fft_r32 - 512 threads x 32 points, the next frame prefetched
+    # into registers - unless SDR_FFT_R32=0: k_fft_psd.hip launch_fft)
+    r32_env = os.environ.get("SDR_FFT_R32")
+    r32 = n == 16384 and tones <= 512 and (r32_env not in (None, "0") or (r32_env is None and frames * bands_per_gpu >= 1024))
+    fft_kernel_name = "k_fft_r32" if r32 else "k_fft_psd"
     fft_ms, fft_n = prof["k_fft_psd"]
     fft_avg_ms = fft_ms / max(fft_n, 1)
     fft_alone_ms = prof_alone["k_fft_psd"][0] / max(prof_alone["k_fft_psd"][1], 1)

@@ -1008,7 +1008,7 @@ static hipError_t launch_fft_t(const float *iq, const BatchCursor *cur, const ff
 
 // N = 16384 has two kernels: this file's 16-point one and k_fft_r32.hip (512 threads x 32 points, the next frame
 // prefetched into registers), whose workgroups take several frames each.  SDR_FFT_R32 = 0 / 1 forces one of them (tests);
-// by default the 32-point kernel runs whenever every CU can be given a workgroup of at least two frames.  The bank's
+// by default the 32-point kernel runs from 1024 frames per launch on (k_fft_r32.hip r32_fpw: measured by batch size).  The bank's
 // twiddle buffer holds both kernels' tables, the 32-point kernel's behind the other.
 static int r32_mode()
 {
@@ -1025,7 +1025,7 @@ hipError_t launch_fft(int logn, const float *iq, const BatchCursor *cur, const f
 {
     if (logn == 14) {
         const int mode = r32_mode();
-        if (tap.n <= fft32::T && (mode == 1 || (mode < 0 && (long)n_frames * n_bands >= 512)))
+        if (tap.n <= fft32::T && (mode == 1 || (mode < 0 && (long)n_frames * n_bands >= 1024)))
             return launch_fft_r32(iq, cur, tw + fft64::Plan<14>::TW_TOTAL, psd, n_frames, n_bands, in_stride, out_stride, tap, stream);
     }
     switch (logn) {

@@ -475,15 +475,23 @@ __global__ __launch_bounds__(fft32::T, 2) void k_fft_r32(const float *__restrict
 
 }  // namespace r32
 
-// frames per workgroup of the R32 kernel (SDR_FFT_R32_FPW overrides)
-static int r32_fpw()
+// Frames per workgroup of the R32 kernel (SDR_FFT_R32_FPW overrides).  A workgroup's first frame is not prefetched and
+// its twiddle block is loaded once, so more frames per workgroup are cheaper frames (standalone, 8192 frames: 0.517 ms at
+// four, 0.494 at eight, 0.481 at thirty-two) - but the tail stages hold CUs while a launch runs, and a launch that is two
+// or three rounds of workgroups over the CUs it gets ends on a round that is nearly empty: in the pipeline about a
+// thousand workgroups per launch is what measures best, four frames each at most (config 3, GS/s by frames per batch and
+// frames per workgroup: 8192 - 1: 170, 2: 189, 3: 190, 4: 195, 6: 189, 8: 187; 3072 - 3: 170, 4: 155; 2048 - 1: 154, 2: 173,
+// 3: 174, 4: 155; 1024 - 1: 141, 2: 163, the sixteen-point kernel 152; 512 - 1: 98, 2: 94, the sixteen-point kernel 104:
+// launch_fft sends batches of fewer than 1024 frames there).
+static int r32_fpw(long total_frames)
 {
-    static const int v = [] {
-        if (const char *e = getenv("SDR_FFT_R32_FPW"))
-            return std::max(1, std::min(atoi(e), 1024));
-        return 4;
+    static const int forced = [] {
+        const char *e = getenv("SDR_FFT_R32_FPW");
+        return e ? std::max(1, std::min(atoi(e), 1024)) : 0;
     }();
-    return v;
+    if (forced)
+        return forced;
+    return total_frames >= 4096 ? 4 : total_frames >= 2560 ? 3 : 2;
 }
 
 int r32_twiddle_count() { return fft32::kTwTotal; }
@@ -512,7 +520,7 @@ hipError_t launch_fft_r32(const float *iq, const BatchCursor *cur, const fft64::
     if (tap.n > fft32::T)
         return hipErrorInvalidValue;  // (launch_fft never asks: one listener slot per thread)
     // a workgroup's frames are consecutive; never fewer workgroups than the chip has CUs
-    int fpw = r32_fpw();
+    int fpw = r32_fpw((long)n_frames * n_bands);
     while (fpw > 1 && (long)((n_frames + fpw - 1) / fpw) * n_bands < 256)
         fpw /= 2;
     launch_kernel(r32::k_fft_r32, dim3((n_frames + fpw - 1) / fpw, n_bands), dim3(fft32::T), r32::kLdsBytes, stream, iq, cur, tw, psd,
