@@ -15,8 +15,9 @@
 //
 // Geometry.  A row is cut into SEGMENTS: the reference's windows (W values each) and pieces of the two edges (at most
 // 64 JMAX values).  A WAVE owns one segment of one run of consecutive frames (a cumulation slot, or a share of one): lane l
-// holds the bins begin + l + 64 j; per frame it adds its values into the frame's S1 / S2 (a lane's <= JMAX values in
-// sequence, then a six-step ladder across the lanes: noise_cert.h kScanTerms) and into its bins' running unit counts.
+// holds four neighbouring bins of every 256 (16-byte loads) and single bins of the segment's last < 256; per frame it adds its
+// values into the frame's S1 / S2 (a lane's <= JMAX + 4 values in sequence, then a six-step ladder across the lanes:
+// noise_cert.h kScanTerms) and into its bins' running unit counts.
 // A workgroup = the segments of one run: 14 waves at N = 16384.  Behind a barrier its threads then finish one frame each
 // (certify), and the workgroup as a whole walks the literal loops of the frames that were not accepted.
 #include <hip/hip_runtime.h>
@@ -43,6 +44,7 @@ constexpr int kExactChunk = 2048;                    // terms of the variance ch
 #endif
 
 using scan_rsrc_t = __amdgpu_buffer_rsrc_t;
+typedef unsigned scan_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ scan_rsrc_t scan_make_rsrc(const void *base, unsigned bytes)
 {
     // (inputs made provably wave-uniform, otherwise the descriptor is rebuilt per lane)
@@ -209,22 +211,37 @@ __global__ __launch_bounds__(64 * kScanMaxWaves) void k_psd_scan(const float *__
             len = min(g.piece, g.n - b0);
         }
         const bool bound = g.do_bound && complete;
-        unsigned units[JMAX], hw_max = 0u;
+        // A lane's bins.  The segment's first 256 q4 values go by 16-BYTE loads - lane l holds bins b0 + 256 q + 4 l .. + 3 -
+        // and the rest (fewer than 256) by dword loads, lane l bin b0 + 256 q4 + l + 64 r.  A CU's vector-memory pipe takes a
+        // wave's load every 16 clocks or so whatever its width: nineteen dword loads per frame and window kept the kernel at
+        // 27 GB/s per CU with the arithmetic units half idle.  All of them are BUFFER loads through descriptors that span
+        // exactly the bytes they may touch (the 16-byte loads whole groups of 256 values, the dword loads the remainder): a
+        // load beyond reads 0.0 without a compare, an exec mask or a branch, and the address is a scalar base plus one
+        // per-lane offset.  (As global loads under per-lane predicates the loop was 38 instructions per value, five of them
+        // the arithmetic.)  What such a value adds is harmless: nothing to S1 / S2, something to a unit count never stored.
+        constexpr int Q4MAX = JMAX / 4, R1MAX = JMAX < 4 ? JMAX : 4, Q4A = Q4MAX ? Q4MAX : 1;
+        const int q4 = len >> 8, rem = len - (q4 << 8);  // (wave-uniform; q4 <= Q4MAX as len <= 64 JMAX)
+        unsigned u4[Q4A][4], u1[R1MAX], hw_max = 0u;
 #pragma unroll
-        for (int j = 0; j < JMAX; j++)
-            units[j] = 0u;
-        // lane's bins: b0 + lane + 64 j, j < JMAX, valid while < b0 + len.  The loads are BUFFER loads through a descriptor
-        // that spans exactly the segment's bytes of one row: a bin beyond the segment reads as 0.0 without a compare, an exec
-        // mask or a branch, and the address is a scalar base plus one per-lane offset.  (As global loads under per-lane
-        // predicates the loop was 38 instructions per value, five of them the arithmetic.)  What such a bin adds is harmless:
-        // nothing to S1 / S2, something to a unit count that is never stored.
-        const unsigned lane4 = (unsigned)lane * 4u;
-        unsigned v[SDR_SCAN_AHEAD + 1][JMAX];
+        for (int q = 0; q < Q4A; q++)
+#pragma unroll
+            for (int c4 = 0; c4 < 4; c4++)
+                u4[q][c4] = 0u;
+#pragma unroll
+        for (int r = 0; r < R1MAX; r++)
+            u1[r] = 0u;
+        const unsigned lane4 = (unsigned)lane * 4u, lane16 = (unsigned)lane * 16u;
+        scan_u32x4 v4[SDR_SCAN_AHEAD + 1][Q4A];
+        unsigned v1[SDR_SCAN_AHEAD + 1][R1MAX];
         auto fetch = [&](int f, int k) {
-            const scan_rsrc_t row = scan_make_rsrc(rows + (size_t)(f - f_begin) * g.n + b0, (unsigned)len * 4u);
+            const float *seg = rows + (size_t)(f - f_begin) * g.n + b0;
+            const scan_rsrc_t wide = scan_make_rsrc(seg, (unsigned)q4 * 1024u), narrow = scan_make_rsrc(seg + (q4 << 8), (unsigned)rem * 4u);
 #pragma unroll
-            for (int j = 0; j < JMAX; j++)
-                v[k][j] = __builtin_amdgcn_raw_buffer_load_b32(row, lane4 + 256u * (unsigned)j, 0, SDR_SCAN_AUX);
+            for (int q = 0; q < Q4MAX; q++)
+                v4[k][q] = __builtin_amdgcn_raw_buffer_load_b128(wide, lane16 + 1024u * (unsigned)q, 0, SDR_SCAN_AUX);
+#pragma unroll
+            for (int r = 0; r < R1MAX; r++)
+                v1[k][r] = __builtin_amdgcn_raw_buffer_load_b32(narrow, lane4 + 256u * (unsigned)r, 0, SDR_SCAN_AUX);
         };
         // (the frame loop is unrolled over the ring of SDR_SCAN_AHEAD + 1 register sets)
         constexpr int RING = SDR_SCAN_AHEAD + 1;
@@ -242,12 +259,21 @@ __global__ __launch_bounds__(64 * kScanMaxWaves) void k_psd_scan(const float *__
                     fetch(f + SDR_SCAN_AHEAD, (k + SDR_SCAN_AHEAD) % RING);
                 if (w >= 0) {  // (wave-uniform)
                     double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-                    for (int j = 0; j < JMAX; j++) {
-                        const double xd = (double)__uint_as_float(v[k][j]);
+                    auto add = [&](unsigned bits) {
+                        const double xd = (double)__uint_as_float(bits);
                         s1 += xd;
                         s2 = __builtin_fma(xd, xd, s2);  // (a float32 squared has 48 bits: the product is exact either way)
+                    };
+#pragma unroll
+                    for (int q = 0; q < Q4MAX; q++) {
+                        add(v4[k][q].x);
+                        add(v4[k][q].y);
+                        add(v4[k][q].z);
+                        add(v4[k][q].w);
                     }
+#pragma unroll
+                    for (int r = 0; r < R1MAX; r++)
+                        add(v1[k][r]);
                     s1 = wave_sum_to_lane63(s1);
                     s2 = wave_sum_to_lane63(s2);
                     if (lane == 63) {
@@ -256,12 +282,21 @@ __global__ __launch_bounds__(64 * kScanMaxWaves) void k_psd_scan(const float *__
                     }
                 }
                 if (bound) {  // (wave-uniform)
-#pragma unroll
-                    for (int j = 0; j < JMAX; j++) {
-                        const unsigned hw = v[k][j] >> 16;  // gomath::cum_bound_units without its + 1 (added below, per frame)
-                        units[j] += hw < 128u ? 128u : hw;
+                    auto count = [&](unsigned bits, unsigned &units) {
+                        const unsigned hw = bits >> 16;  // gomath::cum_bound_units without its + 1 (added below, per frame)
+                        units += hw < 128u ? 128u : hw;
                         hw_max = hw > hw_max ? hw : hw_max;  // gomath::cum_bound_special: hw >= 0x7f80 - infinity, NaN or a sign bit
+                    };
+#pragma unroll
+                    for (int q = 0; q < Q4MAX; q++) {
+                        count(v4[k][q].x, u4[q][0]);
+                        count(v4[k][q].y, u4[q][1]);
+                        count(v4[k][q].z, u4[q][2]);
+                        count(v4[k][q].w, u4[q][3]);
                     }
+#pragma unroll
+                    for (int r = 0; r < R1MAX; r++)
+                        count(v1[k][r], u1[r]);
                 }
             }
         }
@@ -271,17 +306,23 @@ __global__ __launch_bounds__(64 * kScanMaxWaves) void k_psd_scan(const float *__
             // psd row that holds an infinity or a NaN is not a case to be fast in)
             const bool sp = hw_max >= 0x7f80u;
             const unsigned n_run = (unsigned)(f_end - f_begin);  // units(psd) = max(hw, 128) + 1: the + 1 of every frame
+            // The raw unit count goes out (all ones: a special value in the column), part 0's into the slot's row, part 1's
+            // into the second buffer: k_bound_finish (k_peaks.hip) adds the parts and - slot 0 continues the cumulation
+            // carried in from the previous batch, and that carry is produced on the peaks stream - the carry, and forms
+            // the bound there.
+            float *__restrict__ out = (part == 0 ? cum_out : cum_part) + ((size_t)band * g.max_chunks + slot) * g.n + b0;
 #pragma unroll
-            for (int j = 0; j < JMAX; j++) {
-                if (lane + 64 * j < len) {
-                    const int bin = b0 + lane + 64 * j;
-                    // The raw unit count goes out (all ones: a special value in the column), part 0's into the slot's row,
-                    // part 1's into the second buffer: k_bound_finish (k_peaks.hip) adds the parts and - slot 0 continues the
-                    // cumulation carried in from the previous batch, and that carry is produced on the peaks stream - the
-                    // carry, and forms the bound there.
-                    (part == 0 ? cum_out : cum_part)[((size_t)band * g.max_chunks + slot) * g.n + bin] = __uint_as_float(sp ? 0xffffffffu : units[j] + n_run);
+            for (int q = 0; q < Q4MAX; q++) {
+                if (q < q4) {
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; c4++)
+                        out[256 * q + 4 * lane + c4] = __uint_as_float(sp ? 0xffffffffu : u4[q][c4] + n_run);
                 }
             }
+#pragma unroll
+            for (int r = 0; r < R1MAX; r++)
+                if (lane + 64 * r < rem)
+                    out[(q4 << 8) + lane + 64 * r] = __uint_as_float(sp ? 0xffffffffu : u1[r] + n_run);
         }
     }
     __syncthreads();
@@ -364,7 +405,13 @@ hipError_t launch_noise_exact_check(const float *psd_band, sdr_frame_rec *recs_b
 }
 
 // parts a slot's frames are dealt over (k_peaks.hip's k_bound_finish must add as many)
-int scan_parts(int n_slots, int n_bands) { return (long)n_slots * n_bands < 160 ? 2 : 1; }
+int scan_parts(int n_slots, int n_bands)
+{
+    static const int forced = getenv("SDR_SCAN_PARTS") ? atoi(getenv("SDR_SCAN_PARTS")) : 0;  // (experiments: 1 or 2)
+    if (forced == 1 || forced == 2)
+        return forced;
+    return (long)n_slots * n_bands < 160 ? 2 : 1;
+}
 
 static int scan_jmax(int window)
 {

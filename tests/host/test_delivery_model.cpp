@@ -239,12 +239,12 @@ struct Tally {
         }
         order.push_back(o.batch);
     }
-    bool complete(int64_t n, const char *what)
+    bool complete(int64_t n, const char *what, int64_t first = 0)
     {
         std::lock_guard<std::mutex> g(mu);
         bool ok = !bad && (int64_t)order.size() == n;
         for (int64_t i = 0; ok && i < n; i++)
-            ok = order[(size_t)i] == i;
+            ok = order[(size_t)i] == first + i;
         if (!ok)
             fprintf(stderr, "%s: delivered %zu of %lld batches, in order: %s\n", what, order.size(), (long long)n, ok ? "yes" : "NO");
         return ok;
@@ -356,6 +356,41 @@ bool graph_mode()
     return ok;
 }
 
+// sdr_enable_results on a bank that already delivers (round 4's advice): what was not delivered is discarded - the
+// parked entries AND the batches still sitting in their sets - and delivery starts again at the next batch.  With the
+// stale entries kept, a real batch parked behind them was never found and poll failed for good.
+bool re_enable()
+{
+    Rig r(15);
+    Tally t;
+    for (int i = 0; i < 3 * RING + 2; i++)
+        r.process();  // nobody polls: the oldest are parked, the youngest six sit in their sets
+    bool ok = r.d.parked_count() > 0;
+    // sync_bank: the pipeline is drained before the mode is set
+    for (int i = 0; i < RING; i++) {
+        host::ResultSet &rs = r.d.set(i);
+        while (r.be.query(rs.ev_listen) != SDR_OK || r.be.query(rs.ev_peaks) != SDR_OK)
+            std::this_thread::yield();
+    }
+    const int64_t first = r.batch_index;
+    r.d.reset(true, first);
+    ok = ok && r.d.parked_count() == 0 && r.d.pending() == 0;
+    if (!ok)
+        fprintf(stderr, "re_enable: %zu parked, %d pending after the reset\n", r.d.parked_count(), r.d.pending());
+    // the consumer lags past the ring: batches are parked again, behind nothing stale
+    const int64_t n = 4 * RING + 3;
+    for (int64_t i = 0; i < n; i++)
+        r.process();
+    Out o;
+    if (r.d.poll(&o, false) != SDR_OK || o.batch != first) {
+        fprintf(stderr, "re_enable: the first poll after the reset gave batch %lld, not %lld\n", (long long)o.batch, (long long)first);
+        return false;
+    }
+    t.take(o);
+    consume(r, t, n, true, 21, 0);
+    return ok && t.complete(n, "re_enable", first) && r.d.pending() == 0;
+}
+
 }  // namespace
 
 int main()
@@ -363,7 +398,7 @@ int main()
     struct {
         const char *name;
         bool (*fn)();
-    } tests[] = {{"erratic", erratic}, {"nosync", nosync}, {"blocking", [] { return blocking(1); }}, {"two", [] { return blocking(2); }}, {"graph", graph_mode}};
+    } tests[] = {{"erratic", erratic}, {"nosync", nosync}, {"blocking", [] { return blocking(1); }}, {"two", [] { return blocking(2); }}, {"graph", graph_mode}, {"re_enable", re_enable}};
     int failed = 0;
     for (auto &tc : tests) {
         const bool ok = tc.fn();

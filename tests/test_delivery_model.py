@@ -22,4 +22,4 @@ def test_delivery_model(tmp_path, sanitizer):
     for _ in range(3):  # (the interleavings differ from run to run)
         run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
         assert run.returncode == 0 and "ThreadSanitizer" not in run.stderr and "FAILED" not in run.stdout, run.stdout + run.stderr
-    assert run.stdout.split() == ["erratic", "ok", "nosync", "ok", "blocking", "ok", "two", "ok", "graph", "ok"]
+    assert run.stdout.split() == ["erratic", "ok", "nosync", "ok", "blocking", "ok", "two", "ok", "graph", "ok", "re_enable", "ok"]
