@@ -91,7 +91,7 @@ __device__ __forceinline__ void wave_sync()
 // Development aid (tools/fft_r32_bench.hip only): -DSDR_R32_PHASES=<workgroup> makes every wave of that workgroup read the
 // shader clock at each phase boundary of its SECOND frame (steady state: the frame's input was prefetched) into SGPRs and
 // store the stamps at its last instruction.
-enum R32Stamp { RS_TOP = 0, RS_LANDED, RS_WIDENED, RS_PASS0, RS_E0, RS_PASS1, RS_E1, RS_PASS2, RS_ROW, RS_STORED, RS_COUNT };
+enum R32Stamp { RS_TOP = 0, RS_LANDED, RS_CVT, RS_FLUSHED, RS_WIDENED, RS_PASS0, RS_E0, RS_PASS1, RS_E1, RS_PASS2, RS_ROW, RS_STORED, RS_COUNT };
 #if defined(SDR_R32_PHASES)
 // (the stamps live in the lanes of ONE vector register: the kernel has neither SGPRs nor VGPRs to spare.  Every wave of
 // every workgroup takes them, unconditionally: a branch around each stamp cut the unrolled frame into a dozen basic blocks
@@ -338,7 +338,16 @@ __global__ __launch_bounds__(fft32::T, 2) void k_fft_r32(const float *__restrict
             fetch(frame + 1, t, pf_begin(point), pf_begin(point + 1));
             __builtin_amdgcn_sched_barrier(0);
         };
+#if defined(SDR_R32_PHASES)  // (the first point taken apart for its stamps)
+        SDR_R32_STAMP(st, RS_CVT);
+        __builtin_amdgcn_sched_barrier(0);
+        flush_row(frame - 1, t, st_begin(PF_WIDENED), st_begin(PF_WIDENED + 1));
+        SDR_R32_STAMP(st, RS_FLUSHED);
+        fetch(frame + 1, t, pf_begin(PF_WIDENED), pf_begin(PF_WIDENED + 1));
+        __builtin_amdgcn_sched_barrier(0);
+#else
         pf_point(PF_WIDENED);
+#endif
         SDR_R32_STAMP(st, RS_WIDENED);
 
         // pass 0; behind its stage 3 everybody must be out of the previous frame's psd row (it shares the area with E0):

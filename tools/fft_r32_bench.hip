@@ -195,7 +195,7 @@ int main(int argc, char **argv)
         for (int w = 0; w < 8; w++)
             if (ph[w][0])
                 t0 = std::min(t0, ph[w][0]);
-        const char *names[] = {"top", "landed", "widened", "pass0", "E0", "pass1", "E1", "pass2", "row", "stored"};
+        const char *names[] = {"top", "landed", "cvt", "flushed", "widened", "pass0", "E0", "pass1", "E1", "pass2", "row", "stored"};
         printf("phase timeline of workgroup %d's second frame, shader-clock cycles since its first wave reached the frame's top (stamp = the phase named has just ended)\nwave",
                (int)SDR_R32_PHASES);
         for (int k = 0; k < sdr::r32::RS_COUNT; k++)

@@ -52,7 +52,8 @@ def pmc(directory, name):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(find(f"{directory}/**/{name}_counter_collection.csv"))):
         k = r["Kernel_Name"]
-        if "sdr::" in k:
+        # (k_noise_exact_check belongs to the record read behind the run - sdr_read_frame_records - not to a step)
+        if "sdr::" in k and "k_noise_exact_check" not in k and "k_mfma_order_probe" not in k:
             agg[k.split("(")[0].replace("void ", "").replace("sdr::", "")].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
@@ -92,7 +93,7 @@ copies = [("bench_full.json", f"{tag}_bench_{key}.json"), ("bench_serial.err", f
           ("host_input_rate.txt", f"{tag}_host_input_rate.txt"), ("strain_e2e.json", f"{tag}_strain_e2e.json"),
           ("mfma_f64.txt", f"{tag}_mfma_f64_probe.txt"), ("cu_time.txt", f"{tag}_cu_time_per_kernel.txt"),
           ("noise_trace.txt", f"{tag}_noise_consumer_trace.txt"), ("decode_clocks.txt", f"{tag}_decode_stage_clocks.txt"),
-          ("ubench_f64.txt", f"{tag}_ubench_f64.txt"), ("r32_standalone.txt", f"{tag}_fft_r32_standalone.txt"),
+          ("ubench_f64.txt", f"{tag}_ubench_f64.txt"), ("ubench_cvt.txt", f"{tag}_ubench_cvt.txt"), ("r32_standalone.txt", f"{tag}_fft_r32_standalone.txt"),
           ("r32_phases.txt", f"{tag}_fft_r32_phase_order.txt"), ("fences.txt", f"{tag}_fences_priced.txt"),
           ("noise_paths.txt", f"{tag}_noise_scan_vs_chains.txt")]
 for src, dst in copies:
@@ -112,7 +113,7 @@ def line(name):
 
 other = {}
 names = ["bench_steps20", "bench_steps20_b", "bench_steps20_c", "bench_f2048", "bench_f2048_steps20", "bench_f4096", "bench_insitu", "bench_nodelivery", "bench_c5",
-         "bench_c2", "bench_c3_r32off", "bench_c3_chains", "bench_c5_chains"] + \
+         "bench_c2", "bench_c2_f8192", "bench_c3_r32off", "bench_c3_chains", "bench_c5_chains"] + \
         [f"bench_graph_c5_{i}" for i in range(1, 6)] + [f"bench_graph_c3_{i}" for i in range(1, 4)]
 for name in names:
     try:

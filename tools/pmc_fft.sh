@@ -25,7 +25,7 @@ import csv, collections, glob
 for f in sorted(glob.glob("gpurun_out/pmc_fft/**/g*_counter_collection.csv", recursive=True)):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "k_fft_psd" in r["Kernel_Name"]:
+        if "k_fft" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         print(f"{k:32s} {sum(v)/len(v):16.0f}  (n={len(v)})")

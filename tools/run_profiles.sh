@@ -40,6 +40,7 @@ timeout -k 5 90 tools/bin/r32_phases 8192 1 > $O/r32_phases.txt 2>&1 || true
   echo "== k_fft_psd<12>: 32768 frames of N = 4096 (134 M samples)"; SDR_FFT_FPW=1 timeout -k 5 90 tools/bin/fb_prod 32768 12 1
 } > $O/fft_standalone_f8192.txt 2>&1
 [ -x tools/ubench_f64 ] && timeout -k 5 120 tools/ubench_f64 > $O/ubench_f64.txt 2>&1 || true
+[ -x tools/ubench_cvt ] && timeout -k 5 120 tools/ubench_cvt > $O/ubench_cvt.txt 2>&1 || true
 echo "fft standalone done"
 
 # 2. SQ / TCP counters of the standalone launch (one pass per group)
@@ -71,6 +72,7 @@ python bench.py --steps 100 --warmup 10 --kernel-breakdown --no-cpu-baseline --s
 python bench.py --steps 400 --warmup 40 --kernel-breakdown --no-cpu-baseline > $O/bench_insitu.json 2> $O/bench_insitu.err
 python bench.py --workload c5 --steps 600 --warmup 60 --no-cpu-baseline > $O/bench_c5.json 2>/dev/null
 python bench.py --workload c2 --frames 4096 --steps 600 --warmup 60 --no-cpu-baseline > $O/bench_c2.json 2>/dev/null
+python bench.py --workload c2 --frames 8192 --steps 600 --warmup 60 --no-cpu-baseline > $O/bench_c2_f8192.json 2>/dev/null
 python bench.py --steps 500 --warmup 50 --no-cpu-baseline --no-delivery > $O/bench_nodelivery.json 2>/dev/null
 # this round's two changes, each switched off: the 16-point FFT kernel, FindNoiseFloor's ordered chains
 SDR_FFT_R32=0 python bench.py --steps 1000 --warmup 100 --no-cpu-baseline > $O/bench_c3_r32off.json 2>/dev/null
