@@ -92,6 +92,8 @@ enum Stage { S_FFT = 0, S_NOISE, S_LISTEN, S_PEAKS, N_STAGES };  // the bank's s
 struct BatchSet {
     DevBuf<float> psd;                // [band][max_batch][N] float32(re^2 + im^2), fft-shifted
     DevBuf<float> tap;                // [band][max_batch][L] psd of each listener slot's bin
+    DevBuf<float> tapw;               // [band][max_batch][L][4] psd at bin - 1, bin, bin + 1, 0 (k_fft_r32's wide tap; N = 16384 only)
+    DevBuf<int32_t> tap_used;         // [band][L] the bins tapw was taken at (-1 = none)
     DevBuf<double> win_mean;          // [band][max_batch][10] (the chain kernels of SDR_NOISE_PATH=chains only)
     DevBuf<sdr_frame_rec> recs;       // [band][max_batch]
     DevBuf<uint64_t> raw_bits, bits;  // [band][L][bit_words] before / after the debouncer
@@ -111,6 +113,8 @@ struct BatchSet {
     {
         psd.release();
         tap.release();
+        tapw.release();
+        tap_used.release();
         win_mean.release();
         cum_part.release();
         recs.release();

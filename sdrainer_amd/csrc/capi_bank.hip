@@ -75,6 +75,10 @@ hipError_t alloc_set(sdr_bank *b, BatchSet &S)
     } while (0)
     SET_ALLOC(S.psd, B * F * N);
     SET_ALLOC(S.tap, B * F * std::max<size_t>(L, 1));
+    if (b->logn == 14) {  // (the kernel that writes them serves this block size only)
+        SET_ALLOC(S.tapw, B * F * 4 * std::max<size_t>(L, 1));
+        SET_ALLOC(S.tap_used, B * std::max<size_t>(L, 1));
+    }
     SET_ALLOC(S.win_mean, B * F * 10);
     SET_ALLOC(S.recs, B * F);
     SET_ALLOC(S.raw_bits, B * L * (size_t)b->bit_words);

@@ -266,7 +266,9 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
     {
         ProfScope ps(b, sdr::K_FFT, stream_of(sdr::K_FFT));
         SDR_ARM(sdr::K_FFT);
-        const sdr::FftTap tap{b->tap_bins.p, S.tap.p, max_slots, c.max_listeners};
+        sdr::FftTap tap{b->tap_bins.p, S.tap.p, max_slots, c.max_listeners};
+        tap.wide = S.tapw.p;
+        tap.used = S.tap_used.p;
         SDR_LAUNCH(sdr::K_FFT, sdr::launch_fft(b->logn, iq_dev, cur, b->tw.p, S.psd.p, n_frames, B, in_stride, stride, tap,
                                                stream_of(sdr::K_FFT)));
     }
@@ -410,8 +412,14 @@ int process_device_body(sdr_bank *b, const float *iq_dev, int n_frames, int in_s
         sdr::PeakGeom pg{N, stride, count0, b->max_chunks, c.max_peaks};
         // (reads the carry buffer this batch's cumulation started from: the next batch's k_cumulate, which writes that
         // buffer, follows on the same stream)
+        // the wide tap this batch's FFT left, if it was the kernel that leaves one (k_cum_refine reads the signals' columns there)
+        sdr::FftTap wide_tap{nullptr, nullptr, max_slots, c.max_listeners};
+        if (S.tapw.p && sdr::fft_writes_wide_tap(b->logn, n_frames, B, max_slots)) {
+            wide_tap.wide = S.tapw.p;
+            wide_tap.used = S.tap_used.p;
+        }
         SDR_LAUNCH(sdr::K_FIND_PEAKS, sdr::launch_find_peaks(S.cum_out.p, S.psd.p, b->db_tab.p, b->carry[0].p, b->carry[1].p, b->carry_cur, S.recs.p,
-                                                             S.dev_peaks.p, S.peak_counts.p, cur, pg, n_frames, n_chunks, B,
+                                                             S.dev_peaks.p, S.peak_counts.p, cur, pg, n_frames, n_chunks, B, wide_tap,
                                                              stream_of(sdr::K_FIND_PEAKS)));
     }
     if (b->results_on && SDR_ON(sdr::K_FIND_PEAKS)) {

@@ -1020,12 +1020,18 @@ static int r32_mode()
     return v;
 }
 
+static bool use_r32(int logn, int n_frames, int n_bands, int tap_n)
+{
+    const int mode = r32_mode();
+    return logn == 14 && tap_n <= fft32::T && (mode == 1 || (mode < 0 && (long)n_frames * n_bands >= 1024));
+}
+bool fft_writes_wide_tap(int logn, int n_frames, int n_bands, int tap_n) { return tap_n > 0 && use_r32(logn, n_frames, n_bands, tap_n); }
+
 hipError_t launch_fft(int logn, const float *iq, const BatchCursor *cur, const fft64::cplx *tw, float *psd, int n_frames,
                       int n_bands, int in_stride, int out_stride, FftTap tap, hipStream_t stream)
 {
     if (logn == 14) {
-        const int mode = r32_mode();
-        if (tap.n <= fft32::T && (mode == 1 || (mode < 0 && (long)n_frames * n_bands >= 1024)))
+        if (use_r32(logn, n_frames, n_bands, tap.n))
             return launch_fft_r32(iq, cur, tw + fft64::Plan<14>::TW_TOTAL, psd, n_frames, n_bands, in_stride, out_stride, tap, stream);
     }
     switch (logn) {

@@ -222,7 +222,8 @@ __device__ __forceinline__ void ex_read(double (&x)[32], int t, const double *ar
 __global__ __launch_bounds__(fft32::T, 2) void k_fft_r32(const float *__restrict__ iq_arg, const BatchCursor *__restrict__ cur,
                                                           const cplx *__restrict__ tw, float *__restrict__ psd, int in_stride,
                                                           int out_stride, int n_frames, int fpw, const int *__restrict__ tap_bins,
-                                                          float *__restrict__ tap_out, int n_tap, int tap_stride)
+                                                          float *__restrict__ tap_out, int n_tap, int tap_stride,
+                                                          float *__restrict__ tap_wide, int *__restrict__ tap_used)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     using namespace fft32;
@@ -259,6 +260,12 @@ __global__ __launch_bounds__(fft32::T, 2) void k_fft_r32(const float *__restrict
     // banks run the 16-point kernel)
     const bool reg_tap = n_tap > 0 && n_tap <= T;
     const int my_bin = (reg_tap && tid < n_tap) ? tap_bins[(size_t)blockIdx.y * tap_stride + tid] : -1;
+    // The WIDE tap (k_peaks.hip k_cum_refine): psd at bin - 1, bin, bin + 1 of every listener, [frame][slot][4] - the exact
+    // cumulation is wanted at the signals' bins and their neighbours, and read there it is four contiguous kilobytes per
+    // frame instead of a hundred scattered 64-byte sectors per candidate.  Which bins these rows hold is recorded with them
+    // (the bank's tap bins may have changed by the time the refinement of this batch runs).
+    if (tap_used && blockIdx.x == 0 && tid < tap_stride)
+        tap_used[(size_t)blockIdx.y * tap_stride + tid] = my_bin;
     unsigned *soft = reinterpret_cast<unsigned *>(smem + kExchangeBytes + kTw1LdsBytes);  // arrival counters, see soft_wait
     if (tid < kSoftCounters)
         soft[tid] = 0;
@@ -470,6 +477,20 @@ __global__ __launch_bounds__(fft32::T, 2) void k_fft_r32(const float *__restrict
             // (a free slot, bin -1, reads word 0 and stores 0)
             const float tv = row[row_word(my_bin & (N - 1))];
             tapv = my_bin >= 0 ? tv : 0.0f;
+            // the wide tap: (left neighbour, the bin, right neighbour, 0) as ONE 16-byte store per slot, by the waves that
+            // hold slots, at once - the memory pipeline is idle here (the prefetch plan leaves this point empty), and what a
+            // store costs the frame is its issue: as three dword stores by every wave this was 2.4 % of the kernel.  Lanes
+            // without a slot aim past the descriptor (no per-lane branch).  A neighbour that does not exist (bin 0's left,
+            // bin N - 1's right) wraps to a word nobody reads.
+            if (__builtin_amdgcn_readfirstlane(t) < n_tap && tap_wide) {  // (wave-uniform)
+                const rsrc_t wr = make_rsrc(tap_wide + (out_band + frame) * (size_t)(4 * tap_stride), reg_tap ? (unsigned)tap_stride * 16u : 0u);
+                u32x4 wv;
+                wv.x = __float_as_uint(row[row_word((my_bin - 1) & (N - 1))]);
+                wv.y = __float_as_uint(tv);
+                wv.z = __float_as_uint(row[row_word((my_bin + 1) & (N - 1))]);
+                wv.w = 0u;
+                __builtin_amdgcn_raw_buffer_store_b128(wv, wr, t < n_tap ? (unsigned)t * 16u : 0x7ffffff0u, 0, 0);
+            }
         }
         soft_arrive(soft + SOFT_ROW);  // this wave is out of the row
         SDR_R32_STAMP(st, RS_STORED);
@@ -533,7 +554,7 @@ hipError_t launch_fft_r32(const float *iq, const BatchCursor *cur, const fft64::
     while (fpw > 1 && (long)((n_frames + fpw - 1) / fpw) * n_bands < 256)
         fpw /= 2;
     launch_kernel(r32::k_fft_r32, dim3((n_frames + fpw - 1) / fpw, n_bands), dim3(fft32::T), r32::kLdsBytes, stream, iq, cur, tw, psd,
-                  in_stride, out_stride, n_frames, fpw, tap.bins, tap.out, tap.n, tap.stride);
+                  in_stride, out_stride, n_frames, fpw, tap.bins, tap.out, tap.n, tap.stride, tap.wide, tap.used);
     return hipGetLastError();
 }
 

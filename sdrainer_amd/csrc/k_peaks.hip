@@ -326,7 +326,8 @@ template <int kRefineSpan, int kRefineThreads>
 __global__ __launch_bounds__(kRefineThreads) void k_cum_refine(float *__restrict__ cum, const float *__restrict__ psd, const void *__restrict__ db_tab,
                                                                const float *__restrict__ carry0, const float *__restrict__ carry1, int carry_in_arg,
                                                                const sdr_frame_rec *__restrict__ recs, const BatchCursor *__restrict__ cur, PeakGeom g,
-                                                               int n_frames, double inv_n2)
+                                                               int n_frames, double inv_n2, const float *__restrict__ tap_wide,
+                                                               const int32_t *__restrict__ tap_used, int n_tap, int tap_stride)
 {
     constexpr int SW = kRefineSpan / 64;  // words per span
     __shared__ __attribute__((aligned(16))) unsigned char s_tab[gomath::kDbTabBytes];
@@ -334,6 +335,7 @@ __global__ __launch_bounds__(kRefineThreads) void k_cum_refine(float *__restrict
     __shared__ unsigned long long s_rflags[SW];
     __shared__ int s_offs[SW + 1];
     __shared__ unsigned short s_list[kRefineSpan];
+    __shared__ unsigned short s_tapidx[kRefineSpan];  // bin -> 3 slot + (0, 1, 2: left neighbour, the bin, right neighbour) of the wide tap, or none
     const int chunk = blockIdx.x, span = blockIdx.y, band = blockIdx.z, tid = threadIdx.x, lane = threadIdx.x & 63;
     int carry_sel = carry_in_arg;
     if (cur) {
@@ -362,6 +364,26 @@ __global__ __launch_bounds__(kRefineThreads) void k_cum_refine(float *__restrict
         uint4 *dst = reinterpret_cast<uint4 *>(s_tab);
         for (int i = tid; i < gomath::kDbTabBytes / 16; i += T)
             dst[i] = src[i];
+    }
+    // The wide tap (k_fft_r32.hip): the FFT kernel left psd at bin - 1, bin, bin + 1 of every listener's bin, frame by frame,
+    // in rows of four kilobytes (16 bytes per listener) - and the bins FindPeaks looks at are the signals' and their neighbours.  A candidate found
+    // in this map reads its column there (contiguous, on chip after the first touch) instead of a hundred 64-byte sectors
+    // of the psd array for a hundred 4-byte values; any other candidate (a signal nobody listens to yet) reads the psd.
+    for (int i = tid; i < kRefineSpan; i += T)
+        s_tapidx[i] = 0xffffu;
+    __syncthreads();
+    if (tap_wide) {
+        for (int l = tid; l < n_tap; l += T) {
+            const int b = tap_used[(size_t)band * tap_stride + l];
+            if (b >= 0) {
+#pragma unroll
+                for (int c3 = 0; c3 < 3; c3++) {
+                    const int nb = b + c3 - 1;
+                    if (nb >= 0 && nb < n && nb >= bin0 && nb < bin0 + span_bins)
+                        s_tapidx[nb - bin0] = (unsigned short)(3 * l + c3);  // (two listeners side by side: either source holds the same word)
+                }
+            }
+        }
     }
     const int first_len = SDR_CUMULATION_SIZE - g.count0;
     const int end_frame = first_len + chunk * SDR_CUMULATION_SIZE - 1;  // frame that completes this chunk
@@ -436,11 +458,17 @@ __global__ __launch_bounds__(kRefineThreads) void k_cum_refine(float *__restrict
         const bool mine = cand < n_exact;  // (lanes without a column repeat the last one and store nothing)
         const int bin = bin0 + (int)s_list[mine ? cand : n_exact - 1];
         const int f0 = q * FR, cnt = min(FR, len - f0);  // (may be <= 0 for the short first cumulation of a batch)
-        const unsigned off = (unsigned)(begin + f0) * (unsigned)n + (unsigned)bin;
+        // the column: frame stride and first element, in the wide tap if the bin is there, else in the psd array
+        const unsigned ti = s_tapidx[bin - bin0];
+        const bool tapped = ti != 0xffffu;
+        const unsigned step = tapped ? 4u * (unsigned)tap_stride : (unsigned)n;
+        const float *__restrict__ col = tapped ? tap_wide + ((size_t)band * g.stride + (size_t)(begin + f0)) * (4u * (unsigned)tap_stride) +
+                                                     (size_t)(ti / 3u) * 4u + ti % 3u
+                                               : base + ((size_t)(begin + f0) * (unsigned)n + (unsigned)bin);
         float v[FR], db[FR];
 #pragma unroll
         for (int k = 0; k < FR; k++)
-            v[k] = k < cnt ? __builtin_nontemporal_load(base + (off + (unsigned)k * (unsigned)n)) : 1.0f;
+            v[k] = k < cnt ? col[(size_t)k * step] : 1.0f;
         float acc = 0.f;
         if (q == 0 && chunk == 0 && g.count0 > 0)
             acc = carry_in[(size_t)band * n + bin];
@@ -454,7 +482,7 @@ __global__ __launch_bounds__(kRefineThreads) void k_cum_refine(float *__restrict
                 // (dynamic index into registers: select through a rotate of the arrays would cost more than this rare loop
                 // is worth - the values are re-read from memory instead)
                 if (k < cnt) {
-                    const float x = __builtin_nontemporal_load(base + (off + (unsigned)k * (unsigned)n));
+                    const float x = col[(size_t)k * step];
                     float t;
                     if (!gomath::psd_value_in_db_fast(x, tab, &t)) {
                         t = db_slow(x, inv_n2);
@@ -730,7 +758,7 @@ hipError_t launch_spectrum_row(const float *psd_row, float *out, int n, hipStrea
 
 hipError_t launch_find_peaks(float *cum, const float *psd, const void *db_tab, const float *carry0, const float *carry1, int carry_in,
                              const sdr_frame_rec *recs, DevPeak *peaks, int *counts, const BatchCursor *cur, PeakGeom g, int n_frames,
-                             int n_chunks, int n_bands, hipStream_t stream)
+                             int n_chunks, int n_bands, FftTap tap, hipStream_t stream)
 {
     if (n_chunks == 0)
         return hipSuccess;
@@ -766,10 +794,11 @@ hipError_t launch_find_peaks(float *cum, const float *psd, const void *db_tab, c
         const bool wide = wide_env >= 0 ? wide_env != 0 : (g.n >= 4096 && (long)n_chunks * n_bands >= 64);
         if (wide)
             hipLaunchKernelGGL((k_cum_refine<16384, 1024>), dim3(n_chunks, (g.n + 16383) / 16384, n_bands), dim3(1024), 0, stream, cum, psd, db_tab,
-                               carry0, carry1, carry_in, recs, cur, g, n_frames, inv_n2);
+                               carry0, carry1, carry_in, recs, cur, g, n_frames, inv_n2, tap.wide, tap.used, tap.n, tap.stride);
         else
             hipLaunchKernelGGL((k_cum_refine<kRefineSpan, kRefineThreads>), dim3(n_chunks, (g.n + kRefineSpan - 1) / kRefineSpan, n_bands),
-                               dim3(kRefineThreads), 0, stream, cum, psd, db_tab, carry0, carry1, carry_in, recs, cur, g, n_frames, inv_n2);
+                               dim3(kRefineThreads), 0, stream, cum, psd, db_tab, carry0, carry1, carry_in, recs, cur, g, n_frames, inv_n2, tap.wide,
+                               tap.used, tap.n, tap.stride);
     }
     t_done_event = done;
     const int threads = g.n < kPeakThreadsMax ? g.n : kPeakThreadsMax;

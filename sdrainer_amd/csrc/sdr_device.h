@@ -132,6 +132,10 @@ struct FftTap {
     float *out;           // [band][out_stride frames][stride]
     int n;                // slots in use (high-water mark over the bands); 0 = no tap
     int stride;           // max_listeners
+    // k_fft_r32 only (null otherwise): psd at bin - 1, bin, bin + 1 of every slot, [band][out_stride frames][stride][4],
+    // and the bins those rows were taken at, [band][stride] (-1 = none): what k_cum_refine reads instead of psd columns
+    float *wide = nullptr;
+    int32_t *used = nullptr;
 };
 
 hipError_t launch_fft(int logn, const float *iq, const BatchCursor *cur, const fft64::cplx *tw, float *psd, int n_frames,
@@ -187,7 +191,9 @@ __host__ __device__ inline int chunks_completed(int count0, int n_frames)
 hipError_t launch_unpack_be16(const uint8_t *raw, float *out, size_t n_values, hipStream_t stream);
 hipError_t launch_find_peaks(float *cum, const float *psd, const void *db_tab, const float *carry0, const float *carry1, int carry_in,
                              const sdr_frame_rec *recs, DevPeak *peaks, int *counts, const BatchCursor *cur, PeakGeom g, int n_frames,
-                             int n_chunks, int n_bands, hipStream_t stream);
+                             int n_chunks, int n_bands, FftTap tap, hipStream_t stream);  // tap: .wide / .used / .n / .stride of this batch's FFT (or null)
+// does launch_fft, called like this, leave the wide tap (k_fft_r32 does; the sixteen-point kernels do not)?
+bool fft_writes_wide_tap(int logn, int n_frames, int n_bands, int tap_n);
 hipError_t launch_cumulation_row(const float *psd_band, const void *db_tab, const float *carry_in_band, float *row_out, CumGeom g, int slot,
                                  hipStream_t stream);
 

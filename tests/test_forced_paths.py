@@ -19,7 +19,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = "test_receiver_run_bit_exact or test_nine_window_geometry or test_config5_geometry or test_batch_split_invariance_and_carry"
+SMALL = ("test_receiver_run_bit_exact or test_nine_window_geometry or test_config5_geometry or test_batch_split_invariance_and_carry"
+         " or test_scan_segment_geometries")
 
 
 @pytest.mark.parametrize("env, files, sel", [
@@ -33,6 +34,10 @@ SMALL = "test_receiver_run_bit_exact or test_nine_window_geometry or test_config
      SMALL + " or config5 or config2"),
     # the randomised streams and cuts of the fuzz test through the cumulation's bound-and-refine path and the wide
     # refinement workgroups (its batches are far too short to pick either by themselves: round 4's advice)
+    # k_fft_r32 and its wide tap on batches far too short to pick them, under the bound-and-refine path: listeners'
+    # columns from the wide tap, a signal without a listener from the psd array, both refinement shapes
+    ({"SDR_FFT_R32": "1", "SDR_CUM_BOUND": "1", "SDR_REFINE_WIDE": "1"}, ["tests/test_gpu_parity.py"], "test_scan_segment_geometries"),
+    ({"SDR_FFT_R32": "1", "SDR_CUM_BOUND": "1", "SDR_REFINE_WIDE": "0"}, ["tests/test_gpu_parity.py"], "test_scan_segment_geometries"),
     ({"SDR_CUM_BOUND": "1", "SDR_REFINE_WIDE": "1"}, ["tests/test_gpu_fuzz.py"], "random_streams"),
     ({"SDR_CUM_BOUND": "1", "SDR_REFINE_WIDE": "0", "SDR_NOISE_PATH": "chains", "SDR_VAR_MFMA": "0"}, ["tests/test_gpu_fuzz.py"], "random_streams"),
 ])

@@ -409,6 +409,32 @@ def test_nine_window_geometry(capi):
     bank.close()
 
 
+@pytest.mark.parametrize("n, edge", [(16384, 100), (16384, 101), (8192, 33), (4096, 1), (2048, 3), (1024, 7), (512, 71), (16384, 2243)])
+def test_scan_segment_geometries(capi, n, edge):
+    """k_psd_scan cuts a row into the reference's windows and pieces of the two edges, and reads each segment by 16-byte
+    loads for whole groups of 256 bins plus dword loads for the rest: windows that start on odd bins (the 16-byte loads are
+    only dword-aligned then), the widest windows a block size allows (N = 16384 with a narrow edge: more than 1216 bins, the
+    kernel's largest instantiation), windows narrower than one group (N <= 2048: dword loads only), edges shorter than a
+    piece.  Records, peaks and a whole cumulation row against the oracle; tests/test_forced_paths.py runs the same cases with
+    the cumulation's bound forced on, which is what writes the unit counts through the same lane-to-bin map."""
+    rate = 48000
+    frames = 230 if n <= 4096 else 130
+    iq, bins, _ = synth.make_band(frames, rate, n, 3, seed=n + edge, edge_width=edge)
+    ref = orc.Receiver(rate, n, edge)
+    bank = capi.Bank(rate, n, edge_width=edge, max_batch_frames=256, max_listeners=4, max_peaks=64)
+    for b in bins[:2]:  # (the third signal has no listener: with the wide tap in use, its column comes from the psd array)
+        ref.attach(int(b))
+        bank.attach(0, int(b))
+    out = ref.process(iq)
+    bank.process_host(iq)
+    _assert_records_equal(bank.read_frame_records(0), out["frames"])
+    assert len(out["peaks"]) >= 1
+    for c in range(len(out["peaks"])):
+        assert bank.read_peaks(0, c)[0] == out["peaks"][c], c
+        assert _bits_equal(bank.read_cumulation(0, c), out["cumulation"][c]), c
+    bank.close()
+
+
 def _nan_equal_bits(a, b):
     a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
     both_nan = np.isnan(a) & np.isnan(b)  # the sign / payload of a NaN is not part of the contract

@@ -73,6 +73,7 @@ int main(int argc, char **argv)
     CK(hipMemset(pd32, 0xee, total * N * 4));
     const int n_tap = getenv("SDR_TAP") ? atoi(getenv("SDR_TAP")) : 256;
     sdr::FftTap tap16{nullptr, nullptr, n_tap, n_tap > 0 ? n_tap : 1}, tap32 = tap16;
+    std::vector<int32_t> host_bins;
     float *dout16 = nullptr, *dout32 = nullptr;
     if (n_tap > 0) {
         std::vector<int32_t> bins((size_t)n_tap * bands);
@@ -89,6 +90,13 @@ int main(int argc, char **argv)
         tap16.bins = tap32.bins = dbins;
         tap16.out = dout16;
         tap32.out = dout32;
+        if (!(getenv("SDR_WIDE") && atoi(getenv("SDR_WIDE")) == 0)) {  // the wide tap (k_fft_r32 only)
+            CK(hipMalloc(&tap32.wide, total * 4 * n_tap * 4));
+            CK(hipMemset(tap32.wide, 0xdd, total * 4 * n_tap * 4));
+            CK(hipMalloc(&tap32.used, (size_t)bands * n_tap * 4));
+            CK(hipMemset(tap32.used, 0x77, (size_t)bands * n_tap * 4));
+        }
+        host_bins = bins;
     }
     {
         // wide dynamic range: a strong on-bin carrier, weak noise, a few zeros and subnormals
@@ -142,6 +150,33 @@ int main(int argc, char **argv)
                 tbad += memcmp(&ta[i], &tb[i], 4) != 0;
             printf("tap: %zu of %zu words differ\n", tbad, ta.size());
             rc |= tbad != 0;
+            if (tap32.wide) {
+                // psd at bin - 1, bin, bin + 1 of every slot in use, [frame][slot][4], and the bins they were taken at
+                std::vector<float> w(total * 4 * n_tap);
+                std::vector<int32_t> used((size_t)bands * n_tap);
+                CK(hipMemcpy(w.data(), tap32.wide, w.size() * 4, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(used.data(), tap32.used, used.size() * 4, hipMemcpyDeviceToHost));
+                size_t wbad = 0, ubad = 0, checked = 0;
+                for (size_t i = 0; i < used.size(); i++)
+                    ubad += used[i] != host_bins[i];
+                for (size_t f = 0; f < total; f++) {
+                    const size_t band = f / (size_t)frames;
+                    for (int i = 0; i < n_tap; i++) {
+                        const int bin = host_bins[band * n_tap + i];
+                        if (bin < 0)
+                            continue;
+                        for (int c = 0; c < 3; c++) {
+                            const int nb = bin + c - 1;
+                            if (nb < 0 || nb >= N)
+                                continue;
+                            checked++;
+                            wbad += memcmp(&w[(f * n_tap + i) * 4 + c], &b[f * N + nb], 4) != 0;
+                        }
+                    }
+                }
+                printf("wide tap: %zu of %zu words differ, %zu of %zu recorded bins differ\n", wbad, checked, ubad, used.size());
+                rc |= wbad != 0 || ubad != 0;
+            }
         }
     }
     auto time_it = [&](const char *name, auto launch) -> int {
