@@ -95,7 +95,7 @@ copies = [("bench_full.json", f"{tag}_bench_{key}.json"), ("bench_serial.err", f
           ("noise_trace.txt", f"{tag}_noise_consumer_trace.txt"), ("decode_clocks.txt", f"{tag}_decode_stage_clocks.txt"),
           ("ubench_f64.txt", f"{tag}_ubench_f64.txt"), ("ubench_cvt.txt", f"{tag}_ubench_cvt.txt"), ("r32_standalone.txt", f"{tag}_fft_r32_standalone.txt"),
           ("r32_phases.txt", f"{tag}_fft_r32_phase_order.txt"), ("fences.txt", f"{tag}_fences_priced.txt"),
-          ("noise_paths.txt", f"{tag}_noise_scan_vs_chains.txt")]
+          ("noise_paths.txt", f"{tag}_noise_scan_vs_chains.txt"), ("box_probe.txt", f"{tag}_box_probe.txt")]
 for src, dst in copies:
     s = os.path.join(G, src)
     if os.path.exists(s) and os.path.getsize(s) > 0:

@@ -50,6 +50,11 @@ fi
 [ "$PART" = fft ] && { echo "fft part done"; exit 0; }
 
 # 3. the whole pipeline: kernel trace, HBM traffic (separate PMC passes), bench lines
+# (the boxes of the pool differ by up to 7 %: the standalone FFT launch says which kind this one is, and the figure goes
+# into the collection; MAX_PROBE_MS=<ms> gives a slow box back at once instead of spending the round's GPU budget on it)
+PROBE=$(SDR_R32_ONLY=1 timeout -k 5 90 tools/bin/r32_prod 8192 1 | grep -o "back to back: [0-9.]*" | tail -1 | awk '{print $4}')
+echo "box probe: k_fft_r32 standalone, 8192 frames, back to back: $PROBE ms per launch (this round's boxes: 0.502 ... 0.545)" | tee $O/box_probe.txt
+if [ -n "$MAX_PROBE_MS" ] && [ "$(python3 -c "print(int(float('${PROBE:-9}') > float('$MAX_PROBE_MS')))")" = 1 ]; then echo "slow box: given back"; exit 7; fi
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/rocprof_bench.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace_c5 -o t --output-format csv -- python3 bench.py --workload c5 --steps 150 --warmup 15 --no-cpu-baseline > $O/rocprof_bench_c5.log 2>&1
 echo "kernel trace done"
