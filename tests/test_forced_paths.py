@@ -38,6 +38,10 @@ SMALL = ("test_receiver_run_bit_exact or test_nine_window_geometry or test_confi
     # columns from the wide tap, a signal without a listener from the psd array, both refinement shapes
     ({"SDR_FFT_R32": "1", "SDR_CUM_BOUND": "1", "SDR_REFINE_WIDE": "1"}, ["tests/test_gpu_parity.py"], "test_scan_segment_geometries"),
     ({"SDR_FFT_R32": "1", "SDR_CUM_BOUND": "1", "SDR_REFINE_WIDE": "0"}, ["tests/test_gpu_parity.py"], "test_scan_segment_geometries"),
+    ({"SDR_FFT_R32": "1", "SDR_CUM_BOUND": "1", "SDR_FUZZ_N": "16384", "SDR_FUZZ_SEEDS": "6"}, ["tests/test_gpu_fuzz.py"], "random_streams"),
+    # config 3's 256 listeners x 2048 frames with the bound forced on: the refinement reads 768 columns per cumulation from
+    # the wide tap, and the peaks are the oracle's
+    ({"SDR_CUM_BOUND": "1"}, ["tests/test_gpu_parity_bench_sizes.py"], "config3"),
     ({"SDR_CUM_BOUND": "1", "SDR_REFINE_WIDE": "1"}, ["tests/test_gpu_fuzz.py"], "random_streams"),
     ({"SDR_CUM_BOUND": "1", "SDR_REFINE_WIDE": "0", "SDR_NOISE_PATH": "chains", "SDR_VAR_MFMA": "0"}, ["tests/test_gpu_fuzz.py"], "random_streams"),
 ])

@@ -30,8 +30,10 @@ def _bits_equal(a, b):
 def test_random_streams_and_cuts(capi, seed):
     rng = np.random.default_rng(4242 + seed)
     n = int(rng.choice([512, 1024, 2048]))
-    rate = {512: 48000, 1024: 96000, 2048: 192000}[n]
-    frames = int(rng.integers(230, 620))
+    if os.environ.get("SDR_FUZZ_N"):  # (tests/test_forced_paths.py: N = 16384 through k_fft_r32 and its wide tap)
+        n = int(os.environ["SDR_FUZZ_N"])
+    rate = {512: 48000, 1024: 96000, 2048: 192000}.get(n, 2_000_000)
+    frames = int(rng.integers(230, 620 if n <= 2048 else 420))
     tones = int(rng.integers(2, 11))
     debounce = int(rng.choice([1, 1, 2, 3, 5]))
     weak = bool(rng.integers(0, 2))
