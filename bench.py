@@ -88,12 +88,13 @@ def parse():
     return ap.parse_args()
 
 
-def f64_ops_per_sample(n):
-    """float64 add / mul instructions per IQ sample in k_fft_psd and in the whole path, counted in the compiled
-    kernels by tools/count_f64_ops.py (profiles/f64_ops.json); None if the count is missing for this block size."""
+def f64_ops_per_sample(n, r32=False):
+    """float64 add / mul instructions per IQ sample in the FFT kernel and in the whole path, counted in the compiled
+    kernels (tools/count_f64_ops.py for k_fft_psd; k_fft_r32's frame loop in its assembly: profiles/f64_ops.json);
+    None if the count is missing for this block size."""
     path = os.path.join(ROOT, "profiles", "f64_ops.json")
     try:
-        d = json.load(open(path))[str(n)]
+        d = json.load(open(path))[f"{n}_r32" if r32 else str(n)]
         return d["k_fft_psd"], d["whole_path"]
     except (OSError, KeyError, ValueError):
         return None, None
@@ -523,7 +524,7 @@ def main():
     fft_alone_ms = prof_alone["k_fft_psd"][0] / max(prof_alone["k_fft_psd"][1], 1)
     achieved = BYTES_PER_SAMPLE * samples_per_step_rank / (fft_avg_ms * 1e-3) / 1e9
     traffic = measured_traffic(args.workload, frames)
-    ops_fft, ops_path = f64_ops_per_sample(n)
+    ops_fft, ops_path = f64_ops_per_sample(n, r32)
     if args.kernel_breakdown and rank == 0:
         tot = sum(v[0] for v in prof.values())
         for k, (ms, cnt) in prof.items():

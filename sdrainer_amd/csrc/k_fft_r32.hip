@@ -34,14 +34,16 @@
 #if !defined(SDR_R32_CHUNK0)
 #define SDR_R32_CHUNK0 4  // pass 0: scalar twiddles fetched per chunk (a stage's sixteen rows at once are 64 SGPRs)
 #endif
-// The next frame's 32 loads per thread are dealt over the frame (loads per program point; fifteen points: behind the
-// widening, behind each of pass 0's five stages, at the four steps of E0, in front of pass 1, behind pass 1's stages 0-3).
-// Issued in one go - 256 wave instructions, 128 KB per CU - they do not overlap anything: a wave cannot issue a vector
-// memory instruction while the CU's memory pipeline is backed up, and it takes the pipeline 5 us to work a frame off
-// (first build: 13 000 of a frame's 44 000 clocks went into issuing them).  Nothing after pass 1's stage 3: the last
-// group needs time to land before pass 2's twiddle loads, which return behind it (vector memory retires in order).
+// The next frame's 32 loads per thread are dealt over the frame (loads per program point; seventeen points: behind the
+// widening, behind each of pass 0's five stages, at the four steps of E0, in front of pass 1, behind pass 1's stages 0-3,
+// behind pass 2, at the row).  Issued in one go - 256 wave instructions, 128 KB per CU - they do not overlap anything: a
+// wave cannot issue a vector memory instruction while the CU's memory pipeline is backed up, and it takes the pipeline
+// 5 us to work a frame off (first build: 13 000 of a frame's 44 000 clocks went into issuing them).  Two at every point
+// but the first, where the previous frame's row starts to leave: measured 1 % faster than {4, 2 x 14, 0, 0} (nothing
+// behind pass 1's stage 3, so that the last group lands before pass 2's twiddle loads, which return behind it), and the
+// kernel compiles without a spilled vector register this way.
 #if !defined(SDR_R32_PF_PLAN)
-#define SDR_R32_PF_PLAN {4, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 0, 0}
+#define SDR_R32_PF_PLAN {0, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2}
 #endif
 // Issue priority, alternating between the two waves of a SIMD stage by stage (1; 0 = leave it to the hardware).  The
 // arbiter serves the OLDER of two waves first: waves 0-3 ran a pass at the pace of a wave alone on its SIMD (6.3 clocks per
@@ -57,6 +59,13 @@
 #endif
 #if !defined(SDR_R32_CHUNK1)
 #define SDR_R32_CHUNK1 2  // twiddles fetched per chunk in pass 1 (0: the compiler decides - and spills; 4 / 4 / 4 spills prefetched samples)
+#endif
+#if !defined(SDR_R32_PRIO_FLIP2)
+#define SDR_R32_PRIO_FLIP2 0
+#endif
+#if !defined(SDR_R32_PRIO_FLIP1)
+#define SDR_R32_PRIO_FLIP1 1  // 1: pass 1's stages favour the other half of the workgroup than pass 0's do (0: waves 0-3 lead
+                              // in three of five stages of both passes and then idle at the row's barrier: 1.5 % slower)
 #endif
 #if !defined(SDR_R32_CHUNK2)
 #define SDR_R32_CHUNK2 4
@@ -400,7 +409,7 @@ __global__ __launch_bounds__(fft32::T, 2) void k_fft_r32(const float *__restrict
             run_pass<5, false, SDR_R32_CHUNK1>(
                 xr, xi, [row0](int row, int) { return *reinterpret_cast<const cplx *>(row0 + row * 512); },
                 [&](int q) {
-                    set_prio(q);
+                    set_prio(q + SDR_R32_PRIO_FLIP1);
                     if (q < 4)
                         pf_point(PF_PASS1 + q);
                     if (q == 3)
@@ -439,9 +448,9 @@ __global__ __launch_bounds__(fft32::T, 2) void k_fft_r32(const float *__restrict
         SDR_R32_STAMP(st, RS_E1);
 
 #if SDR_R32_DEPTH2 == 2
-        run_pass2_with<4, false, SDR_R32_CHUNK2>(xr, xi, tw2_first, tw2, [&](int q) { set_prio(q); });
+        run_pass2_with<4, false, SDR_R32_CHUNK2>(xr, xi, tw2_first, tw2, [&](int q) { set_prio(q + SDR_R32_PRIO_FLIP2); });
 #else
-        run_pass_with<4, false, SDR_R32_CHUNK2>(xr, xi, tw2_first, tw2, [&](int q) { set_prio(q); });
+        run_pass_with<4, false, SDR_R32_CHUNK2>(xr, xi, tw2_first, tw2, [&](int q) { set_prio(q + SDR_R32_PRIO_FLIP2); });
 #endif
         pf_point(PF_POST2);
         SDR_R32_STAMP(st, RS_PASS2);
