@@ -410,7 +410,9 @@ int scan_parts(int n_slots, int n_bands)
     static const int forced = getenv("SDR_SCAN_PARTS") ? atoi(getenv("SDR_SCAN_PARTS")) : 0;  // (experiments: 1 or 2)
     if (forced == 1 || forced == 2)
         return forced;
-    return (long)n_slots * n_bands < 160 ? 2 : 1;
+    // (two parts while the slots alone are fewer than a quarter of the CUs; from there on whole slots: with 16-byte loads a
+    // workgroup walks a frame in 1.6 us, and 83 fat workgroups hold less CU time than 166 - config 3: 205.5 -> 209.7 GS/s)
+    return (long)n_slots * n_bands < 64 ? 2 : 1;
 }
 
 static int scan_jmax(int window)
