@@ -449,7 +449,9 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    t_enq = time.perf_counter()
     torch.cuda.synchronize()
+    t_gpu = time.perf_counter()
     if delivery:
         take(wait=True)  # the last batches' results, still inside the timed region
     own_elapsed = time.perf_counter() - t0  # this rank alone: a straggling GPU shows here, not in the max below
@@ -526,6 +528,8 @@ def main():
     traffic = measured_traffic(args.workload, frames)
     ops_fft, ops_path = f64_ops_per_sample(n, r32)
     if args.kernel_breakdown and rank == 0:
+        print("  timed region: enqueued after %.3f ms, device idle after %.3f ms, last batch delivered after %.3f ms" %
+              ((t_enq - t0) * 1e3, (t_gpu - t0) * 1e3, own_elapsed * 1e3), file=sys.stderr)
         tot = sum(v[0] for v in prof.values())
         for k, (ms, cnt) in prof.items():
             print(f"  {k:16s} {ms / max(cnt, 1):9.3f} ms/launch  {100 * ms / max(tot, 1e-9):5.1f}%", file=sys.stderr)
