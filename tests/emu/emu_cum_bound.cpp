@@ -101,6 +101,30 @@ int main()
             }
             const float ub = gomath::cum_bound(count0 ? (double)carry : 0.0, units, 100 - count0, a128, per_frame, special);
             columns++;
+            // Round 5: the unit counts are formed by k_psd_scan and put together by k_bound_finish (k_noise_scan.hip,
+            // k_peaks.hip) - per value max(bits >> 16, 128) WITHOUT the + 1, the + 1 of every frame added once per run, a
+            // slot's frames dealt over one or two workgroups whose counts are added, and "special" as one running maximum
+            // of bits >> 16 (which a lane shares over all its columns: more columns than needed become +infinity, never
+            // fewer).  The same total, the same flag for this column's own frames:
+            {
+                const int n_run = 100 - count0, split = count0 + (n_run + 1) / 2;
+                uint32_t part[2] = {0, 0}, hw_max = 0;
+                for (int f = count0; f < 100; f++) {
+                    uint32_t bits;
+                    std::memcpy(&bits, &psd[f], 4);
+                    const uint32_t hw = bits >> 16;
+                    part[f < split ? 0 : 1] += hw < 128u ? 128u : hw;
+                    hw_max = hw > hw_max ? hw : hw_max;
+                }
+                part[0] += (uint32_t)(split - count0);
+                part[1] += (uint32_t)(100 - split);
+                const bool sp = hw_max >= 0x7f80u;
+                if (part[0] + part[1] != units || sp != special) {
+                    if (bad++ < 10)
+                        printf("scan order: units %u + %u against %u, special %d against %d (N %d kind %d)\n", part[0], part[1], units, (int)sp,
+                               (int)special, n, kind);
+                }
+            }
             if (std::isnan(exact)) {
                 // a NaN cumulation is never "above" in the reference; ours must reach the exact evaluation or be NaN itself
                 if (!(special || std::isnan(ub) || std::isnan(carry) || std::isinf(carry)))
