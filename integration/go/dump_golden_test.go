@@ -16,9 +16,11 @@
 // A mismatch names the first array that differs; the oracle is then wrong about go-dsp's factor table or about
 // math.Log10 / math.Sincos, and so is the GPU path that is bit-identical to it.
 //
-// Known soft spot (DESIGN.md section 2): the restatement follows the pure-Go math.Log (FreeBSD e_log.c); on amd64 the Go
-// runtime evaluates math.Log in assembly.  If only spectrum_sha256 / nf_in / dev_in differ while psd_sha256 agrees,
-// that is where to look.
+// Known soft spot (DESIGN.md section 2): the restatement follows the pure-Go math.Log (FreeBSD e_log.c) and math.Sincos
+// (Cephes).  As recalled - it could not be checked in the image this was written in - the toolchain the reference's go.mod
+// names (go 1.23) uses those files on amd64 and arm64 (older toolchains had an assembly Log on amd64; s390x still has
+// one).  If only spectrum_sha256 / nf_in / dev_in differ while psd_sha256 agrees, math.Log is where to look; if
+// psd_sha256 differs, go-dsp's factor table (math.Sincos for the odd entries) is.
 package hipgolden
 
 import (
