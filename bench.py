@@ -446,6 +446,9 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    if os.environ.get("SDR_BENCH_PROFILE_TIMED"):  # (development: the library's stage events over the timed region itself)
+        bank.sync()
+        bank.profile_enable(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
